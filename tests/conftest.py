@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return load
+
+
+def smooth_image(B, H, W, seed):
+    """Piece-wise smooth RGB in [0,1] (same recipe as tests/golden/make_golden.py)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    img = torch.zeros(B, 3, H, W)
+    for b in range(B):
+        for c in range(3):
+            for _ in range(4):
+                fy, fx, ph = (torch.rand(3, generator=g) * torch.tensor([3.0, 3.0, 6.28])).tolist()
+                img[b, c] += 0.25 * torch.sin(6.28 * (fy * yy + fx * xx) + ph)
+    img = img * 0.5 + 0.5 + 0.01 * torch.randn(B, 3, H, W, generator=g)
+    return img.clamp(0, 1)

@@ -1,0 +1,175 @@
+"""Pin the CPU oracle against golden vectors captured from the reference's own function bodies
+(tests/golden/make_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle
+
+T = torch.from_numpy
+REL = 1e-4   # oracle vs reference: same fp32 arithmetic, different association
+
+
+def _close(a, b, rel=REL, abs_=1e-7):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    scale = b.abs().max().item()
+    assert (a - b).abs().max().item() <= rel * scale + abs_, ((a - b).abs().max().item(), scale)
+
+
+def test_ncut_loss_and_grad(golden):
+    g = golden("losses")
+    meta = [m for m in json.loads(str(g["meta"])) if m["kind"] == "ncut"]
+    assert len(meta) == 4
+    for m in meta:
+        i = m["idx"]
+        preds = T(g[f"ncut{i}_preds"]).requires_grad_()
+        loss = oracle.LocalNormalizedCutLoss(m["sigma_color"], m["window"])(preds, T(g[f"ncut{i}_image"]))
+        loss.backward()
+        _close(loss.detach(), g[f"ncut{i}_loss"])
+        _close(preds.grad, g[f"ncut{i}_grad"])
+
+
+def test_ncut_3d_path(golden):
+    g = golden("losses")
+    preds = T(g["ncut3d_preds"]).requires_grad_()
+    loss = oracle.LocalNormalizedCutLoss(0.1, 5)(preds, T(g["ncut3d_image"]))
+    loss.backward()
+    _close(loss.detach(), g["ncut3d_loss"])
+    _close(preds.grad, g["ncut3d_grad"])
+
+
+def test_compute_affinities(golden):
+    g = golden("losses")
+    aff = oracle.compute_affinities(T(g["aff_image"]), 0.1, 5, 5)
+    assert len(aff) == 24 and aff[0].shape == (2, 1, 16, 16)
+    _close(torch.stack(aff), g["aff_maps"])
+    single = oracle.ConstrainToBoundaryLossSingle.compute_affinities_single(T(g["aff_image"])[1], 0.1, 5, 5)
+    assert len(single) == 24 and single[0].shape == (1, 16, 16)
+    _close(torch.stack(single)[:, 0], g["aff_maps"][:, 1, 0])
+
+
+def test_boundary_loss_and_grad(golden):
+    g = golden("losses")
+    meta = [m for m in json.loads(str(g["meta"])) if m["kind"] == "boundary"]
+    assert len(meta) == 3
+    for m in meta:
+        i = m["idx"]
+        p = T(g[f"bnd{i}_preds"]).requires_grad_()
+        loss = oracle.ConstrainToBoundaryLossSingle(m["sigma_color"], m["sigma_space"], m["window"])(
+            p, T(g[f"bnd{i}_image"]))
+        loss.backward()
+        _close(loss.detach(), g[f"bnd{i}_loss"])
+        _close(p.grad, g[f"bnd{i}_grad"])
+
+
+def test_layercam_epilogue_both_variants(golden):
+    g = golden("layercam")
+    for i in range(2):
+        acts = [T(g[f"act_layer3_{i}"]), T(g[f"act_layer4_{i}"])]
+        grads = [T(g[f"grad_layer3_{i}"]), T(g[f"grad_layer4_{i}"])]
+        for a in (0.5, 1.0, 2.0):
+            _close(oracle.layercam_epilogue(acts, grads, (224, 224), a, "modular"), g[f"modular_cam_{i}_a{a}"],
+                   rel=1e-5)
+        for a in (0.5, 2.0):
+            _close(oracle.layercam_epilogue(acts, grads, (224, 224), a, "notebook"), g[f"notebook_cam_{i}_a{a}"],
+                   rel=1e-5)
+
+
+class _Toy(nn.Module):
+    def __init__(self, c3=48, c4=96, nc=7):
+        super().__init__()
+        self.stem = nn.Sequential(nn.Conv2d(3, 16, 3, 2, 1), nn.ReLU(), nn.Conv2d(16, 32, 3, 2, 1), nn.ReLU())
+        self.layer3 = nn.Sequential(nn.Conv2d(32, c3, 3, 2, 1), nn.ReLU())
+        self.layer4 = nn.Sequential(nn.Conv2d(c3, c4, 3, 1, 2, dilation=2), nn.ReLU())
+        self.fc = nn.Linear(c4, nc)
+
+    def forward(self, x):
+        f3 = self.layer3(self.stem(x))
+        f4 = self.layer4(f3)
+        return self.fc(f4.mean(dim=(2, 3))), [f3, f4]
+
+
+def test_layercam_generator_hooks(golden):
+    g = golden("layercam")
+    net = _Toy()
+    net.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("state/")})
+    imgs = T(g["images"])
+    for variant in ("modular", "notebook"):
+        gen = oracle.LayerCAMGenerator(net, ["layer3", "layer4"], variant=variant)
+        for i in range(2):
+            ci = torch.tensor([int(g["class_idx"][i])])
+            cam = gen.generate(imgs[i], alpha=2.0, class_idx=ci)
+            assert cam.shape == (1, 224, 224)
+            _close(cam, g[f"{variant}_cam_{i}_a2.0"], rel=1e-4)
+        _close(gen.generate(imgs[0]), g[f"{variant}_cam_argmax"], rel=1e-4)   # argmax default
+    # notebook keyword order generate(images, class_idx, alpha) is accepted too
+    gen = oracle.LayerCAMGenerator(net, ["layer3", "layer4"], variant="notebook")
+    _close(gen.generate(imgs[1], torch.tensor([4]), 0.5), g["notebook_cam_1_a0.5"], rel=1e-4)
+    _close(gen(imgs[1], class_idx=torch.tensor([4]), alpha=0.5), g["notebook_cam_1_a0.5"], rel=1e-4)
+
+
+def test_keep_largest_bit_exact(golden):
+    g = golden("keep_largest")
+    names = [k[3:] for k in g.files if k.startswith("in_")]
+    assert {"diag", "tie", "tie_flipped", "empty", "full", "rand224"} <= set(names)
+    for n in names:
+        out = oracle.keep_largest(g["in_" + n])
+        assert out.dtype == np.uint8 and np.array_equal(out, g["out_" + n]), n
+
+
+def test_refine_pseudo_mask(golden):
+    g = golden("refine_metrics")
+    logits = T(g["logits"])
+
+    class Stub(nn.Module):
+        def forward(self, x):
+            return {"out": logits.unsqueeze(0)}
+
+    img, mask = T(g["image"]), T(g["mask"])
+    r = oracle.refine_pseudo_mask(Stub(), img, mask, threshold=0.3, lr=1e-4, num_steps=10)
+    assert np.array_equal(r.numpy(), g["refined_callsite"])
+    r = oracle.refine_pseudo_mask(Stub(), img, mask)
+    assert np.array_equal(r.numpy(), g["refined_default"])
+    r = oracle.refine_pseudo_mask(Stub(), img, mask, lr=0.5, num_steps=12, threshold=0.5)
+    assert (r.numpy() != g["refined_lr0.5"]).mean() <= 0.002      # large-lr case: near-threshold pixels
+    assert not np.array_equal(g["refined_lr0.5"], (g["mask"] == 255).astype(np.float32))
+
+
+def test_metrics(golden):
+    g = golden("refine_metrics")
+    iou, acc = oracle.compute_iou_and_acc(T(g["metric_pred"]), T(g["metric_true"]))
+    assert abs(iou - g["metric_iou_acc"][0]) < 1e-12 and abs(acc - g["metric_iou_acc"][1]) < 1e-12
+
+
+def test_model_structure_selfchecks():
+    """torchvision is absent: pin the restated architectures by their published parameter counts."""
+    n = lambda m: sum(p.numel() for p in m.parameters())
+    assert n(oracle.ResNet50Trunk()) == 25_557_032
+    assert n(oracle.DeepLabV3ResNet50(21, True)) == 42_004_074
+    seg = oracle.build_segmentation_model()
+    assert n(seg) == 41_999_191
+    assert sum(p.numel() for k, p in seg.named_parameters() if not k.startswith("aux_")) == 39_633_986
+    cam = oracle.FrozenResNetCAM()
+    assert n(cam) == 23_583_845
+    assert [k for k, p in cam.named_parameters() if p.requires_grad] == ["fc.weight", "fc.bias"]
+    keys = set(seg.state_dict())
+    for k in ("backbone.layer4.2.conv3.weight", "classifier.0.convs.4.1.weight", "classifier.0.project.1.running_var",
+              "classifier.4.bias", "aux_classifier.4.weight", "backbone.layer2.0.downsample.1.weight"):
+        assert k in keys, k
+    assert {"layer0.0.weight", "layer0.1.running_mean", "layer4.0.downsample.0.weight", "fc.bias"} <= set(cam.state_dict())
+
+
+def test_model_shapes_small():
+    torch.manual_seed(0)
+    seg = oracle.build_segmentation_model().eval()
+    with torch.no_grad():
+        out = seg(torch.randn(1, 3, 64, 64))
+    assert out["out"].shape == (1, 2, 64, 64) and out["aux"].shape == (1, 21, 64, 64)
+    cam = oracle.FrozenResNetCAM().eval()
+    with torch.no_grad():
+        logits, feats = cam(torch.randn(1, 3, 64, 64))
+    assert logits.shape == (1, 37)
+    assert [tuple(f.shape[1:]) for f in feats] == [(512, 8, 8), (1024, 4, 4), (2048, 4, 4)]
