@@ -1,0 +1,200 @@
+/*
+ * wsdl_hip.h - C ABI of libwsdl_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * weakly-supervised segmentation hot path of alexncoleman/WeaklySupervisedDL.
+ *
+ * The reference has no FFI of its own: every operator below is a chain of PyTorch ATen ops reached
+ * from Python (reference file:line cited per entry point, relative to the reference root).  These
+ * entry points are what a binding for that path binds instead; INTEGRATION.md shows the ctypes stubs.
+ *
+ * Conventions
+ *   - every tensor is fp32, contiguous NCHW unless a *_bs (batch stride, in elements) says otherwise;
+ *     labels are int64 (the host API's dtype), masks uint8;
+ *   - all pointers are caller-owned DEVICE pointers; the library allocates nothing persistent,
+ *     scratch is an explicit caller-sized workspace (see the *_workspace functions);
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as void*), re-entrant across
+ *     streams, and performs no host synchronisation: launches can be captured into a hipGraph;
+ *   - return value 0 = OK, negative = WSDL_E* ; wsdl_last_error() returns a thread-local message.
+ *     Geometry is validated on the host before any launch; a rejected call launches nothing.
+ */
+#ifndef WSDL_HIP_H
+#define WSDL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* wsdl_stream_t; /* hipStream_t */
+
+enum {
+    WSDL_OK = 0,
+    WSDL_EINVAL = -1,      /* bad geometry / null pointer / unsupported size */
+    WSDL_EHIP = -2,        /* a HIP runtime call failed (message holds hipGetErrorString) */
+    WSDL_EWORKSPACE = -3   /* workspace too small */
+};
+
+const char* wsdl_last_error(void);
+int wsdl_version(void);               /* 10000*major + 100*minor + patch */
+const char* wsdl_target_arch(void);   /* "gfx950" */
+
+/* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
+ * When enabled every launch of the instrumented classes is bracketed by hipEventRecord on the
+ * launch stream.  wsdl_prof_collect synchronises the events and returns, per class, the number of
+ * launches, summed milliseconds and summed algorithmic work (flops for conv classes, bytes else). */
+enum { WSDL_PROF_CONV_FWD = 0, WSDL_PROF_CONV_DGRAD = 1, WSDL_PROF_CONV_WGRAD = 2,
+       WSDL_PROF_PAIRWISE = 3, WSDL_PROF_LAYERCAM = 4, WSDL_PROF_NCLASSES = 5 };
+int wsdl_prof_enable(int on);
+int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work);
+int wsdl_prof_reset(void);
+
+/* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------
+ * Replaces the ATen conv2d forward / input-gradient / weight-gradient reached from
+ *   torchvision ResNet-50 and DeepLabV3 convs called at TraditionalModel/ClassificationModel.py:29-33,
+ *   TraditionalModel/SegmentationModel.py:102,110, TraditionalModel/AlternatingDirectionCutLoss.py:697-703,
+ *   and the class-logit backward at TraditionalModel/LayerCAM.py:48.
+ * Square kernels, one stride / padding / dilation for both spatial dims, groups = 1.
+ *   OH = (H + 2*pad - dil*(kh-1) - 1)/stride + 1 (same for OW).                                   */
+
+/* Re-layout w[Cout][Cin][kh][kw] for the kernels: wt_fwd[(tap*Cin+ci)][Cout], wt_dgrad[(tap*Cout+co)][Cin].
+ * Either destination may be NULL. */
+int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad,
+                             int Cout, int Cin, int kh, int kw, wsdl_stream_t stream);
+
+/* y = act( scale[co]*conv(x) + shift[co] + residual ), any of scale/shift/residual may be NULL
+ * (scale NULL = 1, shift NULL = 0).  relu != 0 applies max(.,0).  x_bs / y_bs / res_bs: batch strides
+ * in elements (0 = dense).  Folded eval-mode BatchNorm, conv bias and the Linear layer (a 1x1 conv on
+ * a 1x1 map) all go through scale/shift. */
+int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y,
+                    int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                    int stride, int pad, int dil,
+                    const float* scale, const float* shift, const float* residual, int relu,
+                    long long x_bs, long long y_bs, long long res_bs, wsdl_stream_t stream);
+
+/* dx = conv_transpose(dy, w)  (+ dx if accumulate).  dy is (B,Cout,OH,OW) with batch stride dy_bs. */
+int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx,
+                      int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                      int stride, int pad, int dil, int accumulate,
+                      long long dy_bs, wsdl_stream_t stream);
+
+/* dw[Cout][Cin][kh][kw] = sum_{b,oh,ow} dy * x_shifted  (+ dw if accumulate).  Split over pixel
+ * ranges into fp32 slabs in `ws`, summed in fixed order by a second kernel (bitwise reproducible). */
+size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                   int stride, int pad, int dil);
+int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw,
+                      int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                      int stride, int pad, int dil, int accumulate,
+                      long long x_bs, long long dy_bs,
+                      void* ws, size_t ws_bytes, wsdl_stream_t stream);
+
+/* dbias[co] = sum_{b,hw} dy  (classifier[4] / fc bias gradient). */
+int wsdl_bias_grad(const float* dy, float* dbias, int B, int C, int HW, long long dy_bs,
+                   int accumulate, wsdl_stream_t stream);
+
+/* ---- BatchNorm2d (train-mode batch statistics; torchvision BN inside the models above) ------ */
+size_t wsdl_bn_workspace(int C);
+/* y = act( (x-mean)*invstd*gamma + beta + residual ); saves mean / invstd (biased var), updates
+ * running_mean / running_var (unbiased var, momentum) when they are non-NULL. */
+int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                      float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                      float momentum, float eps, int B, int C, int HW,
+                      const float* residual, int relu, long long y_bs,
+                      void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* Backward of the above.  y (the forward output) is needed only when relu != 0 (mask = y > 0).
+ * dres (optional) receives the masked upstream gradient (the residual branch's gradient). */
+int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+                      const float* save_mean, const float* save_invstd,
+                      float* dx, float* dgamma, float* dbeta, float* dres,
+                      int B, int C, int HW, int relu, int accumulate_param_grads,
+                      long long dy_bs, long long y_bs,
+                      void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (fed to wsdl_conv2d_fwd). */
+int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* scale, float* shift, int C,
+                 wsdl_stream_t stream);
+/* backward of y = act(scale*conv + shift + res) wrt conv: dconv = dy*[y>0]*scale ; dres = dy*[y>0] */
+int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, float* dconv, float* dres,
+                        int B, int C, int HW, int relu, wsdl_stream_t stream);
+
+/* ---- pooling / resampling / elementwise ----------------------------------------------------- */
+/* MaxPool2d(3, stride 2, pad 1) as in ResNet's stem; argmax (0..8, first max wins) kept as uint8 */
+int wsdl_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int BC, int H, int W,
+                          wsdl_stream_t stream);
+int wsdl_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int BC, int H, int W,
+                          wsdl_stream_t stream);
+/* AdaptiveAvgPool2d(1) */
+int wsdl_global_avgpool_fwd(const float* x, float* y, int BC, int HW, wsdl_stream_t stream);
+int wsdl_global_avgpool_bwd(const float* dy, float* dx, int BC, int HW, int accumulate,
+                            wsdl_stream_t stream);
+/* F.interpolate(mode='bilinear', align_corners=False): (BC,h,w) -> (BC,H,W).  y_bs/C: output may be a
+ * channel slice of a wider tensor (C planes per image, batch stride y_bs elements; 0 = dense). */
+int wsdl_bilinear_fwd(const float* x, float* y, int B, int C, int h, int w, int H, int W,
+                      long long y_bs, wsdl_stream_t stream);
+int wsdl_bilinear_bwd(const float* dy, float* dx, int B, int C, int h, int w, int H, int W,
+                      long long dy_bs, wsdl_stream_t stream);
+/* Dropout: mask is uint8 0/1.  If gen_mask != 0 the mask is drawn (counter hash of seed, element
+ * index) and written; else it is read (injected mask, parity tests).  y = x*mask/(1-p). */
+int wsdl_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p,
+                     unsigned long long seed, int gen_mask, wsdl_stream_t stream);
+int wsdl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, size_t n, float p,
+                     wsdl_stream_t stream);
+/* y = a + b (optionally relu), y = alpha*x, strided channel-slice copy */
+int wsdl_add(const float* a, const float* b, float* y, size_t n, int relu, wsdl_stream_t stream);
+int wsdl_scale_by_device_scalar(const float* x, const float* s, float* y, size_t n, wsdl_stream_t stream);
+int wsdl_copy_planes(const float* src, float* dst, int B, int C, int HW, long long src_bs,
+                     long long dst_bs, wsdl_stream_t stream);
+
+/* ---- losses --------------------------------------------------------------------------------- */
+size_t wsdl_reduce_workspace(void);
+/* nn.CrossEntropyLoss() on (B,C,H,W) logits and int64 (B,H,W) labels, mean over B*H*W
+ * (TraditionalModel/SegmentationModel.py:90,107; AlternatingDirectionCutLoss.py:789,699).
+ * dlogits (optional) = grad_scale * (softmax - onehot)/(B*H*W). */
+int wsdl_softmax_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                            int B, int C, int H, int W, float grad_scale,
+                            void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* Pairwise-affinity loss over a reflect-padded window x window neighbourhood:
+ *   apply_softmax=1, normalise=0, sigma_space<=0 : LocalNormalizedCutLoss.forward
+ *                                  (TraditionalModel/AlternatingDirectionCutLoss.py:65-105)
+ *   apply_softmax=0, normalise=1                 : ConstrainToBoundaryLossSingle.forward
+ *                                  (TraditionalModel/AlternatingDirectionBoundaryLoss.py:12-70)
+ * loss: 1 float (normalise=0) or B floats (normalise=1).  dpreds (optional) = d loss / d preds for
+ * an upstream gradient of 1 (per image for normalise=1). */
+int wsdl_pairwise_affinity_loss_fwd_bwd(const float* preds, const float* image, float* loss,
+                                        float* dpreds, int B, int C, int H, int W, int window,
+                                        float sigma_color, float sigma_space, int apply_softmax,
+                                        int normalise, void* ws, size_t ws_bytes,
+                                        wsdl_stream_t stream);
+size_t wsdl_pairwise_workspace(int B, int H, int W);
+/* compute_affinities (TraditionalModel/AlternatingDirectionCutLoss.py:612-637): K=(w*w-1) maps,
+ * out[(k*B + b)*H*W + p]. */
+int wsdl_compute_affinities(const float* image, float* out, int B, int H, int W, int window,
+                            float sigma_color, float sigma_space, wsdl_stream_t stream);
+
+/* ---- LayerCAM epilogue (TraditionalModel/LayerCAM.py:52-76; variant 1 = notebook arithmetic,
+ * AlternatingDirectionCutLoss.py:261-284) + threshold of PsuedoMasks.py:59-62 ------------------
+ * act[l], grad[l]: (B,C[l],h[l],w[l]) device pointers, given as HOST arrays of n_layers entries.
+ * cam: (B,outH,outW).  mask (optional, thresh >= 0): uint8 (cam >= thresh && cam > 0). */
+size_t wsdl_layercam_workspace(int n_layers, int B, const int* C, const int* h, const int* w);
+int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, const int* C,
+                           const int* h, const int* w, int n_layers, int B, int outH, int outW,
+                           float alpha, int variant, float* cam, float thresh, uint8_t* mask,
+                           void* ws, size_t ws_bytes, wsdl_stream_t stream);
+
+/* ---- optimiser: torch.optim.Adam defaults (TraditionalModel/SegmentationModel.py:91,109-111) -
+ * one launch over a flat parameter / gradient buffer; grad_scale folds the 1/world_size of DP. */
+int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, wsdl_stream_t stream);
+
+/* ---- refine_pseudo_mask inner step (TraditionalModel/AlternatingDirectionCutLoss.py:736-757) -
+ * KL(softmax(X) || S) with log(X+1e-8), reduction 'batchmean', and its gradient wrt softmax(X). */
+int wsdl_kl_div_fwd_bwd(const float* xn, const float* s, float* loss, float* dxn, size_t n, int batch,
+                        void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* softmax over C of (B,C,HW) and its backward */
+int wsdl_softmax_fwd(const float* x, float* y, int B, int C, int HW, wsdl_stream_t stream);
+int wsdl_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int HW, wsdl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WSDL_HIP_H */

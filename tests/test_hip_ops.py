@@ -1,0 +1,406 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI via ops.py) against the CPU
+oracle primitives (torch CPU ATen ops - the arithmetic the reference reaches through torchvision) and the
+golden fixtures.  Tolerances: fp32 1e-3 relative (north_star), integer outputs bit-exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def assert_close(a, b, rel=1e-3, what=""):
+    assert tuple(a.shape) == tuple(b.shape), (what, a.shape, b.shape)
+    e = rel_err(a, b)
+    assert e <= rel, f"{what}: rel err {e:.3e} > {rel}"
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 16, 20, 24, 32, 1, 1, 0, 1),
+    (2, 32, 17, 19, 64, 3, 1, 1, 1),
+    (2, 32, 16, 16, 48, 3, 1, 2, 2),       # dilated, Cout not a tile multiple
+    (1, 64, 12, 12, 32, 3, 1, 12, 12),     # ASPP-like: dilation >= feature size on some taps
+    (2, 32, 18, 22, 64, 3, 2, 1, 1),       # stride 2 (layer2.0.conv2)
+    (2, 48, 16, 16, 96, 1, 2, 0, 1),       # 1x1 stride 2 (downsample)
+    (2, 3, 40, 36, 64, 7, 2, 3, 1),        # stem 7x7 s2, Cin=3 (unaligned K)
+    (3, 64, 9, 11, 2, 1, 1, 0, 1),         # classifier[4]: Cout=2
+    (2, 256, 8, 8, 21, 1, 1, 0, 1),        # aux head: Cout=21
+    (4, 128, 1, 1, 37, 1, 1, 0, 1),        # fc as 1x1 conv on a 1x1 map
+    (2, 160, 14, 14, 192, 3, 1, 1, 1),     # Cout = 128 + 64 (two M tiles, second partial)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from weaklysuperviseddl_amd import ops
+    B, Cin, H, W, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, None, s, p, d)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+
+    xd, wd_, dyd = x.to(dev), w.to(dev), dy.to(dev)
+    wf, wdg = ops.prep_weights(wd_)
+    y = ops.conv2d_fwd(xd, wf, w.shape, s, p, d)
+    assert_close(y, yr, what="fwd")
+    dx = ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d)
+    assert_close(dx, xr.grad, what="dgrad")
+    dw = ops.conv2d_wgrad(xd, dyd, w.shape, s, p, d)
+    assert_close(dw, wr.grad, what="wgrad")
+    # accumulate forms
+    dx2 = ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d, accumulate_into=dx.clone())
+    assert_close(dx2, 2 * xr.grad, what="dgrad accumulate")
+    dw2 = ops.conv2d_wgrad(xd, dyd, w.shape, s, p, d, out=dw.clone(), accumulate=True)
+    assert_close(dw2, 2 * wr.grad, what="wgrad accumulate")
+
+
+def test_conv_epilogue_scale_shift_residual_relu(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 10, 10, generator=g)
+    w = torch.randn(64, 32, 3, 3, generator=g) * 0.1
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    res = torch.randn(2, 64, 10, 10, generator=g)
+    ref = F.relu(F.conv2d(x, w, None, 1, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    wf, _ = ops.prep_weights(w.to(dev), True, False)
+    y = ops.conv2d_fwd(x.to(dev), wf, w.shape, 1, 1, 1, sc.to(dev), sh.to(dev), res.to(dev), True)
+    assert_close(y, ref, what="fused epilogue")
+    # strided output (channel slice of a wider tensor)
+    wide = torch.zeros(2, 100, 10, 10, device=dev)
+    ops.conv2d_fwd(x.to(dev), wf, w.shape, 1, 1, 1, out=wide[:, 20:84])
+    assert_close(wide[:, 20:84], F.conv2d(x, w, None, 1, 1, 1), what="sliced output")
+    assert wide[:, :20].abs().max().item() == 0 and wide[:, 84:].abs().max().item() == 0
+
+
+def test_conv_bad_geometry_raises(dev):
+    from weaklysuperviseddl_amd import ops, WsdlError
+    x = torch.randn(1, 8, 4, 4, device=dev)
+    w = torch.randn(8, 8, 3, 3, device=dev)
+    wf, _ = ops.prep_weights(w)
+    with pytest.raises(WsdlError):
+        ops.conv2d_fwd(x, wf, (8, 4, 3, 3), 1, 1, 1)          # channel mismatch
+    with pytest.raises(WsdlError):
+        ops.conv2d_fwd(x, wf, w.shape, 1, 0, 4)               # empty output
+    with pytest.raises(WsdlError):
+        ops.conv2d_fwd(x.cpu(), wf, w.shape, 1, 1, 1)         # host tensor: no CPU fallback
+
+
+@pytest.mark.parametrize("shape,relu,res", [((4, 24, 9, 7), True, True), ((3, 64, 16, 16), True, False),
+                                            ((8, 40, 1, 1), False, False), ((2, 16, 12, 20), False, True)])
+def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 2 + 0.7)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    r = torch.randn(shape, generator=g) if res else None
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    yr = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(shape, generator=g)
+    yr.backward(dy)
+
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    y, mean, invstd = ops.bn_train_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rm_d, rv_d, 0.1, 1e-5,
+                                       r.to(dev) if res else None, relu)
+    assert_close(y, yr, what="bn fwd")
+    assert_close(rm_d, rm_ref, what="running mean")
+    assert_close(rv_d, rv_ref, what="running var")
+    dx, dgamma, dbeta, dres = ops.bn_train_bwd(x.to(dev), dy.to(dev), y, gamma.to(dev), mean, invstd, relu, res)
+    assert_close(dx, xr.grad, what="bn dx")
+    assert_close(dgamma, gr.grad, what="bn dgamma")
+    assert_close(dbeta, br.grad, what="bn dbeta")
+    if res:
+        assert_close(dres, rr.grad, what="bn dres")
+
+
+def test_bn_fold_and_affine_bwd(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(5)
+    C = 20
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.2
+    sc, sh = ops.bn_fold(gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), 1e-5)
+    assert_close(sc, gamma / torch.sqrt(rv + 1e-5), rel=1e-6)
+    assert_close(sh, beta - rm * gamma / torch.sqrt(rv + 1e-5), rel=1e-5)
+    y = torch.randn(2, C, 5, 5, generator=g)
+    dy = torch.randn(2, C, 5, 5, generator=g)
+    dconv, dres = ops.affine_act_bwd(dy.to(dev), y.to(dev), sc, True, True, True)
+    m = (y > 0).float()
+    assert_close(dres, dy * m, rel=1e-6)
+    assert_close(dconv, dy * m * sc.cpu().view(1, -1, 1, 1), rel=1e-6)
+
+
+@pytest.mark.parametrize("hw", [(16, 16), (15, 17), (7, 7), (112, 112)])
+def test_maxpool_fwd_bwd(dev, hw):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(hw[0])
+    x = F.relu(torch.randn(2, 5, *hw, generator=g))     # post-ReLU input: many ties at zero
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_()
+    y = ops.max_pool_3x3_s2(xd)
+    assert torch.equal(y.cpu(), yr.detach())
+    y.backward(dy.to(dev))
+    # ties at zero may route gradient to a different zero element; everything else must agree
+    nz = x > 0
+    assert_close(xd.grad.cpu() * nz, xr.grad * nz, rel=1e-6, what="maxpool dx")
+    assert abs(xd.grad.sum().item() - xr.grad.sum().item()) < 1e-3
+
+
+def test_global_avgpool_and_linear(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(3, 40, 7, 9, generator=g)
+    w, b = torch.randn(11, 40, generator=g) * 0.2, torch.randn(11, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    out_r = F.linear(F.adaptive_avg_pool2d(xr, 1).flatten(1), wr, br)
+    dy = torch.randn(3, 11, generator=g)
+    out_r.backward(dy)
+    xd, wd_, bd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    out = ops.linear(ops.global_avg_pool(xd).flatten(1), wd_, bd)
+    assert_close(out, out_r, what="linear fwd")
+    out.backward(dy.to(dev))
+    assert_close(xd.grad, xr.grad, what="dx")
+    assert_close(wd_.grad, wr.grad, what="dw")
+    assert_close(bd.grad, br.grad, what="db")
+
+
+@pytest.mark.parametrize("shape,size", [((2, 3, 4, 4), (32, 32)), ((1, 2, 14, 14), (224, 224)),
+                                        ((2, 5, 1, 1), (8, 8)), ((1, 2, 7, 9), (20, 31)), ((2, 2, 8, 8), (8, 8))])
+def test_bilinear_fwd_bwd(dev, shape, size):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_()
+    yr = F.interpolate(xr, size=size, mode="bilinear", align_corners=False)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    xd = x.to(dev).requires_grad_()
+    y = ops.bilinear_resize(xd, size)
+    assert_close(y, yr, rel=1e-5, what="bilinear fwd")
+    y.backward(dy.to(dev))
+    assert_close(xd.grad, xr.grad, rel=1e-4, what="bilinear bwd")
+
+
+def test_dropout_injected_mask_and_rng(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 6, 6, generator=g)
+    mask = (torch.rand(x.shape, generator=g) > 0.5).to(torch.uint8)
+    xd = x.to(dev).requires_grad_()
+    y = ops.dropout(xd, 0.5, True, mask=mask.to(dev))
+    assert_close(y, x * mask * 2.0, rel=1e-6)
+    dy = torch.randn(x.shape, generator=g)
+    y.backward(dy.to(dev))
+    assert_close(xd.grad, dy * mask * 2.0, rel=1e-6)
+    big = torch.ones(1 << 20, device=dev).view(1, 1, 1024, 1024)
+    z = ops.dropout(big, 0.5, True, seed=1234)
+    keep = (z > 0).float().mean().item()
+    assert abs(keep - 0.5) < 5e-3 and abs(z.max().item() - 2.0) < 1e-6
+    z2 = ops.dropout(big, 0.5, True, seed=1234)
+    z3 = ops.dropout(big, 0.5, True, seed=1235)
+    assert torch.equal(z, z2) and not torch.equal(z, z3)
+    assert ops.dropout(big, 0.5, False) is big                    # eval: identity
+
+
+def test_concat_and_add(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(2, c, 5, 6, generator=g) for c in (3, 8, 1)]
+    xd = [t.to(dev).requires_grad_() for t in xs]
+    y = ops.concat_channels(xd)
+    assert torch.equal(y.cpu(), torch.cat(xs, 1))
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.to(dev))
+    off = 0
+    for t, c in zip(xd, (3, 8, 1)):
+        assert torch.equal(t.grad.cpu(), dy[:, off:off + c])
+        off += c
+    a, b = xs[1], torch.randn(2, 8, 5, 6, generator=g)
+    ad, bd = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    z = ops.add_act(ad, bd, True)
+    assert_close(z, F.relu(a + b), rel=1e-6)
+    z.backward(torch.ones_like(z))
+    assert_close(ad.grad, ((a + b) > 0).float(), rel=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 16, 16), (3, 5, 9, 13), (1, 21, 8, 8)])
+def test_cross_entropy(dev, shape):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(shape[1])
+    B, C, H, W = shape
+    logits = torch.randn(shape, generator=g) * 3
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    lr = logits.clone().requires_grad_()
+    ref = F.cross_entropy(lr, labels)
+    (ref * 0.7).backward()
+    ld = logits.to(dev).requires_grad_()
+    loss = ops.cross_entropy(ld, labels.to(dev))
+    assert_close(loss, ref.detach(), rel=1e-5, what="ce loss")
+    (loss * 0.7).backward()
+    assert_close(ld.grad, lr.grad, rel=1e-4, what="ce grad")
+
+
+def test_pairwise_loss_vs_golden(dev, golden):
+    from weaklysuperviseddl_amd.TraditionalModel import LocalNormalizedCutLoss, ConstrainToBoundaryLossSingle
+    g = golden("losses")
+    for m in json.loads(str(g["meta"])):
+        i = m["idx"]
+        if m["kind"] == "ncut":
+            preds = T(g[f"ncut{i}_preds"]).to(dev).requires_grad_()
+            loss = LocalNormalizedCutLoss(m["sigma_color"], m["window"])(preds, T(g[f"ncut{i}_image"]).to(dev))
+            loss.backward()
+            assert_close(loss, T(g[f"ncut{i}_loss"]), what=f"ncut{i} loss")
+            assert_close(preds.grad, T(g[f"ncut{i}_grad"]), what=f"ncut{i} grad")
+        else:
+            p = T(g[f"bnd{i}_preds"]).to(dev).requires_grad_()
+            loss = ConstrainToBoundaryLossSingle(m["sigma_color"], m["sigma_space"], m["window"])(
+                p, T(g[f"bnd{i}_image"]).to(dev))
+            loss.backward()
+            assert_close(loss, T(g[f"bnd{i}_loss"]), what=f"bnd{i} loss")
+            assert_close(p.grad, T(g[f"bnd{i}_grad"]), what=f"bnd{i} grad")
+    # 3-D path
+    preds = T(g["ncut3d_preds"]).to(dev).requires_grad_()
+    loss = LocalNormalizedCutLoss(0.1, 5)(preds, T(g["ncut3d_image"]).to(dev))
+    loss.backward()
+    assert_close(loss, T(g["ncut3d_loss"]), what="ncut3d loss")
+    assert_close(preds.grad, T(g["ncut3d_grad"]), what="ncut3d grad")
+
+
+def test_compute_affinities_vs_golden(dev, golden):
+    from weaklysuperviseddl_amd.TraditionalModel import compute_affinities, ConstrainToBoundaryLossSingle
+    g = golden("losses")
+    aff = compute_affinities(T(g["aff_image"]).to(dev), 0.1, 5, 5)
+    assert len(aff) == 24 and tuple(aff[0].shape) == (2, 1, 16, 16)
+    assert_close(torch.stack(aff), T(g["aff_maps"]), rel=1e-5)
+    single = ConstrainToBoundaryLossSingle.compute_affinities_single(T(g["aff_image"])[1].to(dev), 0.1, 5, 5)
+    assert len(single) == 24 and tuple(single[0].shape) == (1, 16, 16)
+    assert_close(torch.stack(single)[:, 0], T(g["aff_maps"])[:, 1, 0], rel=1e-5)
+
+
+@pytest.mark.parametrize("shape,window,space,softmax,norm", [
+    ((2, 2, 64, 96), 5, 0.0, True, 0), ((1, 3, 33, 70), 7, 3.0, True, 0), ((3, 2, 40, 40), 5, 5.0, False, 1),
+    ((2, 4, 3, 50), 5, 5.0, True, 1), ((1, 2, 5, 4), 3, 0.0, False, 0)])
+def test_pairwise_loss_vs_oracle(dev, shape, window, space, softmax, norm):
+    import oracle
+    from conftest import smooth_image
+    from weaklysuperviseddl_amd import ops
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    img = smooth_image(B, H, W, 77)
+    preds = torch.randn(shape, generator=g) * 2
+    if not softmax:
+        preds = F.softmax(preds, 1)
+    pr = preds.clone().requires_grad_()
+    ref = oracle.pairwise_affinity_loss(pr, img, window, 0.1, space, softmax, norm)
+    wts = torch.linspace(0.5, 1.5, ref.numel()).view(ref.shape)
+    (ref * wts).sum().backward()
+    pd = preds.to(dev).requires_grad_()
+    out = ops.pairwise_affinity_loss(pd, img.to(dev), window, 0.1, space, softmax, norm)
+    assert_close(out, ref.detach(), what="loss")
+    (out * wts.to(dev)).sum().backward()
+    assert_close(pd.grad, pr.grad, what="grad")
+
+
+def test_layercam_epilogue_vs_golden(dev, golden):
+    from weaklysuperviseddl_amd import ops
+    g = golden("layercam")
+    for i in range(2):
+        acts = [T(g[f"act_layer3_{i}"]).to(dev), T(g[f"act_layer4_{i}"]).to(dev)]
+        grads = [T(g[f"grad_layer3_{i}"]).to(dev), T(g[f"grad_layer4_{i}"]).to(dev)]
+        for a in (0.5, 1.0, 2.0):
+            cam = ops.layercam_epilogue(acts, grads, (224, 224), a, "modular")
+            assert_close(cam, T(g[f"modular_cam_{i}_a{a}"]), rel=1e-4, what=f"modular a={a}")
+        for a in (0.5, 2.0):
+            cam = ops.layercam_epilogue(acts, grads, (224, 224), a, "notebook")
+            assert_close(cam, T(g[f"notebook_cam_{i}_a{a}"]), rel=1e-4, what=f"notebook a={a}")
+        # fused threshold -> mask indices bit-exact against the golden CAM away from the threshold
+        ref = T(g[f"modular_cam_{i}_a1.0"])[0]
+        cam, mask = ops.layercam_epilogue(acts, grads, (224, 224), 1.0, "modular", thresh=0.3)
+        safe = (ref - 0.3).abs() > 1e-4
+        want = ((ref >= 0.3) & (ref > 0)).to(torch.uint8)
+        assert torch.equal(mask[0].cpu()[safe], want[safe])
+        assert (mask[0].cpu() != want).sum().item() <= (~safe).sum().item()
+
+
+def test_layercam_epilogue_full_size_vs_oracle(dev):
+    """cfg1 shapes: layer3 (B,1024,14,14) + layer4 (B,2048,14,14), B=8."""
+    import oracle
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(21)
+    acts = [F.relu(torch.randn(8, c, 14, 14, generator=g)) for c in (1024, 2048)]
+    grads = [torch.randn(8, c, 14, 14, generator=g) * 1e-3 for c in (1024, 2048)]
+    ref = oracle.layercam_epilogue(acts, grads, (224, 224), 1.0, "modular")
+    cam, mask = ops.layercam_epilogue([a.to(dev) for a in acts], [x.to(dev) for x in grads], (224, 224), 1.0,
+                                      "modular", thresh=0.3)
+    assert_close(cam, ref, rel=1e-4)
+    safe = (ref - 0.3).abs() > 1e-4
+    want = ((ref >= 0.3) & (ref > 0)).to(torch.uint8)
+    assert torch.equal(mask.cpu()[safe], want[safe])
+
+
+def test_adam_matches_torch(dev):
+    from weaklysuperviseddl_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(8)
+    shapes = [(7, 3, 3, 3), (5,), (33, 17), (1,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    ref = [p.clone().requires_grad_() for p in ps]
+    mine = [p.clone().to(dev).requires_grad_() for p in ps]
+    opt_r = torch.optim.Adam(ref, lr=1e-2)
+    opt_m = FlatAdam(mine, lr=1e-2)
+    for step in range(5):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        opt_m.zero_grad()
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        for p, gr in zip(mine, grads):
+            p.grad.copy_(gr.to(dev))
+        opt_r.step()
+        opt_m.step()
+    for a, b in zip(mine, ref):
+        assert_close(a, b, rel=1e-5, what="adam params")
+
+
+def test_softmax_kl(dev):
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 2, 12, 10, generator=g)
+    s = F.softmax(torch.randn(1, 2, 12, 10, generator=g), 1)
+    xr = x.clone().requires_grad_()
+    xn = F.softmax(xr, 1)
+    ref = F.kl_div((xn + 1e-8).log(), s, reduction="batchmean")
+    ref.backward()
+    xd = x.to(dev).requires_grad_()
+    out = ops.kl_div_batchmean(ops.softmax_channels(xd), s.to(dev))
+    assert_close(out, ref.detach(), rel=1e-4)
+    out.backward()
+    assert_close(xd.grad, xr.grad, rel=1e-4)

@@ -1,0 +1,116 @@
+"""LayerCAMGenerator on the HIP path.
+
+Mirrors reference TraditionalModel/LayerCAM.py:7-81 (``variant="modular"``, the default) and the
+notebook twin TraditionalModel/AlternatingDirectionCutLoss.py:216-293 (``variant="notebook"``;
+SURVEY.md D3: extra ``**alpha`` + second min-max per layer, no final power).
+
+What runs where:
+  * the classifier forward and the class-logit backward are the HIP conv / pooling kernels behind
+    ``FrozenResNetCAM`` (eval-mode BN folded into the conv epilogue);
+  * ReLU(grad*act) channel sum, ReLU, per-image min-max, bilinear up-sample to 224x224, layer mean,
+    clamp/pow (and optionally the PsuedoMasks threshold) are ``wsdl_layercam_epilogue``.
+
+``generate(images, alpha=1.0, class_idx=None)`` accepts both reference keyword orders (D2) and
+``__call__`` is an alias.  Two ways to obtain (activation, gradient) pairs:
+  * hook path (any module exposing the named layers; what the reference does - the backward runs all
+    the way to the image);
+  * staged path (default when the model is our FrozenResNetCAM and the targets are among
+    layer3/layer4): layers 0..3 run without a graph and the backward stops at the earliest target's
+    output - the only part of the backward LayerCAM consumes.  Same numbers, ~half the work.
+``generate_batch`` does B images at once (eval-mode BN makes images independent), removing the
+reference's per-image host round trips (``torch.cuda.empty_cache()`` LayerCAM.py:79).
+"""
+import torch
+
+from .. import ops
+from .ClassificationModel import FrozenResNetCAM
+
+_ORDER = ["layer0", "layer1", "layer2", "layer3", "layer4"]
+
+
+class LayerCAMGenerator:
+    def __init__(self, model, target_layer_names=("layer3", "layer4"), variant="modular", out_hw=(224, 224),
+                 staged=None):
+        self.model = model.eval()
+        self.target_layer_names = list(target_layer_names)
+        self.variant = variant
+        self.out_hw = tuple(out_hw)
+        self.activations, self.gradients = {}, {}
+        if staged is None:
+            staged = isinstance(model, FrozenResNetCAM) and all(n in _ORDER[1:] for n in self.target_layer_names)
+        self.staged = staged
+        self._hooks = []
+        if not staged:
+            for name in self.target_layer_names:
+                layer = getattr(self.model, name)
+                self._hooks.append(layer.register_forward_hook(self._fwd(name)))
+                self._hooks.append(layer.register_full_backward_hook(self._bwd(name)))
+
+    def _fwd(self, name):
+        def hook(_m, _inp, out):
+            self.activations[name] = out
+        return hook
+
+    def _bwd(self, name):
+        def hook(_m, _gin, gout):
+            self.gradients[name] = gout[0]
+        return hook
+
+    # -- (activation, gradient) capture ----------------------------------------------------------
+    def _capture_hooks(self, x, class_idx):
+        x = x.detach().clone().requires_grad_()
+        with torch.enable_grad():
+            logits, _ = self.model(x)
+            if class_idx is None:
+                class_idx = logits.argmax(dim=1)
+            score = logits.gather(1, class_idx.view(-1, 1)).squeeze()
+            score.backward(torch.ones_like(score))
+        return logits
+
+    def _capture_staged(self, x, class_idx):
+        m = self.model
+        first = min(_ORDER.index(n) for n in self.target_layer_names)
+        feats = {}
+        with torch.no_grad():
+            h = x
+            for name in _ORDER[:first + 1]:
+                h = getattr(m, name)(h)
+                feats[name] = h
+        with torch.enable_grad():
+            h = h.detach().requires_grad_()
+            feats[_ORDER[first]] = h
+            for name in _ORDER[first + 1:]:
+                h = getattr(m, name)(h)
+                if name in self.target_layer_names:
+                    h.retain_grad()
+                feats[name] = h
+            logits = m.fc(m.avgpool(h).flatten(1))
+            if class_idx is None:
+                class_idx = logits.argmax(dim=1)
+            score = logits.gather(1, class_idx.view(-1, 1)).squeeze()
+            score.backward(torch.ones_like(score))
+        for n in self.target_layer_names:
+            self.activations[n] = feats[n]
+            self.gradients[n] = feats[n].grad
+        return logits
+
+    # -- public API ---------------------------------------------------------------------------------
+    def generate_batch(self, images, alpha=1.0, class_idx=None, thresh=None):
+        """images (B,3,H,W), class_idx LongTensor (B,) or None -> cam (B,outH,outW) [, uint8 mask]."""
+        self.activations.clear()
+        self.gradients.clear()
+        if class_idx is not None:
+            class_idx = class_idx.to(images.device).view(-1)
+        (self._capture_staged if self.staged else self._capture_hooks)(images, class_idx)
+        acts = [self.activations[n].detach() for n in self.target_layer_names]
+        grads = [self.gradients[n].detach() for n in self.target_layer_names]
+        return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
+
+    def generate(self, images, alpha=1.0, class_idx=None):
+        """images (3,H,W) -> (1,outH,outW), as the reference (unsqueeze inside)."""
+        if torch.is_tensor(alpha) and not torch.is_tensor(class_idx):     # notebook order (img, class_idx, alpha)
+            alpha, class_idx = (1.0 if class_idx is None else class_idx), alpha
+        x = images.unsqueeze(0) if images.dim() == 3 else images
+        return self.generate_batch(x, float(alpha), class_idx)
+
+    __call__ = generate

@@ -1,0 +1,138 @@
+"""SegmentationModel (DeepLabV3-ResNet50) on the HIP path.
+
+The reference has no class of this name: it builds
+``torchvision.models.segmentation.deeplabv3_resnet50(pretrained=True)`` and swaps
+``classifier[4] = nn.Conv2d(256, 2, 1)`` (TraditionalModel/SegmentationModel.py:85-88,
+AlternatingDirectionCutLoss.py:784-787), always calling ``model(images)['out']``.  ``SegmentationModel``
+keeps that call surface - ``forward(x)`` returns an OrderedDict with 'out' (and 'aux' while the aux
+head exists) - and torchvision's module / state_dict names (backbone.*, classifier.0.convs.*,
+classifier.0.project.*, classifier.{1,2,4}.*, aux_classifier.{0,1,4}.*).
+
+Architecture (published torchvision definition): ResNet-50 backbone with
+``replace_stride_with_dilation=[False, True, True]`` (output stride 8), DeepLabHead = ASPP(2048,
+rates 12/24/36, + image pooling) -> 1x1 project + Dropout(0.5) -> 3x3 -> 1x1, FCNHead aux classifier
+on layer3 (computed every forward as in the reference, unused by its losses), bilinear up-sampling to
+the input size.  Convolutions, BatchNorm, pooling, dropout, resampling and the loss are HIP kernels.
+
+``train_step`` is one iteration of the reference's training loop (SegmentationModel.py:96-113 /
+AlternatingDirectionCutLoss.py:693-703): clamp masks to {0,1}, forward, CrossEntropy, backward, Adam.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import nn as wnn
+from .. import ops
+from ..optim import FlatAdam
+from .ExtraUtilities import compute_iou_and_acc
+
+
+def _cbr(cin, cout, k, dilation=1):
+    return [wnn.Conv2d(cin, cout, k, padding=0 if k == 1 else dilation, dilation=dilation), wnn.BatchNorm2d(cout),
+            wnn.ReLU()]
+
+
+class _ASPPPooling(wnn.FusedSequential):
+    def __init__(self, cin, cout):
+        super().__init__(wnn.GlobalAvgPool(), *_cbr(cin, cout, 1))
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        return ops.bilinear_resize(super().forward(x), size)
+
+
+class ASPP(nn.Module):
+    def __init__(self, cin=2048, rates=(12, 24, 36), cout=256):
+        super().__init__()
+        branches = [wnn.FusedSequential(*_cbr(cin, cout, 1))]
+        branches += [wnn.FusedSequential(*_cbr(cin, cout, 3, r)) for r in rates]
+        branches.append(_ASPPPooling(cin, cout))
+        self.convs = nn.ModuleList(branches)
+        self.project = wnn.FusedSequential(*_cbr(len(branches) * cout, cout, 1), wnn.Dropout(0.5))
+
+    def forward(self, x):
+        return self.project(ops.concat_channels([b(x) for b in self.convs]))
+
+
+class _Backbone(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1, self.bn1, (self.layer1, self.layer2, self.layer3, self.layer4) = \
+            wnn.make_resnet50_stages((False, True, True))
+        self.relu, self.maxpool = wnn.ReLU(), wnn.MaxPool3x3s2()
+
+    def forward(self, x):
+        x = self.maxpool(wnn.conv_bn(x, self.conv1, self.bn1, True))
+        x = self.layer2(self.layer1(x))
+        f3 = self.layer3(x)
+        return OrderedDict(out=self.layer4(f3), aux=f3)
+
+
+class SegmentationModel(nn.Module):
+    def __init__(self, num_classes=2, aux_loss=True, aux_classes=21):
+        super().__init__()
+        self.backbone = _Backbone()
+        self.classifier = wnn.FusedSequential(ASPP(), *_cbr(256, 256, 3, 1), wnn.Conv2d(256, num_classes, 1, bias=True))
+        self.aux_classifier = None
+        if aux_loss:
+            self.aux_classifier = wnn.FusedSequential(*_cbr(1024, 256, 3, 1), wnn.Dropout(0.1),
+                                                      wnn.Conv2d(256, aux_classes, 1, bias=True))
+        for m in self.modules():
+            if isinstance(m, wnn.Conv2d) and m.bias is not None:
+                m.reset_parameters()
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        feats = self.backbone(x)
+        res = OrderedDict()
+        res["out"] = ops.bilinear_resize(self.classifier(feats["out"]), size)
+        if self.aux_classifier is not None:
+            res["aux"] = ops.bilinear_resize(self.aux_classifier(feats["aux"]), size)
+        return res
+
+
+def build_segmentation_model(num_classes=2, aux_loss=True):
+    """The reference's construction: 21-class DeepLabV3 with aux head, classifier[4] swapped."""
+    return SegmentationModel(num_classes=num_classes, aux_loss=aux_loss, aux_classes=21)
+
+
+def train_step(model, optimizer, images, masks, extra_loss=None):
+    """One training iteration; returns the (device) loss tensor, no host synchronisation."""
+    masks = torch.clamp(masks, max=1)
+    outputs = model(images)["out"]
+    loss = ops.cross_entropy(outputs, masks.long())
+    if extra_loss is not None:
+        loss = loss + extra_loss(outputs, images)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
+
+
+def make_optimizer(model, lr=1e-4):
+    """torch.optim.Adam(model.parameters(), lr) semantics on one flat buffer / one kernel launch."""
+    return FlatAdam([p for p in model.parameters() if p.requires_grad], lr=lr)
+
+
+@torch.no_grad()
+def evaluate_model(model, loader, device="cuda"):
+    """Reference SegmentationModel.py:126-159 / AlternatingDirectionCutLoss.py:639-682: argmax -> IoU/acc
+    against the trimap-derived ground truth (2 -> 1, then inverted)."""
+    model.eval()
+    ious, accs = [], []
+    for img, (_label, true_mask) in loader:
+        x = img[0].to(device).unsqueeze(0)
+        tm = true_mask[0].to(device).clone()
+        tm[tm == 2] = 1
+        tm = 1 - tm
+        out = model(x)["out"]
+        pred = out.squeeze(0).argmax(dim=0)
+        if pred.shape != tm.shape:
+            idx_h = (torch.arange(tm.shape[-2], device=device) * pred.shape[0] // tm.shape[-2])
+            idx_w = (torch.arange(tm.shape[-1], device=device) * pred.shape[1] // tm.shape[-1])
+            pred = pred[idx_h][:, idx_w]
+        iou, acc = compute_iou_and_acc(pred, tm)
+        ious.append(iou)
+        accs.append(acc)
+    return sum(ious) / len(ious), sum(accs) / len(accs)

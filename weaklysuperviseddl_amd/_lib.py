@@ -1,0 +1,83 @@
+"""ctypes binding of libwsdl_hip.so (C ABI declared in include/wsdl_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a tensor is not a device
+tensor the call raises.  ``oracle/`` is never imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwsdl_hip.so")
+
+_vp, _i, _ll, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t, C.c_ulonglong
+
+# name -> (restype, argtypes); mirrors include/wsdl_hip.h one to one
+SIGNATURES = {
+    "wsdl_last_error": (C.c_char_p, []),
+    "wsdl_version": (_i, []),
+    "wsdl_target_arch": (C.c_char_p, []),
+    "wsdl_prof_enable": (_i, [_i]),
+    "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wsdl_prof_reset": (_i, []),
+    "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp]),
+    "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _vp]),
+    "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
+    "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _sz, _vp]),
+    "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),
+    "wsdl_bn_workspace": (_sz, [_i]),
+    "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _sz, _vp]),
+    "wsdl_bn_train_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _sz, _vp]),
+    "wsdl_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp]),
+    "wsdl_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "wsdl_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "wsdl_global_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
+    "wsdl_global_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "wsdl_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
+    "wsdl_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
+    "wsdl_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _i, _vp]),
+    "wsdl_dropout_bwd": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
+    "wsdl_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "wsdl_scale_by_device_scalar": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "wsdl_copy_planes": (_i, [_vp, _vp, _i, _i, _i, _ll, _ll, _vp]),
+    "wsdl_reduce_workspace": (_sz, []),
+    "wsdl_softmax_ce_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "wsdl_pairwise_affinity_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _sz, _vp]),
+    "wsdl_pairwise_workspace": (_sz, [_i, _i, _i]),
+    "wsdl_compute_affinities": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),
+    "wsdl_layercam_workspace": (_sz, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "wsdl_layercam_epilogue": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                    _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
+    "wsdl_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp]),
+    "wsdl_kl_div_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
+    "wsdl_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "wsdl_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+class WsdlError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WsdlError(
+                f"{LIB_PATH} not found: build it with `python -m weaklysuperviseddl_amd._build` "
+                "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the .so is stale / symbol missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WsdlError(f"libwsdl_hip error {rc}: {lib().wsdl_last_error().decode()}")

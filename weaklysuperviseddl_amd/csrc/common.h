@@ -1,0 +1,102 @@
+// common.h - shared host-side helpers for libwsdl_hip.so (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/wsdl_hip.h"
+
+namespace wsdl {
+
+void set_error(const char* fmt, ...);
+
+#define WSDL_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::wsdl::set_error(__VA_ARGS__);     \
+            return WSDL_EINVAL;                 \
+        }                                       \
+    } while (0)
+
+#define WSDL_HIP_CHECK(expr)                                                          \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            ::wsdl::set_error("%s failed: %s", #expr, hipGetErrorString(e_));         \
+            return WSDL_EHIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+#define WSDL_LAUNCH_CHECK()                                                           \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            ::wsdl::set_error("kernel launch failed: %s", hipGetErrorString(e_));     \
+            return WSDL_EHIP;                                                         \
+        }                                                                             \
+    } while (0)
+
+static inline hipStream_t as_stream(wsdl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Profiling scope: records a start/stop event pair on the stream when wsdl_prof_enable(1) is set.
+struct ProfScope {
+    int cls;
+    hipStream_t s;
+    void* slot;
+    ProfScope(int cls, hipStream_t s, double work);
+    ~ProfScope();
+};
+
+// deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
+constexpr int kReduceSlots = 4096;
+
+}  // namespace wsdl
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0.
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += smem[i];
+    return r;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 doubles */) {
+    v = wave_sum_d(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) r += smem[i];
+    return r;
+}

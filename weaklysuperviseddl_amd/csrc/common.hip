@@ -1,0 +1,92 @@
+// common.hip - error channel, version, and the per-kernel-class event timing used by bench.py.
+#include "common.h"
+
+#include <mutex>
+#include <vector>
+
+namespace wsdl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct ProfRec {
+    hipEvent_t start, stop;
+    double work;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof[WSDL_PROF_NCLASSES];
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
+
+ProfScope::ProfScope(int c, hipStream_t st, double work) : cls(c), s(st), slot(nullptr) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.work = work;
+    if (!g_free_events.empty()) {
+        r.start = g_free_events.back().first;
+        r.stop = g_free_events.back().second;
+        g_free_events.pop_back();
+    } else {
+        if (hipEventCreate(&r.start) != hipSuccess) return;
+        if (hipEventCreate(&r.stop) != hipSuccess) return;
+    }
+    (void)hipEventRecord(r.start, s);
+    g_prof[cls].push_back(r);
+    slot = reinterpret_cast<void*>(g_prof[cls].size());  // index + 1
+}
+
+ProfScope::~ProfScope() {
+    if (!slot) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    size_t idx = reinterpret_cast<size_t>(slot) - 1;
+    if (idx < g_prof[cls].size()) (void)hipEventRecord(g_prof[cls][idx].stop, s);
+}
+
+}  // namespace wsdl
+
+extern "C" {
+
+const char* wsdl_last_error(void) { return wsdl::g_err; }
+int wsdl_version(void) { return 100; }
+const char* wsdl_target_arch(void) { return "gfx950"; }
+
+int wsdl_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
+    wsdl::g_prof_on = on != 0;
+    return WSDL_OK;
+}
+
+int wsdl_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
+    for (auto& v : wsdl::g_prof) {
+        for (auto& r : v) wsdl::g_free_events.emplace_back(r.start, r.stop);
+        v.clear();
+    }
+    return WSDL_OK;
+}
+
+int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work) {
+    WSDL_REQUIRE(cls >= 0 && cls < WSDL_PROF_NCLASSES, "prof class %d out of range", cls);
+    std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
+    double ms = 0.0, work = 0.0;
+    for (auto& r : wsdl::g_prof[cls]) {
+        WSDL_HIP_CHECK(hipEventSynchronize(r.stop));
+        float t = 0.f;
+        WSDL_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
+        ms += t;
+        work += r.work;
+    }
+    if (launches) *launches = (long long)wsdl::g_prof[cls].size();
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    return WSDL_OK;
+}
+
+}  // extern "C"

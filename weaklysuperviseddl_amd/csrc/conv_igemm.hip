@@ -1,0 +1,553 @@
+// conv_igemm.hip - convolution forward / input-gradient / weight-gradient as implicit GEMMs on the
+// CDNA4 fp32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, 64 FLOP/clk/SIMD).
+//
+// Layout choices (NCHW activations, 64-lane waves):
+//   forward / dgrad : D[cout][pixel] = sum_k Wt[k][cout] * Xg[k][pixel],  k = tap*Cin + ci.
+//       The MFMA D tile has the pixel on the lane (col = lane&31), so every accumulator register is
+//       stored as 2 x 128-byte runs of consecutive pixels of one output channel: coalesced NCHW writes.
+//       Xg is gathered on the fly (im2col never materialised): for one k the 32 lanes of a half wave
+//       read consecutive pixels of one input channel -> coalesced HBM reads, conflict-free LDS writes.
+//       Weights are pre-laid-out k-major ([k][cout]) so the A tile is read with 16-byte loads.
+//   wgrad           : D[cout][n] = sum_pixel dY[cout][pixel] * Xg[n][pixel],  n = tap*Cin + ci,
+//       both operands pixel-contiguous; LDS rows padded to 33 dwords so the MFMA operand reads
+//       (32 lanes x stride 33) hit 32 distinct banks.  Split over pixel ranges into slabs, summed in
+//       fixed order by a second kernel (bitwise reproducible, no float atomics).
+// One code path serves forward and dgrad: the gather is  num = o*ah + t*bh + ch; src = num/sh
+// (valid when divisible and in range): forward (ah,bh,ch,sh) = (stride, dil, -pad, 1),
+// dgrad = (1, -dil, +pad, stride) over dY with the [tap][cout][cin] weight layout.
+#include "common.h"
+
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct ConvP {
+    const float* x;
+    const float* wt;   // [K][Cout]
+    float* y;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    int B, Cin, H, W, Cout, OH, OW, KH, KW;
+    int ah, bh, ch, sh;
+    int K;
+    long long x_bs, y_bs, res_bs;
+    int relu, accumulate;
+    int P;  // B*OH*OW
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int BM, bool ALIGNED>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
+    constexpr int BK = 16;
+    constexpr int WM = BM / 64;        // waves along M
+    constexpr int WN = 4 / WM;         // waves along N
+    constexpr int BN = WN * 64;
+    constexpr int A_F4 = BK * BM / 4 / kThreads;   // float4 per thread for the A tile
+    constexpr int B_STEP = kThreads / BN;          // k rows covered per pass
+    constexpr int B_PER = BK / B_STEP;             // loads per thread for the B tile
+
+    __shared__ float As[BK * BM];
+    __shared__ float Bs[BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int OHOW = p.OH * p.OW;
+    const int HW = p.H * p.W;
+
+    // ---- per-thread gather state for the B (activation) tile
+    const int pl = tid % BN, kr = tid / BN;
+    const int pix = n0 + pl;
+    const bool pix_ok = pix < p.P;
+    int pb = 0, poh = 0, pow_ = 0;
+    if (pix_ok) {
+        pb = pix / OHOW;
+        const int r = pix - pb * OHOW;
+        poh = r / p.OW;
+        pow_ = r - poh * p.OW;
+    }
+    const float* xb = p.x + (long long)pb * p.x_bs;
+    const bool cout_vec = (p.Cout & 3) == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[A_F4];
+    float rb[B_PER];
+
+    auto load_tiles = [&](int k0) {
+        // A: weights, k-major
+#pragma unroll
+        for (int e = 0; e < A_F4; ++e) {
+            const int q = tid + e * kThreads;
+            const int row = q / (BM / 4), c4 = (q % (BM / 4)) * 4;
+            const int k = k0 + row, m = m0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < p.K) {
+                const float* src = p.wt + (long long)k * p.Cout + m;
+                if (cout_vec) {
+                    if (m < p.Cout) v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (m + 0 < p.Cout) v.x = src[0];
+                    if (m + 1 < p.Cout) v.y = src[1];
+                    if (m + 2 < p.Cout) v.z = src[2];
+                    if (m + 3 < p.Cout) v.w = src[3];
+                }
+            }
+            ra[e] = v;
+        }
+        // B: gathered activations
+        if (ALIGNED) {
+            const int tap = k0 / p.Cin;
+            const int ci0 = k0 - tap * p.Cin + kr;
+            const int ti = tap / p.KW, tj = tap - ti * p.KW;
+            const int nh = poh * p.ah + ti * p.bh + p.ch;
+            const int nw = pow_ * p.ah + tj * p.bh + p.ch;
+            bool ok = pix_ok && nh >= 0 && nw >= 0;
+            int ih = nh, iw = nw;
+            if (p.sh != 1) {
+                ih = nh / p.sh;
+                iw = nw / p.sh;
+                ok = ok && (ih * p.sh == nh) && (iw * p.sh == nw);
+            }
+            ok = ok && ih < p.H && iw < p.W;
+            const float* src = xb + (long long)ci0 * HW + ih * p.W + iw;
+#pragma unroll
+            for (int e = 0; e < B_PER; ++e) rb[e] = ok ? src[(long long)e * B_STEP * HW] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < B_PER; ++e) {
+                const int k = k0 + kr + e * B_STEP;
+                float v = 0.f;
+                if (pix_ok && k < p.K) {
+                    const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                    const int ti = tap / p.KW, tj = tap - ti * p.KW;
+                    const int nh = poh * p.ah + ti * p.bh + p.ch;
+                    const int nw = pow_ * p.ah + tj * p.bh + p.ch;
+                    if (nh >= 0 && nw >= 0) {
+                        const int ih = nh / p.sh, iw = nw / p.sh;
+                        if (ih * p.sh == nh && iw * p.sh == nw && ih < p.H && iw < p.W)
+                            v = xb[(long long)ci * HW + ih * p.W + iw];
+                    }
+                }
+                rb[e] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < A_F4; ++e) {
+            const int q = tid + e * kThreads;
+            *reinterpret_cast<float4*>(&As[q * 4]) = ra[e];   // row-major [BK][BM], q*4 = row*BM + c4
+        }
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) Bs[(kr + e * B_STEP) * BN + pl] = rb[e];
+    };
+
+    const int nchunks = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();            // previous chunk's MFMA reads are done
+        store_tiles();
+        __syncthreads();
+        if (c + 1 < nchunks) load_tiles((c + 1) * BK);   // in flight under the MFMAs below
+        const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(kk + lh) * BM + wm * 64 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + lh) * BN + wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int opix = n0 + wn * 64 + j * 32 + l31;
+        if (opix >= p.P) continue;
+        const int ob = opix / OHOW;
+        const int orp = opix - ob * OHOW;
+        float* yb = p.y + (long long)ob * p.y_bs + orp;
+        const float* rbp = p.res ? p.res + (long long)ob * p.res_bs + orp : nullptr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.scale) v *= p.scale[co];
+                if (p.shift) v += p.shift[co];
+                const long long off = (long long)co * OHOW;
+                if (rbp) v += rbp[off];
+                if (p.accumulate) v += yb[off];
+                if (p.relu) v = fmaxf(v, 0.f);
+                yb[off] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct WgradP {
+    const float* x;
+    const float* dy;
+    float* slab;  // [S][Cout][N]
+    int B, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad, dil;
+    int N;        // KH*KW*Cin
+    int P;        // B*OH*OW
+    int chunks_per_split;
+    long long x_bs, dy_bs;
+};
+
+template <int BM>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
+    constexpr int BK = 32, LD = BK + 1;
+    constexpr int WM = BM / 64, WN = 4 / WM, BN = WN * 64;
+    constexpr int A_PER = BM / 8, B_PER = BN / 8;
+
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int OHOW = p.OH * p.OW, HW = p.H * p.W;
+    const int px = tid & 31, row0 = tid >> 5;
+
+    // fixed per-thread row decode of the B tile: n -> (tap, ci) -> (dh, dw, channel offset)
+    int b_shift[B_PER];   // (dh << 16) | (dw & 0xffff), dh/dw = tap offset in input pixels
+    int b_coff[B_PER];    // ci*H*W, or -1 when n >= N
+#pragma unroll
+    for (int e = 0; e < B_PER; ++e) {
+        const int n = n0 + row0 + 8 * e;
+        if (n < p.N) {
+            const int tap = n / p.Cin, ci = n - tap * p.Cin;
+            const int ti = tap / p.KW, tj = tap - ti * p.KW;
+            const int dh = ti * p.dil - p.pad, dw = tj * p.dil - p.pad;
+            b_shift[e] = (int)(((unsigned)dh << 16) | ((unsigned)dw & 0xffffu));
+            b_coff[e] = ci * HW;
+        } else {
+            b_shift[e] = 0;
+            b_coff[e] = -1;
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[A_PER], rb[B_PER];
+    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    const int total_chunks = (p.P + BK - 1) / BK;
+    const int chunk_end = min(chunk_begin + p.chunks_per_split, total_chunks);
+
+    auto load_tiles = [&](int chunk) {
+        const int pix = chunk * BK + px;
+        const bool ok = pix < p.P;
+        int pb = 0, oh = 0, ow = 0, rp = 0;
+        if (ok) {
+            pb = pix / OHOW;
+            rp = pix - pb * OHOW;
+            oh = rp / p.OW;
+            ow = rp - oh * p.OW;
+        }
+        const float* dyb = p.dy + (long long)pb * p.dy_bs + rp;
+#pragma unroll
+        for (int e = 0; e < A_PER; ++e) {
+            const int co = m0 + row0 + 8 * e;
+            ra[e] = (ok && co < p.Cout) ? dyb[(long long)co * OHOW] : 0.f;
+        }
+        const float* xb = p.x + (long long)pb * p.x_bs;
+        const int bh = oh * p.stride, bw = ow * p.stride;
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) {
+            const int ih = bh + (b_shift[e] >> 16);
+            const int iw = bw + (int)(short)(b_shift[e] & 0xffff);
+            const bool v = ok && b_coff[e] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            rb[e] = v ? xb[(long long)b_coff[e] + ih * p.W + iw] : 0.f;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < A_PER; ++e) As[(row0 + 8 * e) * LD + px] = ra[e];
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) Bs[(row0 + 8 * e) * LD + px] = rb[e];
+    };
+
+    if (chunk_begin < chunk_end) load_tiles(chunk_begin);
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int c = chunk_begin; c < chunk_end; ++c) {
+        __syncthreads();
+        store_tiles();
+        __syncthreads();
+        if (c + 1 < chunk_end) load_tiles(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 64 + i * 32 + l31) * LD + kk + lh];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 64 + j * 32 + l31) * LD + kk + lh];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < p.Cout) slab[(long long)co * p.N + n] = acc[i][j][r];
+            }
+    }
+}
+
+// slab[z][co][tap*Cin+ci] summed over z in order -> dw[co][ci][tap]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                    int Cout, int Cin, int T, int accumulate) {
+    const long long total = (long long)Cout * Cin * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int N = Cin * T;
+        const int co = (int)(idx / N), n = (int)(idx - (long long)co * N);
+        const int tap = n / Cin, ci = n - tap * Cin;
+        float s = 0.f;
+        for (int z = 0; z < S; ++z) s += slab[(long long)z * total + idx];
+        const long long o = ((long long)co * Cin + ci) * T + tap;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+// w[co][ci][tap] -> fwd[(tap*Cin+ci)][co], dgrad[(tap*Cout+co)][ci]
+__global__ void prep_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                    float* __restrict__ dg, int Cout, int Cin, int T) {
+    const long long total = (long long)Cout * Cin * T;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        // idx enumerates the fwd layout (co fastest) so the fwd write is coalesced
+        const int co = (int)(idx % Cout);
+        const long long k = idx / Cout;
+        const int ci = (int)(k % Cin), tap = (int)(k / Cin);
+        const float v = w[((long long)co * Cin + ci) * T + tap];
+        if (fwd) fwd[idx] = v;
+        if (dg) dg[((long long)tap * Cout + co) * Cin + ci] = v;
+    }
+}
+
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int B, int C,
+                                 int HW, long long dy_bs, int accumulate) {
+    __shared__ float sm[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* src = dy + (long long)b * dy_bs + (long long)c * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) s += src[i];
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;
+}
+
+int check_geom(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil,
+               int* OH, int* OW) {
+    WSDL_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "conv: non-positive dimension");
+    WSDL_REQUIRE(kh > 0 && kw > 0 && kh == kw && kh <= 15, "conv: kernel must be square, <= 15 (got %dx%d)", kh, kw);
+    WSDL_REQUIRE(stride >= 1 && stride <= 8 && dil >= 1 && pad >= 0, "conv: bad stride/pad/dilation");
+    const int oh = (H + 2 * pad - dil * (kh - 1) - 1) / stride + 1;
+    const int ow = (W + 2 * pad - dil * (kw - 1) - 1) / stride + 1;
+    WSDL_REQUIRE(oh > 0 && ow > 0, "conv: empty output (%d x %d)", oh, ow);
+    WSDL_REQUIRE((long long)B * oh * ow < (1ll << 31) && (long long)B * H * W < (1ll << 31),
+                 "conv: pixel count exceeds int32");
+    WSDL_REQUIRE((long long)Cin * H * W < (1ll << 31) && (long long)Cout * oh * ow < (1ll << 31),
+                 "conv: per-image tensor exceeds int32 elements");
+    WSDL_REQUIRE((long long)kh * kw * Cin < (1ll << 31) && (long long)kh * kw * Cout < (1ll << 31), "conv: K too large");
+    WSDL_REQUIRE(dil * (kh - 1) < 32768 && pad < 32768, "conv: tap offset exceeds int16");
+    *OH = oh;
+    *OW = ow;
+    return WSDL_OK;
+}
+
+int launch_igemm(const ConvP& p, hipStream_t s) {
+    const bool aligned = (p.Cin % 16) == 0;
+    if (p.Cout <= 64) {
+        dim3 grid(wsdl::cdiv(p.P, 256), wsdl::cdiv(p.Cout, 64));
+        if (aligned)
+            hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, dim3(kThreads), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, dim3(kThreads), 0, s, p);
+    } else {
+        dim3 grid(wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 128));
+        if (aligned)
+            hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, dim3(kThreads), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, dim3(kThreads), 0, s, p);
+    }
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+// split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
+int wgrad_splits(int Cout, int N, int P) {
+    const int BM = Cout <= 64 ? 64 : 128, BN = Cout <= 64 ? 256 : 128;
+    const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
+    const int chunks = wsdl::cdiv(P, 32);
+    long long s = (768 + tiles - 1) / tiles;
+    if (s > chunks / 8) s = chunks / 8;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad, int Cout, int Cin,
+                             int kh, int kw, wsdl_stream_t stream) {
+    WSDL_REQUIRE(w && (wt_fwd || wt_dgrad), "prep_weights: null pointer");
+    WSDL_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "prep_weights: bad shape");
+    const long long total = (long long)Cout * Cin * kh * kw;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), w,
+                       wt_fwd, wt_dgrad, Cout, Cin, kh * kw);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Cin, int H, int W,
+                    int Cout, int kh, int kw, int stride, int pad, int dil, const float* scale,
+                    const float* shift, const float* residual, int relu, long long x_bs,
+                    long long y_bs, long long res_bs, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && wt_fwd && y, "conv2d_fwd: null pointer");
+    int OH, OW;
+    if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
+    ConvP p{};
+    p.x = x; p.wt = wt_fwd; p.y = y; p.scale = scale; p.shift = shift; p.res = residual;
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.KH = kh; p.KW = kw;
+    p.ah = stride; p.bh = dil; p.ch = -pad; p.sh = 1;
+    p.K = kh * kw * Cin;
+    p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
+    p.y_bs = y_bs ? y_bs : (long long)Cout * OH * OW;
+    p.res_bs = res_bs ? res_bs : (long long)Cout * OH * OW;
+    WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
+    p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
+    wsdl::ProfScope prof(WSDL_PROF_CONV_FWD, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
+    return launch_igemm(p, wsdl::as_stream(stream));
+}
+
+int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, int Cin, int H, int W,
+                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                      long long dy_bs, wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && wt_dgrad && dx, "conv2d_dgrad: null pointer");
+    int OH, OW;
+    if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
+    ConvP p{};
+    p.x = dy; p.wt = wt_dgrad; p.y = dx;
+    // roles swap: "input" is dY (Cout channels, OH x OW), "output" is dX (Cin channels, H x W)
+    p.B = B; p.Cin = Cout; p.H = OH; p.W = OW; p.Cout = Cin; p.OH = H; p.OW = W; p.KH = kh; p.KW = kw;
+    p.ah = 1; p.bh = -dil; p.ch = pad; p.sh = stride;
+    p.K = kh * kw * Cout;
+    p.x_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
+    p.y_bs = (long long)Cin * H * W;
+    p.res_bs = p.y_bs;
+    WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
+    p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
+    wsdl::ProfScope prof(WSDL_PROF_CONV_DGRAD, wsdl::as_stream(stream),
+                         2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin);
+    return launch_igemm(p, wsdl::as_stream(stream));
+}
+
+size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                                   int pad, int dil) {
+    int OH, OW;
+    if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
+    const int N = kh * kw * Cin;
+    return (size_t)wgrad_splits(Cout, N, B * OH * OW) * Cout * N * sizeof(float);
+}
+
+int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                      long long x_bs, long long dy_bs, void* ws, size_t ws_bytes,
+                      wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+    int OH, OW;
+    if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
+    WgradP p{};
+    p.x = x; p.dy = dy; p.slab = static_cast<float*>(ws);
+    p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.KH = kh; p.KW = kw;
+    p.stride = stride; p.pad = pad; p.dil = dil;
+    p.N = kh * kw * Cin; p.P = B * OH * OW;
+    p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
+    p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
+    const int S = wgrad_splits(Cout, p.N, p.P);
+    const size_t need = (size_t)S * Cout * p.N * sizeof(float);
+    if (ws_bytes < need) {
+        wsdl::set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+        return WSDL_EWORKSPACE;
+    }
+    const int chunks = wsdl::cdiv(p.P, 32);
+    p.chunks_per_split = wsdl::cdiv(chunks, S);
+    hipStream_t s = wsdl::as_stream(stream);
+    wsdl::ProfScope prof(WSDL_PROF_CONV_WGRAD, s, 2.0 * p.P * (double)Cout * p.N);
+    if (Cout <= 64) {
+        dim3 grid(wsdl::cdiv(p.N, 256), wsdl::cdiv(Cout, 64), S);
+        hipLaunchKernelGGL((conv_wgrad_kernel<64>), grid, dim3(kThreads), 0, s, p);
+    } else {
+        dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 128), S);
+        hipLaunchKernelGGL((conv_wgrad_kernel<128>), grid, dim3(kThreads), 0, s, p);
+    }
+    WSDL_LAUNCH_CHECK();
+    const long long total = (long long)Cout * p.N;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S, Cout, Cin,
+                       kh * kw, accumulate);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_bias_grad(const float* dy, float* dbias, int B, int C, int HW, long long dy_bs, int accumulate,
+                   wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && dbias && B > 0 && C > 0 && HW > 0, "bias_grad: bad arguments");
+    if (!dy_bs) dy_bs = (long long)C * HW;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, wsdl::as_stream(stream), dy, dbias, B, C,
+                       HW, dy_bs, accumulate);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+}  // extern "C"

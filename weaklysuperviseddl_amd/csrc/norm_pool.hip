@@ -1,0 +1,471 @@
+// norm_pool.hip - the HBM-bound companions of the conv stack: BatchNorm2d (train statistics, backward,
+// eval fold), ReLU / residual epilogues, max / average pooling, dropout, plane copies.
+// All are streaming kernels: 16-byte accesses where the plane size allows, one pass per tensor.
+#include "common.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int kStatSplit = 32;  // partial sums per channel (fixed: results are bitwise reproducible)
+
+// ws layout for BN: double part[C][kStatSplit][2] ; float coef[C][2]
+__global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                const float* __restrict__ y, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, double* __restrict__ part, int B, int C,
+                                int HW, long long dy_bs, long long y_bs, int relu, int backward) {
+    // forward : part = (sum x, sum x^2) ; backward: part = (sum dy', sum dy'*xhat), dy' = dy*[y>0]
+    __shared__ double sm[16];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const int slice = (HW + kStatSplit - 1) / kStatSplit;
+    const int r0 = s * slice;
+    const int len = min(slice, HW - r0);
+    double a0 = 0.0, a1 = 0.0;
+    float mu = 0.f, is = 0.f;
+    if (backward) {
+        mu = mean[c];
+        is = invstd[c];
+    }
+    const int total = len > 0 ? B * len : 0;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int b = i / len, r = r0 + (i - b * len);
+        const float xv = x[((long long)b * C + c) * HW + r];
+        if (!backward) {
+            a0 += xv;
+            a1 += (double)xv * xv;
+        } else {
+            float g = dy[(long long)b * dy_bs + (long long)c * HW + r];
+            if (relu && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
+            a0 += g;
+            a1 += (double)g * ((xv - mu) * is);
+        }
+    }
+    a0 = block_sum_d(a0, sm);
+    a1 = block_sum_d(a1, sm);
+    if (threadIdx.x == 0) {
+        part[((long long)c * kStatSplit + s) * 2 + 0] = a0;
+        part[((long long)c * kStatSplit + s) * 2 + 1] = a1;
+    }
+}
+
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
+                                       float* __restrict__ save_invstd, float* __restrict__ rmean,
+                                       float* __restrict__ rvar, float momentum, float eps, long long n,
+                                       int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < kStatSplit; ++s) {
+        s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
+        s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
+    }
+    const double mean = s0 / (double)n;
+    double var = s1 / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    if (rvar) {
+        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// y = act((x-mean)*invstd*gamma + beta + res); one block row per (b,c) plane
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ res,
+                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int b = plane / C, c = plane - b * C;
+    const float mu = mean[c], g = invstd[c] * gamma[c], be = beta[c];
+    const float* xp = x + (long long)plane * HW;
+    const float* rp = res ? res + (long long)plane * HW : nullptr;
+    float* yp = y + (long long)b * y_bs + (long long)c * HW;
+    if ((HW & 3) == 0 && (y_bs & 3) == 0) {
+        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
+            float4 v = *reinterpret_cast<const float4*>(xp + i);
+            v.x = (v.x - mu) * g + be; v.y = (v.y - mu) * g + be;
+            v.z = (v.z - mu) * g + be; v.w = (v.w - mu) * g + be;
+            if (rp) {
+                const float4 r = *reinterpret_cast<const float4*>(rp + i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(yp + i) = v;
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+            float v = (xp[i] - mu) * g + be;
+            if (rp) v += rp[i];
+            if (relu) v = fmaxf(v, 0.f);
+            yp[i] = v;
+        }
+    }
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef, long long n,
+                                       int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int s = 0; s < kStatSplit; ++s) {
+        s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
+        s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
+    }
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
+    coef[2 * c + 0] = (float)(s0 / (double)n);   // mean(dy')
+    coef[2 * c + 1] = (float)(s1 / (double)n);   // mean(dy' * xhat)
+}
+
+// dx = gamma*invstd*(dy' - k0 - xhat*k1) ; dres = dy'
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ y, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ coef, float* __restrict__ dx,
+                                    float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
+                                    int relu, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int b = plane / C, c = plane - b * C;
+    const float mu = mean[c], is = invstd[c], gi = gamma[c] * is, k0 = coef[2 * c], k1 = coef[2 * c + 1];
+    const float* xp = x + (long long)plane * HW;
+    const float* gp = dy + (long long)b * dy_bs + (long long)c * HW;
+    const float* yp = relu ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
+    float* dxp = dx + (long long)plane * HW;
+    float* drp = dres ? dres + (long long)plane * HW : nullptr;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float g = gp[i];
+        if (yp && !(yp[i] > 0.f)) g = 0.f;
+        const float xh = (xp[i] - mu) * is;
+        dxp[i] = gi * (g - k0 - xh * k1);
+        if (drp) drp[i] = g;
+    }
+  }
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+}
+
+__global__ void affine_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                      const float* __restrict__ scale, float* __restrict__ dconv,
+                                      float* __restrict__ dres, int C, int HW, int relu, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int c = plane % C;
+    const float sc = scale ? scale[c] : 1.f;
+    const long long base = (long long)plane * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float g = dy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        if (dconv) dconv[base + i] = g * sc;
+        if (dres) dres[base + i] = g;
+    }
+  }
+}
+
+// ---- MaxPool2d(3, 2, 1)
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ am, int H, int W, int OH, int OW, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const float* xp = x + (long long)plane * H * W;
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < OH * OW; o += gridDim.x * blockDim.x) {
+        const int oh = o / OW, ow = o - oh * OW;
+        float best = -INFINITY;
+        int bi = 0;
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ih = oh * 2 - 1 + i, iw = ow * 2 - 1 + j;
+                if (ih < 0 || ih >= H || iw < 0 || iw >= W) continue;
+                const float v = xp[ih * W + iw];
+                if (!any || v > best || v != v) {   // first max wins; NaN propagates (ATen semantics)
+                    best = v;
+                    bi = i * 3 + j;
+                    any = true;
+                }
+            }
+        y[(long long)plane * OH * OW + o] = best;
+        if (am) am[(long long)plane * OH * OW + o] = (uint8_t)bi;
+    }
+  }
+}
+
+// gather form: every input pixel checks the (at most 4) windows that contain it
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                   float* __restrict__ dx, int H, int W, int OH, int OW, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const float* gp = dy + (long long)plane * OH * OW;
+    const uint8_t* ap = am + (long long)plane * OH * OW;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < H * W; idx += gridDim.x * blockDim.x) {
+        const int ih = idx / W, iw = idx - ih * W;
+        float s = 0.f;
+        // windows oh with oh*2-1 <= ih <= oh*2+1  ->  oh in [(ih-1+1)/2 .. (ih+1)/2]
+        for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+            if (oh >= OH) continue;
+            const int i = ih - (oh * 2 - 1);
+            if (i < 0 || i > 2) continue;
+            for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+                if (ow >= OW) continue;
+                const int j = iw - (ow * 2 - 1);
+                if (j < 0 || j > 2) continue;
+                if (ap[oh * OW + ow] == i * 3 + j) s += gp[oh * OW + ow];
+            }
+        }
+        dx[(long long)plane * H * W + idx] = s;
+    }
+  }
+}
+
+__global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int HW) {
+    __shared__ float sm[16];
+    const float* xp = x + (long long)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += xp[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) y[blockIdx.x] = s / (float)HW;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int HW, int accumulate,
+                               int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const float g = dy[plane] / (float)HW;
+    float* dp = dx + (long long)plane * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x)
+        dp[i] = accumulate ? dp[i] + g : g;
+  }
+}
+
+// ---- dropout: counter-based hash (splitmix64 of seed + element index) -> uniform [0,1)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   uint8_t* __restrict__ mask, size_t n, float p, float inv_keep,
+                                   unsigned long long seed, int gen) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint8_t m;
+        if (gen) {
+            m = hash_uniform(seed, i) >= p ? 1 : 0;
+            mask[i] = m;
+        } else {
+            m = mask[i];
+        }
+        y[i] = m ? x[i] * inv_keep : 0.f;
+    }
+}
+
+__global__ void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                   float* __restrict__ dx, size_t n, float inv_keep) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = mask[i] ? dy[i] * inv_keep : 0.f;
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                           size_t n, int relu) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = a[i] + b[i];
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                 float* __restrict__ y, size_t n) {
+    const float k = s[0];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * k;
+}
+
+__global__ void copy_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                   long long src_bs, long long dst_bs, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int b = plane / C, c = plane - b * C;
+    const float* sp = src + (long long)b * src_bs + (long long)c * HW;
+    float* dp = dst + (long long)b * dst_bs + (long long)c * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) dp[i] = sp[i];
+  }
+}
+
+inline dim3 plane_grid(int planes, int HW, int per_thread = 1) {
+    int gx = wsdl::cdiv(HW, 256 * per_thread);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    return dim3(gx, planes > 65535 ? 65535 : planes);
+}
+inline int flat_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
+
+}  // namespace
+
+extern "C" {
+
+size_t wsdl_bn_workspace(int C) {
+    return C > 0 ? (size_t)C * kStatSplit * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) : 0;
+}
+
+int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                      float* save_invstd, float* running_mean, float* running_var, float momentum,
+                      float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
+                      void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
+    WSDL_REQUIRE(B > 0 && C > 0 && HW > 0 , "bn_train_fwd: bad shape");
+    WSDL_REQUIRE((long long)B * HW > 1, "bn_train_fwd: needs more than one value per channel (as torch)");
+    if (ws_bytes < wsdl_bn_workspace(C)) {
+        wsdl::set_error("bn_train_fwd: workspace too small");
+        return WSDL_EWORKSPACE;
+    }
+    if (!y_bs) y_bs = (long long)C * HW;
+    hipStream_t s = wsdl::as_stream(stream);
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kStatSplit), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
+                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, save_mean,
+                       save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, C);
+    hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, save_mean,
+                       save_invstd, residual, y, C, HW, y_bs, relu, B * C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+                      const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
+                      float* dbeta, float* dres, int B, int C, int HW, int relu,
+                      int accumulate_param_grads, long long dy_bs, long long y_bs, void* ws,
+                      size_t ws_bytes, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
+    WSDL_REQUIRE(!relu || y, "bn_train_bwd: relu mask needs the forward output y");
+    WSDL_REQUIRE(B > 0 && C > 0 && HW > 0, "bn_train_bwd: bad shape");
+    if (ws_bytes < wsdl_bn_workspace(C)) {
+        wsdl::set_error("bn_train_bwd: workspace too small");
+        return WSDL_EWORKSPACE;
+    }
+    if (!dy_bs) dy_bs = (long long)C * HW;
+    if (!y_bs) y_bs = (long long)C * HW;
+    hipStream_t s = wsdl::as_stream(stream);
+    double* part = static_cast<double*>(ws);
+    float* coef = reinterpret_cast<float*>(part + (size_t)C * kStatSplit * 2);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kStatSplit), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
+                       part, B, C, HW, dy_bs, y_bs, relu, 1);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, gamma,
+                       save_invstd, dgamma, dbeta, coef, (long long)B * HW, C, accumulate_param_grads);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW), dim3(256), 0, s, x, dy, y, gamma, save_mean,
+                       save_invstd, coef, dx, dres, C, HW, dy_bs, y_bs, relu, B * C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,
+                 const float* running_var, float eps, float* scale, float* shift, int C,
+                 wsdl_stream_t stream) {
+    WSDL_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(wsdl::cdiv(C, 256)), dim3(256), 0, wsdl::as_stream(stream), gamma,
+                       beta, running_mean, running_var, eps, scale, shift, C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, float* dconv, float* dres,
+                        int B, int C, int HW, int relu, wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && (dconv || dres) && B > 0 && C > 0 && HW > 0, "affine_act_bwd: bad arguments");
+    WSDL_REQUIRE(!relu || y, "affine_act_bwd: relu mask needs y");
+    hipLaunchKernelGGL(affine_act_bwd_kernel, plane_grid(B * C, HW), dim3(256), 0, wsdl::as_stream(stream), dy, y,
+                       scale, dconv, dres, C, HW, relu, B * C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* argmax, int BC, int H, int W,
+                          wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && y && BC > 0 && H > 0 && W > 0 , "maxpool_fwd: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, plane_grid(BC, OH * OW), dim3(256), 0, wsdl::as_stream(stream), x, y,
+                       argmax, H, W, OH, OW, BC);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_maxpool3x3s2_bwd(const float* dy, const uint8_t* argmax, float* dx, int BC, int H, int W,
+                          wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && argmax && dx && BC > 0 && H > 0 && W > 0, "maxpool_bwd: bad arguments");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, plane_grid(BC, H * W), dim3(256), 0, wsdl::as_stream(stream), dy,
+                       argmax, dx, H, W, OH, OW, BC);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_global_avgpool_fwd(const float* x, float* y, int BC, int HW, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && y && BC > 0 && HW > 0, "global_avgpool_fwd: bad arguments");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(BC), dim3(256), 0, wsdl::as_stream(stream), x, y, HW);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_global_avgpool_bwd(const float* dy, float* dx, int BC, int HW, int accumulate,
+                            wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && dx && BC > 0 && HW > 0, "global_avgpool_bwd: bad arguments");
+    hipLaunchKernelGGL(gap_bwd_kernel, plane_grid(BC, HW), dim3(256), 0, wsdl::as_stream(stream), dy, dx, HW,
+                       accumulate, BC);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p, unsigned long long seed,
+                     int gen_mask, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && y && mask && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad arguments");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(flat_blocks(n)), dim3(256), 0, wsdl::as_stream(stream), x, y,
+                       mask, n, p, 1.f / (1.f - p), seed, gen_mask);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, size_t n, float p,
+                     wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && dx && mask && n > 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad arguments");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(flat_blocks(n)), dim3(256), 0, wsdl::as_stream(stream), dy, mask,
+                       dx, n, 1.f / (1.f - p));
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_add(const float* a, const float* b, float* y, size_t n, int relu, wsdl_stream_t stream) {
+    WSDL_REQUIRE(a && b && y && n > 0, "add: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(flat_blocks(n)), dim3(256), 0, wsdl::as_stream(stream), a, b, y, n, relu);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_scale_by_device_scalar(const float* x, const float* s, float* y, size_t n, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && s && y && n > 0, "scale_by_device_scalar: bad arguments");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(flat_blocks(n)), dim3(256), 0, wsdl::as_stream(stream), x, s, y, n);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_copy_planes(const float* src, float* dst, int B, int C, int HW, long long src_bs,
+                     long long dst_bs, wsdl_stream_t stream) {
+    WSDL_REQUIRE(src && dst && B > 0 && C > 0 && HW > 0, "copy_planes: bad arguments");
+    if (!src_bs) src_bs = (long long)C * HW;
+    if (!dst_bs) dst_bs = (long long)C * HW;
+    hipLaunchKernelGGL(copy_planes_kernel, plane_grid(B * C, HW), dim3(256), 0, wsdl::as_stream(stream), src, dst,
+                       C, HW, src_bs, dst_bs, B * C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+}  // extern "C"

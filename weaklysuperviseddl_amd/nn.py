@@ -1,0 +1,176 @@
+"""Parameter-holding modules for the HIP path.
+
+They keep torchvision's attribute / state_dict names (conv1.weight, bn1.running_mean, downsample.0.weight,
+classifier.0.convs.1.0.weight ...) so real weights drop in, but never call an ATen compute op: every
+forward goes through ``ops`` (libwsdl_hip.so).  ``FusedSequential`` runs Conv2d -> BatchNorm2d [-> ReLU]
+triples as one fused node (conv + BN statistics/apply + activation).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = cin, cout, k
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # nn.Conv2d default init (kaiming_uniform a=sqrt(5)); model builders re-init as torchvision does
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(self.in_channels * self.kernel_size * self.kernel_size)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.conv_bias_act(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, "
+                f"p={self.padding}, d={self.dilation}, bias={self.bias is not None}")
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self._pending_steps = 0     # train-mode forwards not yet folded into num_batches_tracked
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        if self._pending_steps:
+            self.num_batches_tracked += self._pending_steps
+            self._pending_steps = 0
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def forward(self, x):
+        # stand-alone BN = identity 1x1 "conv" is wasteful; only the fused path is used by the models
+        raise RuntimeError("BatchNorm2d is only run fused behind a Conv2d (see FusedSequential / conv_bn)")
+
+
+class ReLU(nn.Module):
+    def forward(self, x):
+        raise RuntimeError("ReLU is only run fused (see FusedSequential / conv_bn)")
+
+
+class MaxPool3x3s2(nn.Module):
+    def forward(self, x):
+        return ops.max_pool_3x3_s2(x)
+
+
+class GlobalAvgPool(nn.Module):
+    """nn.AdaptiveAvgPool2d(1)"""
+
+    def forward(self, x):
+        return ops.global_avg_pool(x)
+
+
+class Dropout(nn.Module):
+    def __init__(self, p):
+        super().__init__()
+        self.p = p
+        self.injected_mask = None   # parity tests: uint8 mask used instead of the device RNG
+
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training, mask=self.injected_mask)
+
+
+class Linear(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        nn.init.uniform_(self.bias, -1.0 / math.sqrt(fin), 1.0 / math.sqrt(fin))
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+def conv_bn(x, conv, bn, relu, residual=None):
+    """conv -> bn (batch stats when bn.training, folded running stats otherwise) -> +residual -> relu."""
+    if conv.bias is not None:
+        raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
+    if bn.training:
+        bn._pending_steps += 1      # momentum is fixed, so the counter never feeds the arithmetic
+    return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
+                           conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training)
+
+
+class FusedSequential(nn.Sequential):
+    """nn.Sequential whose Conv2d, BatchNorm2d[, ReLU] runs execute as single fused nodes."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], BatchNorm2d):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], ReLU)
+                x = conv_bn(x, m, mods[i + 1], relu)
+                i += 3 if relu else 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, padding=dilation, dilation=dilation)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = ReLU()
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = conv_bn(x, self.conv1, self.bn1, True)
+        y = conv_bn(y, self.conv2, self.bn2, True)
+        return conv_bn(y, self.conv3, self.bn3, True, residual=idt)   # relu(bn3(conv3) + identity)
+
+
+def make_resnet50_stages(replace_stride_with_dilation):
+    """-> (conv1, bn1, layer1..layer4) with torchvision ResNet-50 v1.5 wiring and initialisation."""
+    state = {"inplanes": 64, "dilation": 1}
+
+    def stage(planes, blocks, stride, dilate):
+        prev = state["dilation"]
+        if dilate:
+            state["dilation"] *= stride
+            stride = 1
+        down = None
+        if stride != 1 or state["inplanes"] != planes * 4:
+            down = FusedSequential(Conv2d(state["inplanes"], planes * 4, 1, stride=stride), BatchNorm2d(planes * 4))
+        mods = [Bottleneck(state["inplanes"], planes, stride, prev, down)]
+        state["inplanes"] = planes * 4
+        for _ in range(1, blocks):
+            mods.append(Bottleneck(state["inplanes"], planes, 1, state["dilation"], None))
+        return nn.Sequential(*mods)
+
+    conv1 = Conv2d(3, 64, 7, stride=2, padding=3)
+    bn1 = BatchNorm2d(64)
+    r = replace_stride_with_dilation
+    layers = [stage(64, 3, 1, False), stage(128, 4, 2, r[0]), stage(256, 6, 2, r[1]), stage(512, 3, 2, r[2])]
+    for m in [conv1] + [mm for l in layers for mm in l.modules()]:
+        if isinstance(m, Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+    return conv1, bn1, layers

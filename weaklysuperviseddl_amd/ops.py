@@ -1,0 +1,620 @@
+"""Host-side glue between PyTorch tensors (device memory, streams, autograd bookkeeping) and the HIP
+kernels of libwsdl_hip.so.  Every arithmetic step runs in the library; torch here only allocates
+buffers and orders calls on the current stream.  No CPU fallback: non-device tensors raise.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, WsdlError
+
+_vp = C.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _req(t, name="tensor", dtype=torch.float32):
+    if not t.is_cuda:
+        raise WsdlError(f"{name}: the HIP path needs a device tensor (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype:
+        raise WsdlError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _dense(t, name="tensor"):
+    _req(t, name)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _planes(t, name="tensor"):
+    """(tensor, batch_stride): accept NCHW tensors whose images are dense but batch stride is larger
+    (channel slices of a concatenated tensor) without copying; anything else is made contiguous."""
+    _req(t, name)
+    B, Cc, H, W = t.shape
+    if t.is_contiguous():
+        return t, Cc * H * W
+    st = t.stride()
+    if st[3] == 1 and st[2] == W and st[1] == H * W and st[0] >= Cc * H * W:
+        return t, st[0]
+    t = t.contiguous()
+    return t, Cc * H * W
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Stream-ordered scratch: one growing buffer per (device, stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_out_hw(H, W, k, stride, pad, dil):
+    return ((H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1)
+
+
+# ------------------------------------------------------------------------------------------ raw ops
+def prep_weights(w, want_fwd=True, want_dgrad=True):
+    w = _dense(w, "weight")
+    Cout, Cin, kh, kw = w.shape
+    wf = torch.empty(kh * kw * Cin, Cout, device=w.device, dtype=torch.float32) if want_fwd else None
+    wd = torch.empty(kh * kw * Cout, Cin, device=w.device, dtype=torch.float32) if want_dgrad else None
+    check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd), Cout, Cin, kh, kw, _stream()))
+    return wf, wd
+
+
+def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, residual=None, relu=False, out=None):
+    x, x_bs = _planes(x, "x")
+    B, Cin, H, W = x.shape
+    Cout, Cin2, kh, kw = wshape
+    if Cin2 != Cin:
+        raise WsdlError(f"conv2d: input has {Cin} channels, weight expects {Cin2}")
+    OH, OW = conv_out_hw(H, W, kh, stride, pad, dil)
+    if out is None:
+        out = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+        y_bs = Cout * OH * OW
+    else:
+        out, y_bs = _planes(out, "out")
+        if tuple(out.shape) != (B, Cout, OH, OW):
+            raise WsdlError("conv2d: bad preallocated output shape")
+    res_bs = 0
+    if residual is not None:
+        residual, res_bs = _planes(residual, "residual")
+        if tuple(residual.shape) != (B, Cout, OH, OW):
+            raise WsdlError("conv2d: residual shape mismatch")
+    check(lib().wsdl_conv2d_fwd(_p(x), _p(wt_fwd), _p(out), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
+                                _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs, _stream()))
+    return out
+
+
+def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into=None):
+    dy, dy_bs = _planes(dy, "dy")
+    B, Cin, H, W = xshape
+    Cout, _, kh, kw = wshape
+    dx = accumulate_into if accumulate_into is not None else torch.empty(xshape, device=dy.device, dtype=torch.float32)
+    check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
+                                  int(accumulate_into is not None), dy_bs, _stream()))
+    return dx
+
+
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False):
+    x, x_bs = _planes(x, "x")
+    dy, dy_bs = _planes(dy, "dy")
+    B, Cin, H, W = x.shape
+    Cout, _, kh, kw = wshape
+    geom = (B, Cin, H, W, Cout, kh, kw, stride, pad, dil)
+    nbytes = lib().wsdl_conv2d_wgrad_workspace(*geom)
+    if nbytes == 0:
+        raise WsdlError("conv2d_wgrad: bad geometry " + repr(geom))
+    ws = workspace(nbytes, x.device)
+    if out is None:
+        out = torch.empty(wshape, device=x.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().wsdl_conv2d_wgrad(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(ws), ws.numel(),
+                                  _stream()))
+    return out
+
+
+def bias_grad(dy, out=None, accumulate=False):
+    dy, dy_bs = _planes(dy, "dy")
+    B, Cc, H, W = dy.shape
+    if out is None:
+        out = torch.empty(Cc, device=dy.device, dtype=torch.float32)
+        accumulate = False
+    check(lib().wsdl_bias_grad(_p(dy), _p(out), B, Cc, H * W, dy_bs, int(accumulate), _stream()))
+    return out
+
+
+def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps):
+    Cc = bn_weight.numel()
+    scale = torch.empty(Cc, device=bn_weight.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    check(lib().wsdl_bn_fold(_p(_dense(bn_weight)), _p(_dense(bn_bias)), _p(_dense(running_mean)),
+                             _p(_dense(running_var)), float(eps), _p(scale), _p(shift), Cc, _stream()))
+    return scale, shift
+
+
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, out=None):
+    x = _dense(x, "x")
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+        y_bs = Cc * H * W
+    else:
+        out, y_bs = _planes(out, "out")
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
+    if residual is not None:
+        residual = _dense(residual, "residual")
+    check(lib().wsdl_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(invstd), _p(running_mean),
+                                  _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
+                                  int(relu), y_bs, _p(ws), ws.numel(), _stream()))
+    return out, mean, invstd
+
+
+def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None):
+    x = _dense(x, "x")
+    dy, dy_bs = _planes(dy, "dy")
+    B, Cc, H, W = x.shape
+    y_bs = 0
+    if relu:
+        y, y_bs = _planes(y, "y")
+    dx = torch.empty_like(x)
+    acc = dgamma_out is not None
+    dgamma = dgamma_out if acc else torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dbeta = dbeta_out if acc else torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dres = torch.empty_like(x) if want_dres else None
+    ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
+    check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if relu else None), _p(gamma), _p(mean), _p(invstd), _p(dx),
+                                  _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, int(relu), int(acc), dy_bs, y_bs,
+                                  _p(ws), ws.numel(), _stream()))
+    return dx, dgamma, dbeta, dres
+
+
+def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
+    dy = _dense(dy, "dy")
+    B, Cc, H, W = dy.shape
+    dconv = torch.empty_like(dy) if want_dconv else None
+    dres = torch.empty_like(dy) if want_dres else None
+    check(lib().wsdl_affine_act_bwd(_p(dy), _p(_dense(y) if relu else None), _p(scale), _p(dconv), _p(dres), B, Cc,
+                                    H * W, int(relu), _stream()))
+    return dconv, dres
+
+
+# ------------------------------------------------------------------------------------------ autograd
+class _ConvBNAct(torch.autograd.Function):
+    """Train-mode conv -> BatchNorm(batch statistics) -> (+residual) -> ReLU as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil, relu,
+                momentum, eps):
+        wf, wd = prep_weights(weight, True, x.requires_grad)
+        conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil)
+        y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
+                                       residual, relu)
+        ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
+        ctx.save_for_backward(x, conv, y if relu else None, gamma, mean, invstd, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, conv, y, gamma, mean, invstd, wd = ctx.saved_tensors
+        stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
+        need_res = has_res and ctx.needs_input_grad[4]
+        dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res)
+        dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                raise WsdlError("conv backward: dgrad weights were not prepared")
+            dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil)
+        return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
+                dres, None, None, None, None, None, None, None, None)
+
+
+class _ConvAffineAct(torch.autograd.Function):
+    """y = act(scale*conv(x,w) + shift + residual): eval-mode (folded) BN, conv bias, Linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, relu, shift_is_param):
+        need_dx = x.requires_grad
+        wf, wd = prep_weights(weight, True, need_dx)
+        y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu)
+        ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None, shift_is_param)
+        need_w = weight.requires_grad
+        ctx.save_for_backward(x if need_w else None, y if relu else None, scale, wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, scale, wd = ctx.saved_tensors
+        stride, pad, dil, relu, wshape, xshape, has_res, shift_is_param = ctx.cfg
+        need_res = has_res and ctx.needs_input_grad[4]
+        dyc = _dense(dy, "dy")
+        if relu or scale is not None or need_res:
+            dconv, dres = affine_act_bwd(dyc, y, scale, relu, True, need_res)
+            if need_res and not relu:
+                dres = dyc
+        else:
+            dconv, dres = dyc, None
+        dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil) if ctx.needs_input_grad[1] else None
+        dshift = None
+        if ctx.needs_input_grad[3] and shift_is_param:
+            # with scale None the shift is a plain bias: d/dshift = sum of the masked upstream gradient
+            dshift = bias_grad(dconv)
+        dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil) if ctx.needs_input_grad[0] else None
+        return dx, dw, None, dshift, dres, None, None, None, None, None
+
+
+class _MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x, "x")
+        B, Cc, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, Cc, OH, OW, device=x.device, dtype=torch.float32)
+        am = torch.empty(B, Cc, OH, OW, device=x.device, dtype=torch.uint8)
+        check(lib().wsdl_maxpool3x3s2_fwd(_p(x), _p(y), _p(am), B * Cc, H, W, _stream()))
+        ctx.save_for_backward(am)
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        B, Cc, H, W = ctx.xshape
+        dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+        check(lib().wsdl_maxpool3x3s2_bwd(_p(_dense(dy)), _p(am), _p(dx), B * Cc, H, W, _stream()))
+        return dx
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x, "x")
+        B, Cc, H, W = x.shape
+        y = torch.empty(B, Cc, 1, 1, device=x.device, dtype=torch.float32)
+        check(lib().wsdl_global_avgpool_fwd(_p(x), _p(y), B * Cc, H * W, _stream()))
+        ctx.xshape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cc, H, W = ctx.xshape
+        dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
+        check(lib().wsdl_global_avgpool_bwd(_p(_dense(dy)), _p(dx), B * Cc, H * W, 0, _stream()))
+        return dx
+
+
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W):
+        x = _dense(x, "x")
+        B, Cc, h, w = x.shape
+        y = torch.empty(B, Cc, H, W, device=x.device, dtype=torch.float32)
+        check(lib().wsdl_bilinear_fwd(_p(x), _p(y), B, Cc, h, w, H, W, 0, _stream()))
+        ctx.shape = (B, Cc, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Cc, h, w, H, W = ctx.shape
+        dy, dy_bs = _planes(dy, "dy")
+        dx = torch.empty(B, Cc, h, w, device=dy.device, dtype=torch.float32)
+        check(lib().wsdl_bilinear_bwd(_p(dy), _p(dx), B, Cc, h, w, H, W, dy_bs, _stream()))
+        return dx, None, None
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, mask):
+        x = _dense(x, "x")
+        y = torch.empty_like(x)
+        gen = mask is None
+        if gen:
+            mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+        else:
+            mask = _req(mask, "dropout mask", torch.uint8).contiguous()
+        check(lib().wsdl_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), int(gen), _stream()))
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _dense(dy, "dy")
+        dx = torch.empty_like(dy)
+        check(lib().wsdl_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _stream()))
+        return dx, None, None, None
+
+
+class _ConcatChannels(torch.autograd.Function):
+    """torch.cat(dim=1) with plane copies; backward hands out zero-copy channel slices."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H, W = xs[0].shape
+        Cs = [int(t.shape[1]) for t in xs]
+        out = torch.empty(B, sum(Cs), H, W, device=xs[0].device, dtype=torch.float32)
+        off, tot = 0, sum(Cs) * H * W
+        for t, c in zip(xs, Cs):
+            t = _dense(t, "cat input")
+            dst = out[:, off:off + c]
+            check(lib().wsdl_copy_planes(_p(t), _vp(dst.data_ptr()), B, c, H * W, 0, tot, _stream()))
+            off += c
+        ctx.Cs = Cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, off = [], 0
+        for c in ctx.Cs:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+class _AddAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, relu):
+        a, b = _dense(a, "a"), _dense(b, "b")
+        y = torch.empty_like(a)
+        check(lib().wsdl_add(_p(a), _p(b), _p(y), a.numel(), int(relu), _stream()))
+        ctx.relu = relu
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        if ctx.relu:
+            dy4 = dy if dy.dim() == 4 else dy.reshape(dy.shape[0], -1, 1, 1)
+            y4 = y.reshape(dy4.shape)
+            g, _ = affine_act_bwd(dy4, y4, None, True, True, False)
+            g = g.reshape(dy.shape)
+        else:
+            g = dy
+        return g, g, None
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    """nn.CrossEntropyLoss() on (B,C,H,W) logits, int64 labels; forward and gradient in one kernel."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = _dense(logits, "logits")
+        labels = _req(labels, "labels", torch.int64).contiguous()
+        B, Cc, H, W = logits.shape
+        if tuple(labels.shape) != (B, H, W):
+            raise WsdlError(f"cross entropy: labels {tuple(labels.shape)} do not match logits {tuple(logits.shape)}")
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        need = logits.requires_grad
+        dl = torch.empty_like(logits) if need else None
+        ws = workspace(lib().wsdl_reduce_workspace(), logits.device)
+        check(lib().wsdl_softmax_ce_fwd_bwd(_p(logits), _p(labels), _p(loss), _p(dl), B, Cc, H, W, 1.0, _p(ws),
+                                            ws.numel(), _stream()))
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        out = torch.empty_like(dl)
+        check(lib().wsdl_scale_by_device_scalar(_p(dl), _p(_dense(g.reshape(1))), _p(out), dl.numel(), _stream()))
+        return out, None
+
+
+class _PairwiseAffinityLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, preds, image, window, sigma_color, sigma_space, apply_softmax, normalise):
+        preds, image = _dense(preds, "preds"), _dense(image, "image")
+        B, Cc, H, W = preds.shape
+        if tuple(image.shape) != (B, 3, H, W):
+            raise WsdlError(f"pairwise loss: image {tuple(image.shape)} does not match preds {tuple(preds.shape)}")
+        loss = torch.empty(B if normalise else 1, device=preds.device, dtype=torch.float32)
+        need = preds.requires_grad
+        dp = torch.empty_like(preds) if need else None
+        ws = workspace(lib().wsdl_pairwise_workspace(B, H, W), preds.device)
+        check(lib().wsdl_pairwise_affinity_loss_fwd_bwd(_p(preds), _p(image), _p(loss), _p(dp), B, Cc, H, W,
+                                                        int(window), float(sigma_color), float(sigma_space or 0.0),
+                                                        int(apply_softmax), int(normalise), _p(ws), ws.numel(),
+                                                        _stream()))
+        ctx.save_for_backward(dp)
+        ctx.normalise = normalise
+        return loss if normalise else loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        if ctx.normalise:
+            # per-image upstream gradients: one scale launch per image (B is small on this path)
+            out = torch.empty_like(dp)
+            g = _dense(g.reshape(-1))
+            n = dp[0].numel()
+            for b in range(dp.shape[0]):
+                check(lib().wsdl_scale_by_device_scalar(_vp(dp[b].data_ptr()), _vp(g[b:b + 1].data_ptr()),
+                                                        _vp(out[b].data_ptr()), n, _stream()))
+        else:
+            out = torch.empty_like(dp)
+            check(lib().wsdl_scale_by_device_scalar(_p(dp), _p(_dense(g.reshape(1))), _p(out), dp.numel(), _stream()))
+        return out, None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------ functional API
+def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
+                momentum=0.1, eps=1e-5, training=True):
+    if training:
+        return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
+                                bool(relu), momentum, eps)
+    scale, shift = bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+    return _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False)
+
+
+def conv_bias_act(x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, residual=None):
+    return _ConvAffineAct.apply(x, weight, None, bias, residual, stride, pad, dil, bool(relu), bias is not None)
+
+
+def linear(x, weight, bias=None):
+    """nn.Linear on (B,F) as a 1x1 convolution over a 1x1 map."""
+    B, Fin = x.shape
+    y = conv_bias_act(x.reshape(B, Fin, 1, 1), weight.reshape(weight.shape[0], Fin, 1, 1), bias)
+    return y.reshape(B, -1)
+
+
+def max_pool_3x3_s2(x):
+    return _MaxPool3x3s2.apply(x)
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+def bilinear_resize(x, size):
+    return _Bilinear.apply(x, int(size[0]), int(size[1]))
+
+
+def dropout(x, p, training=True, seed=None, mask=None):
+    if not training or p == 0.0:
+        return x
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _Dropout.apply(x, p, seed, mask)
+
+
+def concat_channels(xs):
+    return _ConcatChannels.apply(*xs)
+
+
+def add_act(a, b, relu=False):
+    return _AddAct.apply(a, b, bool(relu))
+
+
+def cross_entropy(logits, labels):
+    return _SoftmaxCE.apply(logits, labels)
+
+
+def pairwise_affinity_loss(preds, image, window=5, sigma_color=0.1, sigma_space=0.0, apply_softmax=True,
+                           normalise=0):
+    return _PairwiseAffinityLoss.apply(preds, image, window, sigma_color, sigma_space, bool(apply_softmax),
+                                       int(normalise))
+
+
+def compute_affinities(image, sigma_color=0.1, sigma_space=5, window_size=5):
+    image = _dense(image, "image")
+    B, _, H, W = image.shape
+    K = window_size * window_size - 1
+    out = torch.empty(K, B, 1, H, W, device=image.device, dtype=torch.float32)
+    check(lib().wsdl_compute_affinities(_p(image), _p(out), B, H, W, int(window_size), float(sigma_color),
+                                        float(sigma_space or 0.0), _stream()))
+    return out
+
+
+def layercam_epilogue(acts, grads, out_hw=(224, 224), alpha=1.0, variant="modular", thresh=None):
+    """acts/grads: lists of (B,C,h,w) device tensors -> cam (B,outH,outW) [, uint8 mask]."""
+    n = len(acts)
+    acts = [_dense(a.detach(), "act") for a in acts]
+    grads = [_dense(g.detach(), "grad") for g in grads]
+    B = acts[0].shape[0]
+    for a, g in zip(acts, grads):
+        if a.shape != g.shape or a.shape[0] != B:
+            raise WsdlError("layercam: activation / gradient shape mismatch")
+    IA = C.c_int * n
+    Cs, hs, ws_ = IA(*[a.shape[1] for a in acts]), IA(*[a.shape[2] for a in acts]), IA(*[a.shape[3] for a in acts])
+    PA = _vp * n
+    pa, pg = PA(*[a.data_ptr() for a in acts]), PA(*[g.data_ptr() for g in grads])
+    dev = acts[0].device
+    cam = torch.empty(B, out_hw[0], out_hw[1], device=dev, dtype=torch.float32)
+    mask = torch.empty(B, out_hw[0], out_hw[1], device=dev, dtype=torch.uint8) if thresh is not None else None
+    nbytes = lib().wsdl_layercam_workspace(n, B, Cs, hs, ws_)
+    if nbytes == 0:
+        raise WsdlError("layercam: bad layer geometry")
+    ws = workspace(nbytes, dev)
+    var = {"modular": 0, "notebook": 1}[variant]
+    check(lib().wsdl_layercam_epilogue(pa, pg, Cs, hs, ws_, n, B, out_hw[0], out_hw[1], float(alpha), var, _p(cam),
+                                       float(thresh) if thresh is not None else -1.0, _p(mask), _p(ws), ws.numel(),
+                                       _stream()))
+    return (cam, mask) if thresh is not None else cam
+
+
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    for t in (p, g, m, v):
+        _req(t, "adam buffer")
+    check(lib().wsdl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                               float(eps), int(step), float(grad_scale), _stream()))
+
+
+def softmax_channels(x):
+    return _SoftmaxChannels.apply(x)
+
+
+class _SoftmaxChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _dense(x, "x")
+        B, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * Cc)
+        y = torch.empty_like(x)
+        check(lib().wsdl_softmax_fwd(_p(x), _p(y), B, Cc, HW, _stream()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _dense(dy, "dy")
+        B, Cc = y.shape[0], y.shape[1]
+        dx = torch.empty_like(y)
+        check(lib().wsdl_softmax_bwd(_p(y), _p(dy), _p(dx), B, Cc, y.numel() // (B * Cc), _stream()))
+        return dx
+
+
+class _KLDivBatchMean(torch.autograd.Function):
+    """F.kl_div((xn + 1e-8).log(), s, reduction='batchmean') and d/dxn."""
+
+    @staticmethod
+    def forward(ctx, xn, s):
+        xn, s = _dense(xn, "xn"), _dense(s, "s")
+        loss = torch.empty((), device=xn.device, dtype=torch.float32)
+        dxn = torch.empty_like(xn)
+        ws = workspace(lib().wsdl_reduce_workspace(), xn.device)
+        check(lib().wsdl_kl_div_fwd_bwd(_p(xn), _p(s), _p(loss), _p(dxn), xn.numel(), xn.shape[0], _p(ws), ws.numel(),
+                                        _stream()))
+        ctx.save_for_backward(dxn)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dxn,) = ctx.saved_tensors
+        out = torch.empty_like(dxn)
+        check(lib().wsdl_scale_by_device_scalar(_p(dxn), _p(_dense(g.reshape(1))), _p(out), dxn.numel(), _stream()))
+        return out, None
+
+
+def kl_div_batchmean(xn, s):
+    return _KLDivBatchMean.apply(xn, s)
+
+
+def prof_enable(on):
+    check(lib().wsdl_prof_enable(int(on)))
+
+
+def prof_reset():
+    check(lib().wsdl_prof_reset())
+
+
+def prof_collect(cls):
+    n, ms, work = C.c_longlong(0), C.c_double(0), C.c_double(0)
+    check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work)))
+    return n.value, ms.value, work.value

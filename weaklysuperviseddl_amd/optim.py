@@ -1,0 +1,54 @@
+"""FlatAdam - torch.optim.Adam semantics (defaults betas=(0.9,0.999), eps=1e-8, no weight decay;
+reference TraditionalModel/SegmentationModel.py:91) as ONE kernel launch over flat buffers.
+
+Parameters are re-homed into one contiguous fp32 buffer (``p.data`` become views) and so are their
+gradients (``p.grad`` views of one flat buffer), which is also what the data-parallel gradient
+all-reduce buckets (``dp.GradBucketReducer``) operate on: 39.6 M parameters = 158.5 MB per replica.
+"""
+import torch
+
+from . import ops
+
+_ALIGN = 64   # floats; keeps every parameter 256-byte aligned inside the flat buffer
+
+
+class FlatAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("FlatAdam: empty parameter list")
+        dev = self.params[0].device
+        self.lr, self.betas, self.eps, self.grad_scale = lr, betas, eps, grad_scale
+        self.step_count = 0
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = n
+        self.flat_param = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.flat_grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+        self.pre_step_hook = None      # e.g. wait for the gradient all-reduce
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+
+    def step(self):
+        if self.pre_step_hook is not None:
+            self.pre_step_hook()
+        self.step_count += 1
+        if self.flat_param.is_cuda:
+            ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
+        else:
+            raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
