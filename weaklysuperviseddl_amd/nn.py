@@ -54,6 +54,10 @@ class BatchNorm2d(nn.Module):
             self._pending_steps = 0
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._pending_steps = 0
+        super()._load_from_state_dict(*args, **kwargs)
+
     def forward(self, x):
         # stand-alone BN = identity 1x1 "conv" is wasteful; only the fused path is used by the models
         raise RuntimeError("BatchNorm2d is only run fused behind a Conv2d (see FusedSequential / conv_bn)")

@@ -80,6 +80,8 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
     if Cin2 != Cin:
         raise WsdlError(f"conv2d: input has {Cin} channels, weight expects {Cin2}")
     OH, OW = conv_out_hw(H, W, kh, stride, pad, dil)
+    if OH <= 0 or OW <= 0:
+        raise WsdlError(f"conv2d: empty output ({OH} x {OW})")
     if out is None:
         out = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
         y_bs = Cout * OH * OW
