@@ -42,9 +42,16 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
 /* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
  * When enabled every launch of the instrumented classes is bracketed by hipEventRecord on the
  * launch stream.  wsdl_prof_collect synchronises the events and returns, per class, the number of
- * launches, summed milliseconds and summed algorithmic work (flops for conv classes, bytes else). */
-enum { WSDL_PROF_CONV_FWD = 0, WSDL_PROF_CONV_DGRAD = 1, WSDL_PROF_CONV_WGRAD = 2,
-       WSDL_PROF_PAIRWISE = 3, WSDL_PROF_LAYERCAM = 4, WSDL_PROF_NCLASSES = 5 };
+ * launches, summed milliseconds and summed algorithmic work (flops for conv classes, bytes else).
+ * Classes are kernel instantiations, so a class lines up with one row of `rocprofv3 --stats`. */
+enum { WSDL_PROF_IGEMM_128A = 0,  /* conv_igemm_kernel<128,true>  (forward + dgrad launches) */
+       WSDL_PROF_IGEMM_128U = 1,  /* conv_igemm_kernel<128,false> */
+       WSDL_PROF_IGEMM_64A = 2,   /* conv_igemm_kernel<64,true>   */
+       WSDL_PROF_IGEMM_64U = 3,   /* conv_igemm_kernel<64,false>  */
+       WSDL_PROF_WGRAD_128 = 4,   /* conv_wgrad_kernel<128> */
+       WSDL_PROF_WGRAD_64 = 5,    /* conv_wgrad_kernel<64>  */
+       WSDL_PROF_PAIRWISE = 6, WSDL_PROF_LAYERCAM = 7, WSDL_PROF_NCLASSES = 8 };
+const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work);
 int wsdl_prof_reset(void);

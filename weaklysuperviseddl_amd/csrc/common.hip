@@ -57,6 +57,14 @@ const char* wsdl_last_error(void) { return wsdl::g_err; }
 int wsdl_version(void) { return 100; }
 const char* wsdl_target_arch(void) { return "gfx950"; }
 
+const char* wsdl_prof_class_name(int cls) {
+    static const char* names[WSDL_PROF_NCLASSES] = {
+        "conv_igemm_kernel<128, true>", "conv_igemm_kernel<128, false>", "conv_igemm_kernel<64, true>",
+        "conv_igemm_kernel<64, false>", "conv_wgrad_kernel<128>", "conv_wgrad_kernel<64>",
+        "pairwise_kernel", "layercam_partial_kernel"};
+    return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
+}
+
 int wsdl_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
     wsdl::g_prof_on = on != 0;

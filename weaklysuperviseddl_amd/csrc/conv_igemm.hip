@@ -402,8 +402,11 @@ int check_geom(int B, int Cin, int H, int W, int Cout, int kh, int kw, int strid
     return WSDL_OK;
 }
 
-int launch_igemm(const ConvP& p, hipStream_t s) {
+int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
     const bool aligned = (p.Cin % 16) == 0;
+    const int cls = p.Cout <= 64 ? (aligned ? WSDL_PROF_IGEMM_64A : WSDL_PROF_IGEMM_64U)
+                                 : (aligned ? WSDL_PROF_IGEMM_128A : WSDL_PROF_IGEMM_128U);
+    wsdl::ProfScope prof(cls, s, flops);
     if (p.Cout <= 64) {
         dim3 grid(wsdl::cdiv(p.P, 256), wsdl::cdiv(p.Cout, 64));
         if (aligned)
@@ -466,8 +469,7 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Ci
     p.res_bs = res_bs ? res_bs : (long long)Cout * OH * OW;
     WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
     p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
-    wsdl::ProfScope prof(WSDL_PROF_CONV_FWD, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
-    return launch_igemm(p, wsdl::as_stream(stream));
+    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
 }
 
 int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, int Cin, int H, int W,
@@ -487,9 +489,7 @@ int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, 
     p.res_bs = p.y_bs;
     WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
     p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
-    wsdl::ProfScope prof(WSDL_PROF_CONV_DGRAD, wsdl::as_stream(stream),
-                         2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin);
-    return launch_igemm(p, wsdl::as_stream(stream));
+    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin);
 }
 
 size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
@@ -523,13 +523,15 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     const int chunks = wsdl::cdiv(p.P, 32);
     p.chunks_per_split = wsdl::cdiv(chunks, S);
     hipStream_t s = wsdl::as_stream(stream);
-    wsdl::ProfScope prof(WSDL_PROF_CONV_WGRAD, s, 2.0 * p.P * (double)Cout * p.N);
-    if (Cout <= 64) {
-        dim3 grid(wsdl::cdiv(p.N, 256), wsdl::cdiv(Cout, 64), S);
-        hipLaunchKernelGGL((conv_wgrad_kernel<64>), grid, dim3(kThreads), 0, s, p);
-    } else {
-        dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 128), S);
-        hipLaunchKernelGGL((conv_wgrad_kernel<128>), grid, dim3(kThreads), 0, s, p);
+    {
+        wsdl::ProfScope prof(Cout <= 64 ? WSDL_PROF_WGRAD_64 : WSDL_PROF_WGRAD_128, s, 2.0 * p.P * (double)Cout * p.N);
+        if (Cout <= 64) {
+            dim3 grid(wsdl::cdiv(p.N, 256), wsdl::cdiv(Cout, 64), S);
+            hipLaunchKernelGGL((conv_wgrad_kernel<64>), grid, dim3(kThreads), 0, s, p);
+        } else {
+            dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 128), S);
+            hipLaunchKernelGGL((conv_wgrad_kernel<128>), grid, dim3(kThreads), 0, s, p);
+        }
     }
     WSDL_LAUNCH_CHECK();
     const long long total = (long long)Cout * p.N;

@@ -616,6 +616,13 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
+PROF_NCLASSES = 8
+
+
+def prof_class_name(cls):
+    return lib().wsdl_prof_class_name(int(cls)).decode()
+
+
 def prof_collect(cls):
     n, ms, work = C.c_longlong(0), C.c_double(0), C.c_double(0)
     check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work)))
