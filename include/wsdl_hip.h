@@ -44,13 +44,15 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  * launch stream.  wsdl_prof_collect synchronises the events and returns, per class, the number of
  * launches, summed milliseconds and summed algorithmic work (flops for conv classes, bytes else).
  * Classes are kernel instantiations, so a class lines up with one row of `rocprofv3 --stats`. */
-enum { WSDL_PROF_IGEMM_128A = 0,  /* conv_igemm_kernel<128,true>  (forward + dgrad launches) */
-       WSDL_PROF_IGEMM_128U = 1,  /* conv_igemm_kernel<128,false> */
-       WSDL_PROF_IGEMM_64A = 2,   /* conv_igemm_kernel<64,true>   */
-       WSDL_PROF_IGEMM_64U = 3,   /* conv_igemm_kernel<64,false>  */
-       WSDL_PROF_WGRAD_128 = 4,   /* conv_wgrad_kernel<128> */
-       WSDL_PROF_WGRAD_64 = 5,    /* conv_wgrad_kernel<64>  */
-       WSDL_PROF_PAIRWISE = 6, WSDL_PROF_LAYERCAM = 7, WSDL_PROF_NCLASSES = 8 };
+enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (forward + dgrad launches) */
+       WSDL_PROF_IGEMM_128x128_U = 1,  /* conv_igemm_kernel<128,128,2,false> (K not a multiple of 16)     */
+       WSDL_PROF_IGEMM_128x64_A = 2, WSDL_PROF_IGEMM_128x64_U = 3,
+       WSDL_PROF_IGEMM_64x256_A = 4, WSDL_PROF_IGEMM_64x256_U = 5,
+       WSDL_PROF_IGEMM_64x128_A = 6, WSDL_PROF_IGEMM_64x128_U = 7,
+       WSDL_PROF_WGRAD_128x128 = 8,    /* conv_wgrad_kernel<128,128,2> */
+       WSDL_PROF_WGRAD_64x128 = 9,     /* conv_wgrad_kernel<64,128,1>  */
+       WSDL_PROF_WGRAD_FAST_128x128 = 10,  /* conv_wgrad_fast_kernel<128,128,2> */
+       WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12, WSDL_PROF_NCLASSES = 13 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work);

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the conv kernels on the unique DeepLabV3-R50 shapes at 256x256.
+
+    python tools/conv_shapes_bench.py [--batch 16] [--reps 10] [--only fwd|dgrad|wgrad]
+Prints one line per (shape, pass): microseconds, nominal TFLOP/s, fraction of the fp32 MFMA peak.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from weaklysuperviseddl_amd import ops  # noqa: E402
+
+PEAK = 157.3
+# (count, Cin, Cout, k, stride, dil, Hin, name)
+SHAPES = [
+    (1, 3, 64, 7, 2, 1, 256, "conv1"),
+    (1, 64, 64, 1, 1, 1, 64, "l1.0.conv1"),
+    (3, 64, 64, 3, 1, 1, 64, "l1.conv2"),
+    (4, 64, 256, 1, 1, 1, 64, "l1.conv3/ds"),
+    (2, 256, 64, 1, 1, 1, 64, "l1.conv1"),
+    (1, 256, 128, 1, 1, 1, 64, "l2.0.conv1"),
+    (1, 128, 128, 3, 2, 1, 64, "l2.0.conv2 s2"),
+    (4, 128, 512, 1, 1, 1, 32, "l2.conv3"),
+    (1, 256, 512, 1, 2, 1, 64, "l2.0.ds s2"),
+    (3, 512, 128, 1, 1, 1, 32, "l2.conv1"),
+    (3, 128, 128, 3, 1, 1, 32, "l2.conv2"),
+    (1, 512, 256, 1, 1, 1, 32, "l3.0.conv1"),
+    (2, 256, 256, 3, 1, 1, 32, "l3.0.conv2/head3x3"),
+    (6, 256, 1024, 1, 1, 1, 32, "l3.conv3"),
+    (1, 512, 1024, 1, 1, 1, 32, "l3.0.ds"),
+    (5, 1024, 256, 1, 1, 1, 32, "l3.conv1"),
+    (5, 256, 256, 3, 1, 2, 32, "l3.conv2 d2"),
+    (1, 1024, 512, 1, 1, 1, 32, "l4.0.conv1"),
+    (1, 512, 512, 3, 1, 2, 32, "l4.0.conv2 d2"),
+    (3, 512, 2048, 1, 1, 1, 32, "l4.conv3"),
+    (1, 1024, 2048, 1, 1, 1, 32, "l4.0.ds"),
+    (2, 2048, 512, 1, 1, 1, 32, "l4.conv1"),
+    (2, 512, 512, 3, 1, 4, 32, "l4.conv2 d4"),
+    (1, 2048, 256, 1, 1, 1, 32, "aspp 1x1"),
+    (1, 2048, 256, 3, 1, 12, 32, "aspp d12"),
+    (1, 2048, 256, 3, 1, 24, 32, "aspp d24"),
+    (1, 2048, 256, 3, 1, 36, 32, "aspp d36"),
+    (1, 1280, 256, 1, 1, 1, 32, "aspp project"),
+    (1, 1024, 256, 3, 1, 1, 32, "aux 3x3 (fwd only)"),
+]
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--scale", type=int, default=1, help="2 = 512x512 inputs")
+    ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names to run")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B = args.batch
+    tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    print(f"{'shape':24s} {'pass':6s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  x count")
+    want = [w for w in args.shapes.split(",") if w]
+    for cnt, Cin, Cout, k, s, d, H, name in SHAPES:
+        if want and not any(w in name for w in want):
+            continue
+        H = H * args.scale
+        pad = (k // 2) * d if k > 1 else 0
+        x = torch.randn(B, Cin, H, H, device=dev)
+        w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05
+        wf, wd = ops.prep_weights(w)
+        OH, OW = ops.conv_out_hw(H, H, k, s, pad, d)
+        dy = torch.randn(B, Cout, OH, OW, device=dev)
+        flops = 2.0 * B * OH * OW * Cout * Cin * k * k
+        passes = {"fwd": lambda: ops.conv2d_fwd(x, wf, w.shape, s, pad, d),
+                  "dgrad": lambda: ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d),
+                  "wgrad": lambda: ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)}
+        for pname, fn in passes.items():
+            if args.only and pname != args.only:
+                continue
+            if "fwd only" in name and pname != "fwd":
+                continue
+            if name == "conv1" and pname == "dgrad":
+                continue
+            us = timeit(fn, args.reps)
+            tf = flops / us / 1e6
+            tot[pname][0] += us * cnt
+            tot[pname][1] += flops * cnt
+            print(f"{name:24s} {pname:6s} {us:9.1f} {tf:8.1f} {tf / PEAK:6.3f}  x{cnt}")
+    for pname, (us, fl) in tot.items():
+        if us:
+            print(f"TOTAL {pname:6s} {us / 1e3:8.2f} ms  {fl / us / 1e6:6.1f} TFLOP/s nominal ({fl / us / 1e6 / PEAK:.3f} of peak)")
+
+
+if __name__ == "__main__":
+    main()

@@ -59,8 +59,11 @@ const char* wsdl_target_arch(void) { return "gfx950"; }
 
 const char* wsdl_prof_class_name(int cls) {
     static const char* names[WSDL_PROF_NCLASSES] = {
-        "conv_igemm_kernel<128, true>", "conv_igemm_kernel<128, false>", "conv_igemm_kernel<64, true>",
-        "conv_igemm_kernel<64, false>", "conv_wgrad_kernel<128>", "conv_wgrad_kernel<64>",
+        "conv_igemm_fast_kernel<128, 128, 2>", "conv_igemm_kernel<128, 128, 2, false>",
+        "conv_igemm_fast_kernel<128, 64, 2>", "conv_igemm_kernel<128, 64, 2, false>",
+        "conv_igemm_fast_kernel<64, 256, 1>", "conv_igemm_kernel<64, 256, 1, false>",
+        "conv_igemm_fast_kernel<64, 128, 1>", "conv_igemm_kernel<64, 128, 1, false>",
+        "conv_wgrad_kernel<128, 128, 2>", "conv_wgrad_kernel<64, 128, 1>", "conv_wgrad_fast_kernel<128, 128, 2>",
         "pairwise_kernel", "layercam_partial_kernel"};
     return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
 }

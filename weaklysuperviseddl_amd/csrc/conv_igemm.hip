@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -38,21 +39,29 @@ struct ConvP {
     long long x_bs, y_bs, res_bs;
     int relu, accumulate;
     int P;  // B*OH*OW
+    unsigned x_bytes;   // extent of x in bytes (buffer descriptor; < 2^31 for the fast path)
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int BM, bool ALIGNED>
+// Pipeline: LDS double buffer, ONE barrier per K-chunk.  Iteration q: registers (holding chunk q+1, whose
+// global loads were issued one iteration ago) -> LDS[(q+1)&1]; issue the global loads of chunk q+2; MFMAs on
+// LDS[q&1]; barrier.  Taps whose source pixels are padding for EVERY pixel of the block's tile are skipped
+// (ALIGNED path): exact zeros are not multiplied (ASPP dilation 12/24/36 on 32x32 maps: 52 % of the
+// nominal K-chunks never execute).
+template <int BM, int BN, int WM, bool ALIGNED>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
     constexpr int BK = 16;
-    constexpr int WM = BM / 64;        // waves along M
-    constexpr int WN = 4 / WM;         // waves along N
-    constexpr int BN = WN * 64;
+    constexpr int WN = 4 / WM;              // 4 waves arranged WM x WN
+    constexpr int MI = BM / WM / 32;        // 32x32 MFMA tiles per wave along M
+    constexpr int NI = BN / WN / 32;        // ... along N (pixels)
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
     constexpr int A_F4 = BK * BM / 4 / kThreads;   // float4 per thread for the A tile
     constexpr int B_STEP = kThreads / BN;          // k rows covered per pass
     constexpr int B_PER = BK / B_STEP;             // loads per thread for the B tile
 
-    __shared__ float As[BK * BM];
-    __shared__ float Bs[BK * BN];
+    __shared__ float As[2][BK * BM];
+    __shared__ float Bs[2][BK * BN];
+    __shared__ int vtaps[64];                      // ids of the taps that touch at least one real pixel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -76,23 +85,58 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
     const float* xb = p.x + (long long)pb * p.x_bs;
     const bool cout_vec = (p.Cout & 3) == 0;
 
-    f32x16 acc[2][2];
+    // ---- chunk list
+    const int T = p.KH * p.KW;
+    int nq;                 // number of K-chunks this block executes
+    int cpt = 1;            // chunks per tap (ALIGNED)
+    if (ALIGNED) {
+        cpt = p.Cin / BK;
+        int nv = 0;
+        for (int t = 0; t < T; ++t) {
+            const int ti = t / p.KW, tj = t - ti * p.KW;
+            const int nh = poh * p.ah + ti * p.bh + p.ch;
+            const int nw = pow_ * p.ah + tj * p.bh + p.ch;
+            bool ok = pix_ok && nh >= 0 && nw >= 0;
+            if (ok) {
+                const int ih = nh / p.sh, iw = nw / p.sh;
+                ok = (ih * p.sh == nh) && (iw * p.sh == nw) && ih < p.H && iw < p.W;
+            }
+            if (__syncthreads_or(ok)) {
+                if (tid == 0) vtaps[nv] = t;
+                ++nv;
+            }
+        }
+        nq = nv * cpt;
+        __syncthreads();
+    } else {
+        nq = (p.K + BK - 1) / BK;
+    }
+
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[A_F4];
     float rb[B_PER];
 
-    auto load_tiles = [&](int k0) {
+    auto load_tiles = [&](int q) {
+        int k0, tap = 0;
+        if (ALIGNED) {
+            const int vi = q / cpt;
+            tap = vtaps[vi];
+            k0 = tap * p.Cin + (q - vi * cpt) * BK;
+        } else {
+            k0 = q * BK;
+        }
         // A: weights, k-major
 #pragma unroll
         for (int e = 0; e < A_F4; ++e) {
-            const int q = tid + e * kThreads;
-            const int row = q / (BM / 4), c4 = (q % (BM / 4)) * 4;
+            const int qq = tid + e * kThreads;
+            const int row = qq / (BM / 4), c4 = (qq % (BM / 4)) * 4;
             const int k = k0 + row, m = m0 + c4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < p.K) {
@@ -110,7 +154,6 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
         }
         // B: gathered activations
         if (ALIGNED) {
-            const int tap = k0 / p.Cin;
             const int ci0 = k0 - tap * p.Cin + kr;
             const int ti = tap / p.KW, tj = tap - ti * p.KW;
             const int nh = poh * p.ah + ti * p.bh + p.ch;
@@ -132,8 +175,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
                 const int k = k0 + kr + e * B_STEP;
                 float v = 0.f;
                 if (pix_ok && k < p.K) {
-                    const int tap = k / p.Cin, ci = k - tap * p.Cin;
-                    const int ti = tap / p.KW, tj = tap - ti * p.KW;
+                    const int tp = k / p.Cin, ci = k - tp * p.Cin;
+                    const int ti = tp / p.KW, tj = tp - ti * p.KW;
                     const int nh = poh * p.ah + ti * p.bh + p.ch;
                     const int nw = pow_ * p.ah + tj * p.bh + p.ch;
                     if (nh >= 0 && nw >= 0) {
@@ -147,54 +190,249 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
         }
     };
 
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < A_F4; ++e) {
-            const int q = tid + e * kThreads;
-            *reinterpret_cast<float4*>(&As[q * 4]) = ra[e];   // row-major [BK][BM], q*4 = row*BM + c4
+            const int qq = tid + e * kThreads;
+            *reinterpret_cast<float4*>(&As[buf][qq * 4]) = ra[e];   // row-major [BK][BM]
         }
 #pragma unroll
-        for (int e = 0; e < B_PER; ++e) Bs[(kr + e * B_STEP) * BN + pl] = rb[e];
+        for (int e = 0; e < B_PER; ++e) Bs[buf][(kr + e * B_STEP) * BN + pl] = rb[e];
     };
 
-    const int nchunks = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();            // previous chunk's MFMA reads are done
-        store_tiles();
-        __syncthreads();
-        if (c + 1 < nchunks) load_tiles((c + 1) * BK);   // in flight under the MFMAs below
+    if (nq > 0) {
+        load_tiles(0);
+        store_tiles(0);
+        if (nq > 1) load_tiles(1);
+    }
+    __syncthreads();
+    {
         const int l31 = lane & 31, lh = lane >> 5;
+        for (int q = 0; q < nq; ++q) {
+            const int cur = q & 1;
+            if (q + 1 < nq) store_tiles(cur ^ 1);      // chunk q+1 (registers) -> the idle LDS buffer
+            if (q + 2 < nq) load_tiles(q + 2);         // in flight under the MFMAs below
+            const float* Ab = As[cur];
+            const float* Bb = Bs[cur];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], b[2];
+            for (int kk = 0; kk < BK; kk += 2) {
+                float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(kk + lh) * BM + wm * 64 + i * 32 + l31];
+                for (int i = 0; i < MI; ++i) a[i] = Ab[(kk + lh) * BM + wm * (MI * 32) + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk + lh) * BN + wn * 64 + j * 32 + l31];
+                for (int j = 0; j < NI; ++j) b[j] = Bb[(kk + lh) * BN + wn * (NI * 32) + j * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
         }
     }
 
     // ---- epilogue: D row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int opix = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NI; ++j) {
+        const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
         if (opix >= p.P) continue;
         const int ob = opix / OHOW;
         const int orp = opix - ob * OHOW;
         float* yb = p.y + (long long)ob * p.y_bs + orp;
         const float* rbp = p.res ? p.res + (long long)ob * p.res_bs + orp : nullptr;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.scale) v *= p.scale[co];
+                if (p.shift) v += p.shift[co];
+                const long long off = (long long)co * OHOW;
+                if (rbp) v += rbp[off];
+                if (p.accumulate) v += yb[off];
+                if (p.relu) v = fmaxf(v, 0.f);
+                yb[off] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast path (Cin % 16 == 0, Cout % 4 == 0, x < 2 GiB): same tiling / pipeline as above, but all global
+// traffic goes through buffer descriptors: per-lane byte offsets change only when the tap changes, the
+// per-chunk advance (ci block, k row of the weights) rides in the scalar offset, and padding / ragged
+// edges are lanes whose offset is parked beyond num_records (hardware returns 0) - no exec-mask
+// branches and no 64-bit address arithmetic inside the K loop.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int WM>
+__global__ __launch_bounds__(kThreads) void conv_igemm_fast_kernel(ConvP p) {
+    constexpr int BK = 16;
+    constexpr int WN = 4 / WM;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
+    constexpr int A_F4 = BK * BM / 4 / kThreads;
+    constexpr int B_STEP = kThreads / BN;
+    constexpr int B_PER = BK / B_STEP;
+    constexpr unsigned kOOB = 0x80000000u;
+
+    __shared__ float As[2][BK * BM];
+    __shared__ float Bs[2][BK * BN];
+    __shared__ int vtaps[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int OHOW = p.OH * p.OW;
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, p.K * p.Cout * 4, 0x00020000);
+
+    const int pl = tid % BN, kr = tid / BN;
+    const int pix = n0 + pl;
+    const bool pix_ok = pix < p.P;
+    int pb = 0, poh = 0, pow_ = 0;
+    if (pix_ok) {
+        pb = pix / OHOW;
+        const int r = pix - pb * OHOW;
+        poh = r / p.OW;
+        pow_ = r - poh * p.OW;
+    }
+    const unsigned img_off = (unsigned)((long long)pb * p.x_bs) + (unsigned)(kr * HW);   // elements
+
+    auto tap_src = [&](int t, int& sp) {      // source pixel of this thread's output pixel under tap t
+        const int ti = t / p.KW, tj = t - ti * p.KW;
+        const int nh = poh * p.ah + ti * p.bh + p.ch;
+        const int nw = pow_ * p.ah + tj * p.bh + p.ch;
+        bool ok = pix_ok && nh >= 0 && nw >= 0;
+        int ih = nh, iw = nw;
+        if (p.sh != 1) {
+            ih = nh / p.sh;
+            iw = nw / p.sh;
+            ok = ok && (ih * p.sh == nh) && (iw * p.sh == nw);
+        }
+        ok = ok && ih < p.H && iw < p.W;
+        sp = ih * p.W + iw;
+        return ok;
+    };
+
+    const int T = p.KH * p.KW;
+    const int cpt = p.Cin / BK;
+    int nv = 0;
+    for (int t = 0; t < T; ++t) {
+        int sp;
+        const bool ok = tap_src(t, sp);
+        if (__syncthreads_or(ok)) {
+            if (tid == 0) vtaps[nv] = t;
+            ++nv;
+        }
+    }
+    const int nq = nv * cpt;
+    __syncthreads();
+
+    // weights: per-thread constant byte offsets inside one [BK][Cout] slab
+    unsigned voff_a[A_F4];
+#pragma unroll
+    for (int e = 0; e < A_F4; ++e) {
+        const int qq = tid + e * kThreads;
+        const int row = qq / (BM / 4), c4 = (qq % (BM / 4)) * 4;
+        voff_a[e] = (m0 + c4 < p.Cout) ? (unsigned)(row * p.Cout + m0 + c4) * 4u : kOOB;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[A_F4];
+    unsigned rb[B_PER];
+    // load cursor: valid-tap index / chunk inside the tap, and this thread's byte offset for the tap
+    int ld_vi = -1, ld_c = cpt, ld_tap = 0;
+    unsigned voff_b = kOOB;
+    const unsigned chan_step = (unsigned)(B_STEP * HW) * 4u;     // bytes between this thread's k rows
+
+    auto load_next = [&]() {                   // issues the loads of the next chunk in sequence
+        if (ld_c == cpt) {
+            ld_c = 0;
+            ++ld_vi;
+            ld_tap = __builtin_amdgcn_readfirstlane(vtaps[ld_vi]);   // block-uniform: keep it scalar
+            int sp;
+            const bool ok = tap_src(ld_tap, sp);
+            voff_b = ok ? (img_off + (unsigned)sp) * 4u : kOOB;
+        }
+        const int k0 = ld_tap * p.Cin + ld_c * BK;
+        const unsigned soff_a = (unsigned)(k0 * p.Cout) * 4u;
+#pragma unroll
+        for (int e = 0; e < A_F4; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+        const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e)
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + e * chan_step, 0);
+        ++ld_c;
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < A_F4; ++e) {
+            const int qq = tid + e * kThreads;
+            *reinterpret_cast<u32x4*>(&As[buf][qq * 4]) = ra[e];
+        }
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) Bs[buf][(kr + e * B_STEP) * BN + pl] = __builtin_bit_cast(float, rb[e]);
+    };
+
+    if (nq > 0) {
+        load_next();
+        store_tiles(0);
+        if (nq > 1) load_next();
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int q = 0; q < nq; ++q) {
+        const int cur = q & 1;
+        if (q + 1 < nq) store_tiles(cur ^ 1);
+        if (q + 2 < nq) load_next();
+        const float* Ab = As[cur];
+        const float* Bb = Bs[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = Ab[(kk + lh) * BM + wm * (MI * 32) + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = Bb[(kk + lh) * BN + wn * (NI * 32) + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (same as the generic kernel)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
+        if (opix >= p.P) continue;
+        const int ob = opix / OHOW;
+        const int orp = opix - ob * OHOW;
+        float* yb = p.y + (long long)ob * p.y_bs + orp;
+        const float* rbp = p.res ? p.res + (long long)ob * p.res_bs + orp : nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Cout) continue;
                 float v = acc[i][j][r];
                 if (p.scale) v *= p.scale[co];
@@ -219,16 +457,22 @@ struct WgradP {
     int P;        // B*OH*OW
     int chunks_per_split;
     long long x_bs, dy_bs;
+    unsigned x_bytes, dy_bytes;   // extents for the buffer-descriptor fast path (0 = not eligible)
 };
 
-template <int BM>
+// Same pipeline as the forward kernel (LDS double buffer, one barrier per 32-pixel chunk).  When the
+// block's N tile lies inside one tap, pixel chunks for which that tap reads only padding are skipped
+// (decided per wave with a ballot: every wave sees the same 32 pixels, so the decision is block-uniform).
+template <int BM, int BN, int WM>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     constexpr int BK = 32, LD = BK + 1;
-    constexpr int WM = BM / 64, WN = 4 / WM, BN = WN * 64;
+    constexpr int WN = 4 / WM, MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int A_PER = BM / 8, B_PER = BN / 8;
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
 
-    __shared__ float As[BM * LD];
-    __shared__ float Bs[BN * LD];
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];   // As[2][BM*LD] | Bs[2][BN*LD]
+    float* const As0 = wg_lds;
+    float* const Bs0 = wg_lds + 2 * BM * LD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -254,12 +498,17 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
             b_coff[e] = -1;
         }
     }
+    // block-uniform tap of the tile (if it has one)
+    const int n_last = min(n0 + BN, p.N) - 1;
+    const int tap0 = n0 / p.Cin;
+    const bool single_tap = tap0 == n_last / p.Cin;
+    const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -267,6 +516,23 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
     const int chunk_begin = blockIdx.z * p.chunks_per_split;
     const int total_chunks = (p.P + BK - 1) / BK;
     const int chunk_end = min(chunk_begin + p.chunks_per_split, total_chunks);
+
+    // first chunk >= c (and < chunk_end) whose pixels are not all padding for this tile's tap
+    auto next_valid = [&](int c) {
+        if (!single_tap) return min(c, chunk_end);
+        for (; c < chunk_end; ++c) {
+            const int pix = c * BK + px;
+            bool ok = pix < p.P;
+            if (ok) {
+                const int pb = pix / OHOW, rp = pix - pb * OHOW;
+                const int oh = rp / p.OW, ow = rp - oh * p.OW;
+                const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
+                ok = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            }
+            if (__any(ok)) break;
+        }
+        return c;
+    };
 
     auto load_tiles = [&](int chunk) {
         const int pix = chunk * BK + px;
@@ -286,54 +552,211 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
         }
         const float* xb = p.x + (long long)pb * p.x_bs;
         const int bh = oh * p.stride, bw = ow * p.stride;
+        if (single_tap) {
+            // one validity test / spatial offset for the whole tile column (all rows share the tap)
+            const int ih = bh + t_dh, iw = bw + t_dw;
+            const bool v = ok && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const float* src = xb + ih * p.W + iw;
 #pragma unroll
-        for (int e = 0; e < B_PER; ++e) {
-            const int ih = bh + (b_shift[e] >> 16);
-            const int iw = bw + (int)(short)(b_shift[e] & 0xffff);
-            const bool v = ok && b_coff[e] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            rb[e] = v ? xb[(long long)b_coff[e] + ih * p.W + iw] : 0.f;
+            for (int e = 0; e < B_PER; ++e) rb[e] = (v && b_coff[e] >= 0) ? src[b_coff[e]] : 0.f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < B_PER; ++e) {
+                const int ih = bh + (b_shift[e] >> 16);
+                const int iw = bw + (int)(short)(b_shift[e] & 0xffff);
+                const bool v = ok && b_coff[e] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                rb[e] = v ? xb[(long long)b_coff[e] + ih * p.W + iw] : 0.f;
+            }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
+        float* A = As0 + buf * BM * LD;
+        float* Bq = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int e = 0; e < A_PER; ++e) As[(row0 + 8 * e) * LD + px] = ra[e];
+        for (int e = 0; e < A_PER; ++e) A[(row0 + 8 * e) * LD + px] = ra[e];
 #pragma unroll
-        for (int e = 0; e < B_PER; ++e) Bs[(row0 + 8 * e) * LD + px] = rb[e];
+        for (int e = 0; e < B_PER; ++e) Bq[(row0 + 8 * e) * LD + px] = rb[e];
     };
 
-    if (chunk_begin < chunk_end) load_tiles(chunk_begin);
+    int c0 = next_valid(chunk_begin), c1 = chunk_end;
+    if (c0 < chunk_end) {
+        load_tiles(c0);
+        store_tiles(0);
+        c1 = next_valid(c0 + 1);
+        if (c1 < chunk_end) load_tiles(c1);
+    }
+    __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int c = chunk_begin; c < chunk_end; ++c) {
-        __syncthreads();
-        store_tiles();
-        __syncthreads();
-        if (c + 1 < chunk_end) load_tiles(c + 1);
+    int cur = 0;
+    while (c0 < chunk_end) {
+        if (c1 < chunk_end) store_tiles(cur ^ 1);
+        const int c2 = c1 < chunk_end ? next_valid(c1 + 1) : chunk_end;
+        if (c2 < chunk_end) load_tiles(c2);
+        const float* A = As0 + cur * BM * LD;
+        const float* Bq = Bs0 + cur * BN * LD;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[2], b[2];
+            float a[MI], b[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 64 + i * 32 + l31) * LD + kk + lh];
+            for (int i = 0; i < MI; ++i) a[i] = A[(wm * (MI * 32) + i * 32 + l31) * LD + kk + lh];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(wn * 64 + j * 32 + l31) * LD + kk + lh];
+            for (int j = 0; j < NI; ++j) b[j] = Bq[(wn * (NI * 32) + j * 32 + l31) * LD + kk + lh];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
+        c0 = c1;
+        c1 = c2;
+        cur ^= 1;
     }
 
     float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.N;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (NI * 32) + j * 32 + l31;
         if (n >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co < p.Cout) slab[(long long)co * p.N + n] = acc[i][j][r];
+            }
+    }
+}
+
+// Fast weight-gradient path (Cout % BM == 0, Cin % BN == 0 so every tile sits inside one tap, tensors
+// < 2 GiB): buffer-descriptor loads, per-lane offsets recomputed once per 32-pixel chunk, row advance in
+// the scalar offset, padding via out-of-range offsets.  Same tiling, pipeline and chunk skipping as
+// conv_wgrad_kernel.
+template <int BM, int BN, int WM>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
+    constexpr int BK = 32, LD = BK + 1;
+    constexpr int WN = 4 / WM, MI = BM / WM / 32, NI = BN / WN / 32;
+    constexpr int A_PER = BM / 8, B_PER = BN / 8;
+    constexpr unsigned kOOB = 0x80000000u;
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];   // As[2][BM*LD] | Bs[2][BN*LD]
+    float* const As0 = wg_lds;
+    float* const Bs0 = wg_lds + 2 * BM * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int OHOW = p.OH * p.OW, HW = p.H * p.W;
+    const int px = tid & 31, row0 = tid >> 5;
+
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
+    const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
+    const unsigned a_row = (unsigned)((m0 + row0) * OHOW);       // elements
+    const unsigned b_row = (unsigned)((ci0 + row0) * HW);
+    const unsigned a_step = (unsigned)(8 * OHOW) * 4u, b_step = (unsigned)(8 * HW) * 4u;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    unsigned ra[A_PER], rb[B_PER];
+    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    const int total_chunks = (p.P + BK - 1) / BK;
+    const int chunk_end = min(chunk_begin + p.chunks_per_split, total_chunks);
+
+    // decode this thread's pixel of chunk c: byte offsets into dy / x (kOOB when padding / past the end)
+    auto decode = [&](int c, unsigned& va, unsigned& vb) {
+        const int pix = c * BK + px;
+        va = kOOB;
+        vb = kOOB;
+        if (pix < p.P) {
+            const int pb = pix / OHOW, rp = pix - pb * OHOW;
+            const int oh = rp / p.OW, ow = rp - oh * p.OW;
+            va = ((unsigned)((long long)pb * p.dy_bs) + (unsigned)rp + a_row) * 4u;
+            const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                vb = ((unsigned)((long long)pb * p.x_bs) + (unsigned)(ih * p.W + iw) + b_row) * 4u;
+        }
+    };
+    unsigned nva = kOOB, nvb = kOOB;            // offsets of the chunk found by next_valid
+    auto next_valid = [&](int c) {
+        for (; c < chunk_end; ++c) {
+            decode(c, nva, nvb);
+            if (__any(nvb != kOOB)) break;
+        }
+        return c;
+    };
+    auto load_tiles = [&]() {                    // loads the chunk last returned by next_valid
+#pragma unroll
+        for (int e = 0; e < A_PER; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b32(rdy, nva, e * a_step, 0);
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, e * b_step, 0);
+    };
+    auto store_tiles = [&](int buf) {
+        float* A = As0 + buf * BM * LD;
+        float* Bq = Bs0 + buf * BN * LD;
+#pragma unroll
+        for (int e = 0; e < A_PER; ++e) A[(row0 + 8 * e) * LD + px] = __builtin_bit_cast(float, ra[e]);
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e) Bq[(row0 + 8 * e) * LD + px] = __builtin_bit_cast(float, rb[e]);
+    };
+
+    int c0 = next_valid(chunk_begin), c1 = chunk_end;
+    if (c0 < chunk_end) {
+        load_tiles();
+        store_tiles(0);
+        c1 = next_valid(c0 + 1);
+        if (c1 < chunk_end) load_tiles();
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    int cur = 0;
+    while (c0 < chunk_end) {
+        if (c1 < chunk_end) store_tiles(cur ^ 1);
+        const int c2 = c1 < chunk_end ? next_valid(c1 + 1) : chunk_end;
+        if (c2 < chunk_end) load_tiles();
+        const float* A = As0 + cur * BM * LD;
+        const float* Bq = Bs0 + cur * BN * LD;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = A[(wm * (MI * 32) + i * 32 + l31) * LD + kk + lh];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = Bq[(wn * (NI * 32) + j * 32 + l31) * LD + kk + lh];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        c0 = c1;
+        c1 = c2;
+        cur ^= 1;
+    }
+
+    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.N;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * (NI * 32) + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)co * p.N + n] = acc[i][j][r];
             }
     }
 }
@@ -402,23 +825,34 @@ int check_geom(int B, int Cin, int H, int W, int Cout, int kh, int kw, int strid
     return WSDL_OK;
 }
 
+template <int BM, int BN, int WM>
+void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
+    dim3 grid(wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
+    if (aligned)
+        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM>), grid, dim3(kThreads), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, false>), grid, dim3(kThreads), 0, s, p);
+}
+
+// Tile choice: 128x128 (64x64 per wave) when that already gives every CU ~2 blocks; otherwise halve the
+// pixel tile (128x64) so small-map layers (Cout 256 at 32x32: 256 -> 512 blocks) keep two waves per SIMD and
+// the tap-skipping imbalance averages out.  Cout <= 64: 64x256 / 64x128.
 int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
-    const bool aligned = (p.Cin % 16) == 0;
-    const int cls = p.Cout <= 64 ? (aligned ? WSDL_PROF_IGEMM_64A : WSDL_PROF_IGEMM_64U)
-                                 : (aligned ? WSDL_PROF_IGEMM_128A : WSDL_PROF_IGEMM_128U);
-    wsdl::ProfScope prof(cls, s, flops);
-    if (p.Cout <= 64) {
-        dim3 grid(wsdl::cdiv(p.P, 256), wsdl::cdiv(p.Cout, 64));
-        if (aligned)
-            hipLaunchKernelGGL((conv_igemm_kernel<64, true>), grid, dim3(kThreads), 0, s, p);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<64, false>), grid, dim3(kThreads), 0, s, p);
-    } else {
-        dim3 grid(wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 128));
-        if (aligned)
-            hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, dim3(kThreads), 0, s, p);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, dim3(kThreads), 0, s, p);
+    // fast path: K chunks inside one tap, 16-byte weight rows, 31-bit byte offsets
+    const bool aligned = (p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
+                         (long long)p.K * p.Cout * 4 < (1ll << 31);
+    constexpr long long kWant = 400;   // blocks below which the smaller tile is used (256 CUs x 2.5)
+    int cfg;                           // 0: 128x128, 1: 128x64, 2: 64x256, 3: 64x128
+    if (p.Cout <= 64)
+        cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
+    else
+        cfg = (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant ? 0 : 1;
+    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops);
+    switch (cfg) {
+        case 0: launch_cfg<128, 128, 2>(p, s, aligned); break;
+        case 1: launch_cfg<128, 64, 2>(p, s, aligned); break;
+        case 2: launch_cfg<64, 256, 1>(p, s, aligned); break;
+        default: launch_cfg<64, 128, 1>(p, s, aligned); break;
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -426,7 +860,7 @@ int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
 
 // split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
 int wgrad_splits(int Cout, int N, int P) {
-    const int BM = Cout <= 64 ? 64 : 128, BN = Cout <= 64 ? 256 : 128;
+    const int BM = Cout <= 64 ? 64 : 128, BN = 128;
     const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
     long long s = (768 + tiles - 1) / tiles;
@@ -469,6 +903,10 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Ci
     p.res_bs = res_bs ? res_bs : (long long)Cout * OH * OW;
     WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
     p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
+    {
+        const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4;
+        p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;     // 0 -> generic kernel
+    }
     return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
 }
 
@@ -489,6 +927,10 @@ int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, 
     p.res_bs = p.y_bs;
     WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
     p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
+    {
+        const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cout * OH * OW) * 4;
+        p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
+    }
     return launch_igemm(p, wsdl::as_stream(stream), 2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin);
 }
 
@@ -523,14 +965,37 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     const int chunks = wsdl::cdiv(p.P, 32);
     p.chunks_per_split = wsdl::cdiv(chunks, S);
     hipStream_t s = wsdl::as_stream(stream);
+    const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4;
+    const long long dyb = ((long long)(B - 1) * p.dy_bs + (long long)Cout * OH * OW) * 4;
+    const bool fast = Cout % 128 == 0 && Cin % 128 == 0 && xb < (1ll << 31) && dyb < (1ll << 31);
     {
-        wsdl::ProfScope prof(Cout <= 64 ? WSDL_PROF_WGRAD_64 : WSDL_PROF_WGRAD_128, s, 2.0 * p.P * (double)Cout * p.N);
-        if (Cout <= 64) {
-            dim3 grid(wsdl::cdiv(p.N, 256), wsdl::cdiv(Cout, 64), S);
-            hipLaunchKernelGGL((conv_wgrad_kernel<64>), grid, dim3(kThreads), 0, s, p);
+        wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
+                             s, 2.0 * p.P * (double)Cout * p.N);
+        constexpr size_t lds64 = 2 * (64 + 128) * 33 * sizeof(float), lds128 = 2 * (128 + 128) * 33 * sizeof(float);
+        static std::once_flag once;
+        static hipError_t attr_rc = hipSuccess;
+        std::call_once(once, [] {
+            attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<64, 128, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64);
+            if (attr_rc == hipSuccess)
+                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 128, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+            if (attr_rc == hipSuccess)
+                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fast_kernel<128, 128, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+        });
+        WSDL_HIP_CHECK(attr_rc);
+        if (fast) {
+            p.x_bytes = (unsigned)xb;
+            p.dy_bytes = (unsigned)dyb;
+            dim3 grid(p.N / 128, Cout / 128, S);
+            hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2>), grid, dim3(kThreads), lds128, s, p);
+        } else if (Cout <= 64) {
+            dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
+            hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1>), grid, dim3(kThreads), lds64, s, p);
         } else {
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 128), S);
-            hipLaunchKernelGGL((conv_wgrad_kernel<128>), grid, dim3(kThreads), 0, s, p);
+            hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2>), grid, dim3(kThreads), lds128, s, p);
         }
     }
     WSDL_LAUNCH_CHECK();

@@ -616,7 +616,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 8
+PROF_NCLASSES = 13
 
 
 def prof_class_name(cls):
