@@ -55,7 +55,8 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (fo
        WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12, WSDL_PROF_NCLASSES = 13 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
-int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work);
+int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,
+                      double* total_work_executed /* work minus the skipped all-padding K-chunks */);
 int wsdl_prof_reset(void);
 
 /* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------

@@ -17,7 +17,7 @@ SIGNATURES = {
     "wsdl_version": (_i, []),
     "wsdl_target_arch": (C.c_char_p, []),
     "wsdl_prof_enable": (_i, [_i]),
-    "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wsdl_prof_reset": (_i, []),
     "wsdl_prof_class_name": (C.c_char_p, [_i]),
     "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -43,11 +43,12 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Profiling scope: records a start/stop event pair on the stream when wsdl_prof_enable(1) is set.
+bool prof_enabled();
 struct ProfScope {
     int cls;
     hipStream_t s;
     void* slot;
-    ProfScope(int cls, hipStream_t s, double work);
+    ProfScope(int cls, hipStream_t s, double work, double work_executed = -1.0);
     ~ProfScope();
 };
 

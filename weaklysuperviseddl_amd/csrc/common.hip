@@ -17,18 +17,21 @@ void set_error(const char* fmt, ...) {
 
 struct ProfRec {
     hipEvent_t start, stop;
-    double work;
+    double work, executed;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof[WSDL_PROF_NCLASSES];
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
 
-ProfScope::ProfScope(int c, hipStream_t st, double work) : cls(c), s(st), slot(nullptr) {
+bool prof_enabled() { return g_prof_on; }
+
+ProfScope::ProfScope(int c, hipStream_t st, double work, double work_executed) : cls(c), s(st), slot(nullptr) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.work = work;
+    r.executed = work_executed >= 0.0 ? work_executed : work;
     if (!g_free_events.empty()) {
         r.start = g_free_events.back().first;
         r.stop = g_free_events.back().second;
@@ -83,20 +86,23 @@ int wsdl_prof_reset(void) {
     return WSDL_OK;
 }
 
-int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work) {
+int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,
+                      double* total_work_executed) {
     WSDL_REQUIRE(cls >= 0 && cls < WSDL_PROF_NCLASSES, "prof class %d out of range", cls);
     std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
-    double ms = 0.0, work = 0.0;
+    double ms = 0.0, work = 0.0, exe = 0.0;
     for (auto& r : wsdl::g_prof[cls]) {
         WSDL_HIP_CHECK(hipEventSynchronize(r.stop));
         float t = 0.f;
         WSDL_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
         ms += t;
         work += r.work;
+        exe += r.executed;
     }
     if (launches) *launches = (long long)wsdl::g_prof[cls].size();
     if (total_ms) *total_ms = ms;
     if (total_work) *total_work = work;
+    if (total_work_executed) *total_work_executed = exe;
     return WSDL_OK;
 }
 

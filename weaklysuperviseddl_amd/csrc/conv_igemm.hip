@@ -825,6 +825,46 @@ int check_geom(int B, int Cin, int H, int W, int Cout, int kh, int kw, int strid
     return WSDL_OK;
 }
 
+// Fraction of the nominal K-chunks a launch really executes (profiling only): mirrors the kernels' skip
+// rule - a tap is skipped for a pixel tile when every pixel of the tile reads padding under that tap.
+double igemm_executed_fraction(const ConvP& p, int BN) {
+    const int T = p.KH * p.KW, OHOW = p.OH * p.OW;
+    long long done = 0, all = 0;
+    for (int n0 = 0; n0 < p.P; n0 += BN) {
+        for (int t = 0; t < T; ++t) {
+            const int ti = t / p.KW, tj = t % p.KW;
+            bool any = false;
+            for (int pix = n0; pix < n0 + BN && pix < p.P && !any; ++pix) {
+                const int r = pix % OHOW, oh = r / p.OW, ow = r % p.OW;
+                const int nh = oh * p.ah + ti * p.bh + p.ch, nw = ow * p.ah + tj * p.bh + p.ch;
+                if (nh < 0 || nw < 0 || nh % p.sh || nw % p.sh) continue;
+                any = nh / p.sh < p.H && nw / p.sh < p.W;
+            }
+            done += any;
+            ++all;
+        }
+    }
+    return all ? (double)done / (double)all : 1.0;
+}
+
+double wgrad_executed_fraction(int P, int OH, int OW, int H, int W, int KH, int KW, int stride, int pad, int dil) {
+    const int T = KH * KW, OHOW = OH * OW;
+    long long done = 0, all = 0;
+    for (int c0 = 0; c0 < P; c0 += 32) {
+        for (int t = 0; t < T; ++t) {
+            const int dh = (t / KW) * dil - pad, dw = (t % KW) * dil - pad;
+            bool any = false;
+            for (int pix = c0; pix < c0 + 32 && pix < P && !any; ++pix) {
+                const int r = pix % OHOW, ih = (r / OW) * stride + dh, iw = (r % OW) * stride + dw;
+                any = ih >= 0 && ih < H && iw >= 0 && iw < W;
+            }
+            done += any;
+            ++all;
+        }
+    }
+    return all ? (double)done / (double)all : 1.0;
+}
+
 template <int BM, int BN, int WM>
 void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
     dim3 grid(wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
@@ -847,7 +887,9 @@ int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
         cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
     else
         cfg = (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant ? 0 : 1;
-    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops);
+    double executed = flops;
+    if (aligned && wsdl::prof_enabled()) executed = flops * igemm_executed_fraction(p, cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128);
+    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops, executed);
     switch (cfg) {
         case 0: launch_cfg<128, 128, 2>(p, s, aligned); break;
         case 1: launch_cfg<128, 64, 2>(p, s, aligned); break;
@@ -969,8 +1011,12 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     const long long dyb = ((long long)(B - 1) * p.dy_bs + (long long)Cout * OH * OW) * 4;
     const bool fast = Cout % 128 == 0 && Cin % 128 == 0 && xb < (1ll << 31) && dyb < (1ll << 31);
     {
+        const double flops = 2.0 * p.P * (double)Cout * p.N;
+        double executed = flops;
+        if (wsdl::prof_enabled() && Cin % 128 == 0)     // tiles inside one tap: all-padding pixel chunks are skipped
+            executed = flops * wgrad_executed_fraction(p.P, OH, OW, H, W, kh, kw, stride, pad, dil);
         wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
-                             s, 2.0 * p.P * (double)Cout * p.N);
+                             s, flops, executed);
         constexpr size_t lds64 = 2 * (64 + 128) * 33 * sizeof(float), lds128 = 2 * (128 + 128) * 33 * sizeof(float);
         static std::once_flag once;
         static hipError_t attr_rc = hipSuccess;

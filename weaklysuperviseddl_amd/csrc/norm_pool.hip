@@ -27,6 +27,30 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
         is = invstd[c];
     }
     const int total = len > 0 ? B * len : 0;
+    const bool vec = ((len | r0 | HW) & 3) == 0 && ((dy_bs | y_bs) & 3) == 0;
+    if (vec) {
+        const int len4 = len >> 2, total4 = B * len4;
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) {
+            const int b = i / len4, r = r0 + ((i - b * len4) << 2);
+            const float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
+            if (!backward) {
+                a0 += (double)((xv.x + xv.y) + (xv.z + xv.w));
+                a1 += (double)xv.x * xv.x + (double)xv.y * xv.y + (double)xv.z * xv.z + (double)xv.w * xv.w;
+            } else {
+                float4 g = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
+                if (relu) {
+                    const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
+                    if (!(yv.x > 0.f)) g.x = 0.f;
+                    if (!(yv.y > 0.f)) g.y = 0.f;
+                    if (!(yv.z > 0.f)) g.z = 0.f;
+                    if (!(yv.w > 0.f)) g.w = 0.f;
+                }
+                a0 += (double)((g.x + g.y) + (g.z + g.w));
+                a1 += (double)g.x * ((xv.x - mu) * is) + (double)g.y * ((xv.y - mu) * is) +
+                      (double)g.z * ((xv.z - mu) * is) + (double)g.w * ((xv.w - mu) * is);
+            }
+        }
+    } else
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
         const int b = i / len, r = r0 + (i - b * len);
         const float xv = x[((long long)b * C + c) * HW + r];
@@ -137,6 +161,26 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     const float* yp = relu ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
     float* dxp = dx + (long long)plane * HW;
     float* drp = dres ? dres + (long long)plane * HW : nullptr;
+    if ((HW & 3) == 0 && ((dy_bs | y_bs) & 3) == 0) {
+        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
+            float4 g = *reinterpret_cast<const float4*>(gp + i);
+            if (yp) {
+                const float4 yv = *reinterpret_cast<const float4*>(yp + i);
+                if (!(yv.x > 0.f)) g.x = 0.f;
+                if (!(yv.y > 0.f)) g.y = 0.f;
+                if (!(yv.z > 0.f)) g.z = 0.f;
+                if (!(yv.w > 0.f)) g.w = 0.f;
+            }
+            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+            float4 o;
+            o.x = gi * (g.x - k0 - (xv.x - mu) * is * k1);
+            o.y = gi * (g.y - k0 - (xv.y - mu) * is * k1);
+            o.z = gi * (g.z - k0 - (xv.z - mu) * is * k1);
+            o.w = gi * (g.w - k0 - (xv.w - mu) * is * k1);
+            *reinterpret_cast<float4*>(dxp + i) = o;
+            if (drp) *reinterpret_cast<float4*>(drp + i) = g;
+        }
+    } else
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
         float g = gp[i];
         if (yp && !(yp[i] > 0.f)) g = 0.f;
@@ -363,7 +407,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                        part, B, C, HW, dy_bs, y_bs, relu, 1);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, gamma,
                        save_invstd, dgamma, dbeta, coef, (long long)B * HW, C, accumulate_param_grads);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW), dim3(256), 0, s, x, dy, y, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, coef, dx, dres, C, HW, dy_bs, y_bs, relu, B * C);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;

@@ -63,8 +63,11 @@ class GradBucketReducer:
         self._pending = []
         self._launched = [False] * len(self.bucket_size)
         if self.world > 1:
+            self._index = {id(p): i for i, p in enumerate(optimizer.params)}
             for i, p in enumerate(optimizer.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))
+                p.register_post_accumulate_grad_hook(self._make_hook(i))     # gradients arriving through autograd
+            # gradients written directly by the HIP backward kernels (no AccumulateGrad node runs for them)
+            optimizer.grad_ready_hooks.append(lambda p: self._hooks[self._index[id(p)]](p))
 
     def _make_hook(self, i):
         b = self.bucket_of[i]
@@ -73,6 +76,9 @@ class GradBucketReducer:
             self._remaining[b] -= 1
             if self._remaining[b] == 0:
                 self._launch(b)
+        if not hasattr(self, "_hooks"):
+            self._hooks = {}
+        self._hooks[i] = hook
         return hook
 
     def _launch(self, b):

@@ -165,7 +165,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     return out, mean, invstd
 
 
-def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None):
+def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None, accumulate=False):
     x = _dense(x, "x")
     dy, dy_bs = _planes(dy, "dy")
     B, Cc, H, W = x.shape
@@ -173,9 +173,9 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     if relu:
         y, y_bs = _planes(y, "y")
     dx = torch.empty_like(x)
-    acc = dgamma_out is not None
-    dgamma = dgamma_out if acc else torch.empty(Cc, device=x.device, dtype=torch.float32)
-    dbeta = dbeta_out if acc else torch.empty(Cc, device=x.device, dtype=torch.float32)
+    acc = bool(accumulate) and dgamma_out is not None and dbeta_out is not None
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if relu else None), _p(gamma), _p(mean), _p(invstd), _p(dx),
@@ -195,6 +195,15 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
 
 
 # ------------------------------------------------------------------------------------------ autograd
+def _sink_of(param):
+    """Parameters owned by a FlatAdam carry ``_wsdl_grad_sink``: their gradient is written by the kernels
+    straight into the optimiser's flat gradient buffer (no autograd accumulation pass, no extra add)."""
+    sink = getattr(param, "_wsdl_grad_sink", None)
+    if sink is None or param.grad is None or not param.grad.is_cuda:
+        return None
+    return sink
+
+
 class _ConvBNAct(torch.autograd.Function):
     """Train-mode conv -> BatchNorm(batch statistics) -> (+residual) -> ReLU as one autograd node."""
 
@@ -206,6 +215,7 @@ class _ConvBNAct(torch.autograd.Function):
         y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
                                        residual, relu)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
+        ctx.params = (weight, gamma, beta)
         ctx.save_for_backward(x, conv, y if relu else None, gamma, mean, invstd, wd)
         return y
 
@@ -213,9 +223,26 @@ class _ConvBNAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, conv, y, gamma, mean, invstd, wd = ctx.saved_tensors
         stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
+        pw, pg, pb = ctx.params
         need_res = has_res and ctx.needs_input_grad[4]
-        dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res)
-        dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil) if ctx.needs_input_grad[1] else None
+        sg = _sink_of(pg) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and _sink_of(pg) is _sink_of(pb)) else None
+        if sg is not None:
+            fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
+            dconv, _, _, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res,
+                                             pg.grad, pb.grad, accumulate=not fresh)
+            dgamma = dbeta = None
+            sg.grad_ready(pg)
+            sg.grad_ready(pb)
+        else:
+            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sw = _sink_of(pw)
+            if sw is not None:
+                conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=pw.grad, accumulate=not sw.take_fresh(pw))
+                sw.grad_ready(pw)
+            else:
+                dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil)
         dx = None
         if ctx.needs_input_grad[0]:
             if wd is None:
@@ -234,6 +261,7 @@ class _ConvAffineAct(torch.autograd.Function):
         wf, wd = prep_weights(weight, True, need_dx)
         y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None, shift_is_param)
+        ctx.params = (weight, shift if shift_is_param else None)
         need_w = weight.requires_grad
         ctx.save_for_backward(x if need_w else None, y if relu else None, scale, wd)
         return y
@@ -250,11 +278,24 @@ class _ConvAffineAct(torch.autograd.Function):
                 dres = dyc
         else:
             dconv, dres = dyc, None
-        dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil) if ctx.needs_input_grad[1] else None
+        pw, pbias = ctx.params
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sw = _sink_of(pw)
+            if sw is not None and tuple(pw.grad.shape) == tuple(wshape):
+                conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=pw.grad, accumulate=not sw.take_fresh(pw))
+                sw.grad_ready(pw)
+            else:
+                dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil)
         dshift = None
         if ctx.needs_input_grad[3] and shift_is_param:
             # with scale None the shift is a plain bias: d/dshift = sum of the masked upstream gradient
-            dshift = bias_grad(dconv)
+            sb = _sink_of(pbias)
+            if sb is not None:
+                bias_grad(dconv, out=pbias.grad, accumulate=not sb.take_fresh(pbias))
+                sb.grad_ready(pbias)
+            else:
+                dshift = bias_grad(dconv)
         dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil) if ctx.needs_input_grad[0] else None
         return dx, dw, None, dshift, dres, None, None, None, None, None
 
@@ -624,6 +665,6 @@ def prof_class_name(cls):
 
 
 def prof_collect(cls):
-    n, ms, work = C.c_longlong(0), C.c_double(0), C.c_double(0)
-    check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work)))
-    return n.value, ms.value, work.value
+    n, ms, work, exe = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work), C.byref(exe)))
+    return n.value, ms.value, work.value, exe.value

@@ -36,9 +36,26 @@ class FlatAdam:
                 p.data = view
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
         self.pre_step_hook = None      # e.g. wait for the gradient all-reduce
+        # direct gradient delivery: the HIP backward kernels write each parameter's gradient straight into
+        # its flat_grad slice (ops._sink_of); `_fresh` = not yet written since zero_grad (first write overwrites)
+        self._fresh = {id(p): True for p in self.params}
+        self.grad_ready_hooks = []     # callables(param): fired when a parameter's gradient has been written
+        for p in self.params:
+            p._wsdl_grad_sink = self
+
+    def take_fresh(self, p):
+        f = self._fresh.get(id(p), False)
+        self._fresh[id(p)] = False
+        return f
+
+    def grad_ready(self, p):
+        for h in self.grad_ready_hooks:
+            h(p)
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
+        for k in self._fresh:
+            self._fresh[k] = True
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
