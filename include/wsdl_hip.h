@@ -39,6 +39,10 @@ const char* wsdl_last_error(void);
 int wsdl_version(void);               /* 10000*major + 100*minor + patch */
 const char* wsdl_target_arch(void);   /* "gfx950" */
 
+/* tuning knobs (A/B experiments): "occupancy_cap" 0/1 - pad the LDS request of the conv kernels so that a
+ * CU holds at most ceil(blocks/256) workgroups (even placement).  Default 1. */
+int wsdl_set_option(const char* name, int value);
+
 /* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
  * When enabled every launch of the instrumented classes is bracketed by hipEventRecord on the
  * launch stream.  wsdl_prof_collect synchronises the events and returns, per class, the number of

@@ -16,6 +16,7 @@ SIGNATURES = {
     "wsdl_last_error": (C.c_char_p, []),
     "wsdl_version": (_i, []),
     "wsdl_target_arch": (C.c_char_p, []),
+    "wsdl_set_option": (_i, [C.c_char_p, _i]),
     "wsdl_prof_enable": (_i, [_i]),
     "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wsdl_prof_reset": (_i, []),

@@ -268,9 +268,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
 // branches and no 64-bit address arithmetic inside the K loop.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int WM>
+template <int BM, int BN, int WM, int BK>
 __global__ __launch_bounds__(kThreads) void conv_igemm_fast_kernel(ConvP p) {
-    constexpr int BK = 16;
     constexpr int WN = 4 / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
@@ -865,12 +864,47 @@ double wgrad_executed_fraction(int P, int OH, int OW, int H, int W, int KH, int 
     return all ? (double)done / (double)all : 1.0;
 }
 
+// Workgroup placement: the dispatcher may stack up to `natural occupancy` blocks on one CU while other CUs
+// sit idle, so a 512-block grid (2 per CU on average) can finish at the pace of a CU holding 3-5 blocks.
+// Padding the LDS request caps the blocks a CU can hold at ceil(blocks / 256): placement becomes even.
+int g_occ_cap = 0;     // measured: no gain - the dispatcher already places blocks evenly (profiles/r01_notes.md)
+int g_tile_threshold = 400;   // blocks below which the half-size pixel tile is used
+constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
+
+size_t occupancy_pad(long long blocks, size_t static_lds) {
+    if (!g_occ_cap) return 0;
+    const long long per_cu = (blocks + kNumCU - 1) / kNumCU;
+    if (per_cu >= 5) return 0;
+    // largest request such that exactly per_cu blocks fit: floor(LDS / per_cu), but more than LDS / (per_cu + 1)
+    size_t want = (size_t)kLdsPerCU / (size_t)per_cu - 4096;   // leave slack: exactly LDS/per_cu did not co-reside
+    want -= want % 1024;
+    return want > static_lds ? want - static_lds : 0;
+}
+
+int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
+
+template <int BM, int BN, int WM, int BK>
+void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
+    constexpr size_t static_lds = 2 * BK * (BM + BN) * sizeof(float) + 64 * sizeof(int);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_fast_kernel<BM, BN, WM, BK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCU - (int)static_lds - 2048);
+    });
+    size_t pad = occupancy_pad((long long)grid.x * grid.y, static_lds);
+    if (pad > (size_t)kLdsPerCU - static_lds - 2048) pad = (size_t)kLdsPerCU - static_lds - 2048;
+    hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), pad, s, p);
+}
+
 template <int BM, int BN, int WM>
 void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
     dim3 grid(wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
-    if (aligned)
-        hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM>), grid, dim3(kThreads), 0, s, p);
-    else
+    if (aligned) {
+        if (BM * BN <= 128 * 64 && g_bk32 && p.Cin % 32 == 0)
+            launch_fast<BM, BN, WM, 32>(p, s, grid);
+        else
+            launch_fast<BM, BN, WM, 16>(p, s, grid);
+    } else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, false>), grid, dim3(kThreads), 0, s, p);
 }
 
@@ -881,7 +915,7 @@ int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
     // fast path: K chunks inside one tap, 16-byte weight rows, 31-bit byte offsets
     const bool aligned = (p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
                          (long long)p.K * p.Cout * 4 < (1ll << 31);
-    constexpr long long kWant = 400;   // blocks below which the smaller tile is used (256 CUs x 2.5)
+    const long long kWant = g_tile_threshold;   // blocks below which the smaller tile is used (256 CUs x 2.5)
     int cfg;                           // 0: 128x128, 1: 128x64, 2: 64x256, 3: 64x128
     if (p.Cout <= 64)
         cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
@@ -915,6 +949,15 @@ int wgrad_splits(int Cout, int N, int P) {
 }  // namespace
 
 extern "C" {
+
+int wsdl_set_option(const char* name, int value) {
+    WSDL_REQUIRE(name, "set_option: null name");
+    if (!strcmp(name, "occupancy_cap")) { g_occ_cap = value; return WSDL_OK; }
+    if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
+    if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
+    wsdl::set_error("set_option: unknown option %s", name);
+    return WSDL_EINVAL;
+}
 
 int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad, int Cout, int Cin,
                              int kh, int kw, wsdl_stream_t stream) {
