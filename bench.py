@@ -145,8 +145,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    dev_index = local % torch.cuda.device_count()     # == local on a full node; rehearsal boxes have fewer GPUs
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
 
     torch.manual_seed(0)                       # identical weights on every rank
     model = build_segmentation_model().to(device).train()
