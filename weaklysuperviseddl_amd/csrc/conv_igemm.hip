@@ -631,11 +631,12 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
 // < 2 GiB): buffer-descriptor loads, per-lane offsets recomputed once per 32-pixel chunk, row advance in
 // the scalar offset, padding via out-of-range offsets.  Same tiling, pipeline and chunk skipping as
 // conv_wgrad_kernel.
-template <int BM, int BN, int WM>
+template <int BM, int BN, int WM, int BK>
 __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
-    constexpr int BK = 32, LD = BK + 1;
+    constexpr int LD = BK + 1;
     constexpr int WN = 4 / WM, MI = BM / WM / 32, NI = BN / WN / 32;
-    constexpr int A_PER = BM / 8, B_PER = BN / 8;
+    constexpr int RPP = kThreads / BK;                    // rows covered per pass
+    constexpr int A_PER = BM / RPP, B_PER = BN / RPP;
     constexpr unsigned kOOB = 0x80000000u;
     static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
 
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
     const int wm = wid / WN, wn = wid % WN;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int OHOW = p.OH * p.OW, HW = p.H * p.W;
-    const int px = tid & 31, row0 = tid >> 5;
+    const int px = tid % BK, row0 = tid / BK;
 
     const __amdgpu_buffer_rsrc_t rdy =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
     const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
     const unsigned a_row = (unsigned)((m0 + row0) * OHOW);       // elements
     const unsigned b_row = (unsigned)((ci0 + row0) * HW);
-    const unsigned a_step = (unsigned)(8 * OHOW) * 4u, b_step = (unsigned)(8 * HW) * 4u;
+    const unsigned a_step = (unsigned)(RPP * OHOW) * 4u, b_step = (unsigned)(RPP * HW) * 4u;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -670,9 +671,10 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     unsigned ra[A_PER], rb[B_PER];
-    const int chunk_begin = blockIdx.z * p.chunks_per_split;
+    // p.chunks_per_split counts 32-pixel chunks; this kernel walks BK-pixel chunks
+    const int chunk_begin = blockIdx.z * p.chunks_per_split * (32 / BK);
     const int total_chunks = (p.P + BK - 1) / BK;
-    const int chunk_end = min(chunk_begin + p.chunks_per_split, total_chunks);
+    const int chunk_end = min(chunk_begin + p.chunks_per_split * (32 / BK), total_chunks);
 
     // decode this thread's pixel of chunk c: byte offsets into dy / x (kOOB when padding / past the end)
     auto decode = [&](int c, unsigned& va, unsigned& vb) {
@@ -692,6 +694,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
     auto next_valid = [&](int c) {
         for (; c < chunk_end; ++c) {
             decode(c, nva, nvb);
+            // every wave holds all BK pixels of the chunk (64 / BK copies), so the ballot is block-uniform
             if (__any(nvb != kOOB)) break;
         }
         return c;
@@ -706,9 +709,9 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
         float* A = As0 + buf * BM * LD;
         float* Bq = Bs0 + buf * BN * LD;
 #pragma unroll
-        for (int e = 0; e < A_PER; ++e) A[(row0 + 8 * e) * LD + px] = __builtin_bit_cast(float, ra[e]);
+        for (int e = 0; e < A_PER; ++e) A[(row0 + RPP * e) * LD + px] = __builtin_bit_cast(float, ra[e]);
 #pragma unroll
-        for (int e = 0; e < B_PER; ++e) Bq[(row0 + 8 * e) * LD + px] = __builtin_bit_cast(float, rb[e]);
+        for (int e = 0; e < B_PER; ++e) Bq[(row0 + RPP * e) * LD + px] = __builtin_bit_cast(float, rb[e]);
     };
 
     int c0 = next_valid(chunk_begin), c1 = chunk_end;
@@ -881,6 +884,7 @@ size_t occupancy_pad(long long blocks, size_t static_lds) {
     return want > static_lds ? want - static_lds : 0;
 }
 
+int g_wgrad_bk = 0;    // pixel chunk of the fast weight-gradient kernel: 16, 32, or 0 = choose by split count
 int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
 
 template <int BM, int BN, int WM, int BK>
@@ -955,6 +959,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "occupancy_cap")) { g_occ_cap = value; return WSDL_OK; }
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = (value == 16 || value == 32) ? value : 0; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
     return WSDL_EINVAL;
 }
@@ -1070,7 +1075,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<128, 128, 2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
             if (attr_rc == hipSuccess)
-                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fast_kernel<128, 128, 2>),
+                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_fast_kernel<128, 128, 2, 32>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         });
         WSDL_HIP_CHECK(attr_rc);
@@ -1078,7 +1083,12 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             p.x_bytes = (unsigned)xb;
             p.dy_bytes = (unsigned)dyb;
             dim3 grid(p.N / 128, Cout / 128, S);
-            hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2>), grid, dim3(kThreads), lds128, s, p);
+            // short per-block pixel ranges (many splits) pipeline better with 16-pixel chunks; long ones with 32
+            if (g_wgrad_bk == 16 || (g_wgrad_bk == 0 && S >= 8))
+                hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 16>), grid, dim3(kThreads),
+                                   2 * (128 + 128) * 17 * sizeof(float), s, p);
+            else
+                hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 32>), grid, dim3(kThreads), lds128, s, p);
         } else if (Cout <= 64) {
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1>), grid, dim3(kThreads), lds64, s, p);
