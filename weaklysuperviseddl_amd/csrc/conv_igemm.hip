@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BM, int BN, int WM, int BK>
-__global__ __launch_bounds__(kThreads) void conv_igemm_fast_kernel(ConvP p) {
+__global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
     constexpr int WN = 4 / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_kernel(WgradP p) {
 // the scalar offset, padding via out-of-range offsets.  Same tiling, pipeline and chunk skipping as
 // conv_wgrad_kernel.
 template <int BM, int BN, int WM, int BK>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_fast_kernel(WgradP p) {
+__global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) {
     constexpr int LD = BK + 1;
     constexpr int WN = 4 / WM, MI = BM / WM / 32, NI = BN / WN / 32;
     constexpr int RPP = kThreads / BK;                    // rows covered per pass
@@ -779,7 +779,31 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
-// w[co][ci][tap] -> fwd[(tap*Cin+ci)][co], dgrad[(tap*Cout+co)][ci]
+// Same sum for 2 <= T <= 16 with both sides coalesced: a block owns (co, 32 input channels); each tap's 32
+// slab values are read as one 128-byte run, the (ci,tap) transpose happens in LDS, and the 32*T results leave
+// as one contiguous run of dw.  blockDim = (32, 8); blockIdx = (Cin/32 tiles, Cout).
+__global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                          int Cout, int Cin, int T, int accumulate) {
+    __shared__ float tile[32 * 16];
+    const int ci0 = blockIdx.x * 32, co = blockIdx.y;
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const long long total = (long long)Cout * Cin * T;
+    const long long N = (long long)Cin * T;
+    for (int tap = row; tap < T; tap += 8) {
+        float s = 0.f;
+        if (ci0 + lane < Cin) {
+            const long long idx = (long long)co * N + (long long)tap * Cin + ci0 + lane;
+            for (int z = 0; z < S; ++z) s += slab[(long long)z * total + idx];
+        }
+        tile[lane * T + tap] = s;
+    }
+    __syncthreads();
+    const int nvalid = min(32, Cin - ci0) * T;
+    float* out = dw + ((long long)co * Cin + ci0) * T;
+    for (int j = row * 32 + lane; j < nvalid; j += 256) out[j] = accumulate ? out[j] + tile[j] : tile[j];
+}
+
+// w[co][ci][tap] -> fwd[(tap*Cin+ci)][co], dgrad[(tap*Cout+co)][ci]   (generic, uncoalesced reads)
 __global__ void prep_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd,
                                     float* __restrict__ dg, int Cout, int Cin, int T) {
     const long long total = (long long)Cout * Cin * T;
@@ -792,6 +816,40 @@ __global__ void prep_weights_kernel(const float* __restrict__ w, float* __restri
         const float v = w[((long long)co * Cin + ci) * T + tap];
         if (fwd) fwd[idx] = v;
         if (dg) dg[((long long)tap * Cout + co) * Cin + ci] = v;
+    }
+}
+
+// Tiled version for T <= 9: a block stages w[co0..co0+31][ci0..ci0+31][all taps] (32 contiguous runs of 32*T
+// floats) in LDS and writes both layouts with 128-byte runs.  blockDim = (32, 8).
+template <int TMAX>
+__global__ void prep_weights_tiled_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                          float* __restrict__ dg, int Cout, int Cin, int T) {
+    constexpr int LDT = 32 * TMAX + 1;
+    __shared__ float tile[32 * LDT];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int lane = threadIdx.x, row = threadIdx.y;
+    const int nci = min(32, Cin - ci0), nco = min(32, Cout - co0);
+    const int run = nci * T;
+    for (int r = row; r < nco; r += 8) {
+        const float* src = w + ((long long)(co0 + r) * Cin + ci0) * T;
+        for (int j = lane; j < run; j += 32) tile[r * LDT + j] = src[j];
+    }
+    __syncthreads();
+    if (fwd) {
+        // rows (tap, ci), 32 consecutive co per row
+        for (int q = row; q < nci * T; q += 8) {
+            const int tap = q / nci, cil = q - tap * nci;
+            if (lane < nco)
+                fwd[((long long)tap * Cin + ci0 + cil) * Cout + co0 + lane] = tile[lane * LDT + cil * T + tap];
+        }
+    }
+    if (dg) {
+        // rows (tap, co), 32 consecutive ci per row
+        for (int q = row; q < nco * T; q += 8) {
+            const int tap = q / nco, col = q - tap * nco;
+            if (lane < nci)
+                dg[((long long)tap * Cout + co0 + col) * Cin + ci0 + lane] = tile[col * LDT + lane * T + tap];
+        }
     }
 }
 
@@ -884,7 +942,7 @@ size_t occupancy_pad(long long blocks, size_t static_lds) {
     return want > static_lds ? want - static_lds : 0;
 }
 
-int g_wgrad_bk = 0;    // pixel chunk of the fast weight-gradient kernel: 16, 32, or 0 = choose by split count
+int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 32
 int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
 
 template <int BM, int BN, int WM, int BK>
@@ -939,11 +997,13 @@ int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
 }
 
 // split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
+int g_wgrad_blocks = 768;   // target number of workgroups of a weight-gradient launch (tiles x pixel splits)
+
 int wgrad_splits(int Cout, int N, int P) {
     const int BM = Cout <= 64 ? 64 : 128, BN = 128;
     const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
-    long long s = (768 + tiles - 1) / tiles;
+    long long s = (g_wgrad_blocks + tiles - 1) / tiles;
     if (s > chunks / 8) s = chunks / 8;
     if (s < 1) s = 1;
     if (s > 256) s = 256;
@@ -959,7 +1019,8 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "occupancy_cap")) { g_occ_cap = value; return WSDL_OK; }
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
-    if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = (value == 16 || value == 32) ? value : 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
     return WSDL_EINVAL;
 }
@@ -969,9 +1030,20 @@ int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad, int
     WSDL_REQUIRE(w && (wt_fwd || wt_dgrad), "prep_weights: null pointer");
     WSDL_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "prep_weights: bad shape");
     const long long total = (long long)Cout * Cin * kh * kw;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), w,
-                       wt_fwd, wt_dgrad, Cout, Cin, kh * kw);
+    const int T = kh * kw;
+    if (T <= 9 && Cout <= 65535 * 32) {
+        dim3 grid(wsdl::cdiv(Cin, 32), wsdl::cdiv(Cout, 32));
+        if (T == 1)
+            hipLaunchKernelGGL((prep_weights_tiled_kernel<1>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, wt_fwd,
+                               wt_dgrad, Cout, Cin, T);
+        else
+            hipLaunchKernelGGL((prep_weights_tiled_kernel<9>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, wt_fwd,
+                               wt_dgrad, Cout, Cin, T);
+    } else {
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), w,
+                           wt_fwd, wt_dgrad, Cout, Cin, T);
+    }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -1083,8 +1155,9 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             p.x_bytes = (unsigned)xb;
             p.dy_bytes = (unsigned)dyb;
             dim3 grid(p.N / 128, Cout / 128, S);
-            // short per-block pixel ranges (many splits) pipeline better with 16-pixel chunks; long ones with 32
-            if (g_wgrad_bk == 16 || (g_wgrad_bk == 0 && S >= 8))
+            // 16-pixel chunks (35 KB of LDS, 4 workgroups per CU) beat 32-pixel chunks (68 KB, 2 per CU) on all but two
+            // ASPP shapes (profiles/r01_notes.md)
+            if (g_wgrad_bk != 32)
                 hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 16>), grid, dim3(kThreads),
                                    2 * (128 + 128) * 17 * sizeof(float), s, p);
             else
@@ -1099,9 +1172,14 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     }
     WSDL_LAUNCH_CHECK();
     const long long total = (long long)Cout * p.N;
-    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S, Cout, Cin,
-                       kh * kw, accumulate);
+    const int T = kh * kw;
+    if (T >= 2 && T <= 16 && Cout <= 65535) {
+        hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw, S,
+                           Cout, Cin, T, accumulate);
+    } else {
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S, Cout, Cin, T, accumulate);
+    }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

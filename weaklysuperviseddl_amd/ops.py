@@ -68,8 +68,13 @@ def prep_weights(w, want_fwd=True, want_dgrad=True):
     w = _dense(w, "weight")
     Cout, Cin, kh, kw = w.shape
     wf = torch.empty(kh * kw * Cin, Cout, device=w.device, dtype=torch.float32) if want_fwd else None
-    wd = torch.empty(kh * kw * Cout, Cin, device=w.device, dtype=torch.float32) if want_dgrad else None
-    check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd), Cout, Cin, kh, kw, _stream()))
+    if want_dgrad and kh * kw == 1:
+        wd, make_wd = w.detach().reshape(Cout, Cin), False     # [tap*Cout+co][ci] of a 1x1 kernel IS w's own layout
+    else:
+        wd = torch.empty(kh * kw * Cout, Cin, device=w.device, dtype=torch.float32) if want_dgrad else None
+        make_wd = want_dgrad
+    if want_fwd or make_wd:
+        check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd if make_wd else None), Cout, Cin, kh, kw, _stream()))
     return wf, wd
 
 
