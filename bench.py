@@ -70,6 +70,18 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch (fetch + write) of `kernel` from the committed rocprofv3 --pmc passes of this command
+    (profiles/r*_pmc_traffic.json: FETCH_SIZE x 2 - gfx950 counts half of a coalesced read, calibrated on a
+    known-size copy in our access widths - plus WRITE_SIZE).  PMC passes cannot run inside bench.py itself."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+
+
 def cpu_baseline(B, H, W, steps=2):
     import oracle
     torch.manual_seed(0)
@@ -134,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cam", action="store_true")
+    ap.add_argument("--cam-only", action="store_true", help="only the secondary CAM ms/img measurement (profiling aid)")
     args = ap.parse_args()
 
     from weaklysuperviseddl_amd import ops
@@ -141,6 +154,9 @@ def main():
     from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
     from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
 
+    if args.cam_only:
+        print(json.dumps({"cam": cam_bench(torch.device("cuda", 0), iters=10)}), flush=True)
+        return
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
@@ -208,10 +224,10 @@ def main():
     if rank == 0 and not args.no_roofline:
         kernels = []
         for c in range(ops.PROF_NCLASSES):
-            n, ms, work, exe = ops.prof_collect(c)
+            n, ms, work, exe, byt = ops.prof_collect(c)
             if n:
                 kernels.append({"kernel": ops.prof_class_name(c), "launches": n, "avg_us": round(ms / n * 1e3, 3),
-                                "total_ms": round(ms, 3), "work": work, "executed": exe})
+                                "total_ms": round(ms, 3), "work": work, "executed": exe, "alg_bytes": byt})
         ops.prof_reset()
         kernels.sort(key=lambda k: -k["total_ms"])
         if kernels:
@@ -223,12 +239,15 @@ def main():
             result["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(ach, 3),
                                   "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                                   "achieved_nominal": round(nom, 3),
-                                  "traffic": None, "launches": top["launches"], "avg_launch_us": top["avg_us"],
+                                  "traffic": pmc_traffic(top["kernel"]),
+                                  "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
+                                  "launches": top["launches"], "avg_launch_us": top["avg_us"],
                                   "flop_per_launch_avg": top["executed"] / top["launches"],
                                   "flop_per_launch_avg_nominal": top["work"] / top["launches"],
                                   "peak_note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak; bf16 peak not applicable: "
                                                "the path computes in exact fp32"}
-            result["kernels"] = [{k: (round(v / 1e12, 3) if k in ("work", "executed") else v) for k, v in kk.items()} |
+            result["kernels"] = [{k: (round(v / 1e12, 3) if k in ("work", "executed") else (round(v / 1e9, 3) if k == "alg_bytes" else v))
+                                  for k, v in kk.items()} |
                                  {"tflops": round(kk["executed"] / (kk["total_ms"] * 1e-3) / 1e12, 3),
                                   "tflops_nominal": round(kk["work"] / (kk["total_ms"] * 1e-3) / 1e12, 3)} for kk in kernels]
             result["model_tflops_nominal"] = round(value * GFLOP_PER_IMG_256 * (S / 256) ** 2 / 1e3, 3)

@@ -60,7 +60,8 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (fo
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,
-                      double* total_work_executed /* work minus the skipped all-padding K-chunks */);
+                      double* total_work_executed /* work minus the skipped all-padding K-chunks */,
+                      double* total_bytes /* algorithmic HBM bytes: every operand read once, result written once */);
 int wsdl_prof_reset(void);
 
 /* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------
@@ -84,13 +85,18 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y,
                     int B, int Cin, int H, int W, int Cout, int kh, int kw,
                     int stride, int pad, int dil,
                     const float* scale, const float* shift, const float* residual, int relu,
-                    long long x_bs, long long y_bs, long long res_bs, wsdl_stream_t stream);
+                    long long x_bs, long long y_bs, long long res_bs,
+                    void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* Optional scratch for forward / dgrad: grids too small to fill 256 CUs (small batches of small maps) are split
+ * along K into slabs summed in fixed order.  Returns 0 when the geometry does not benefit; ws may be NULL. */
+size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                                   int stride, int pad, int dil, int dgrad);
 
 /* dx = conv_transpose(dy, w)  (+ dx if accumulate).  dy is (B,Cout,OH,OW) with batch stride dy_bs. */
 int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate,
-                      long long dy_bs, wsdl_stream_t stream);
+                      long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
 /* dw[Cout][Cin][kh][kw] = sum_{b,oh,ow} dy * x_shifted  (+ dw if accumulate).  Split over pixel
  * ranges into fp32 slabs in `ws`, summed in fixed order by a second kernel (bitwise reproducible). */

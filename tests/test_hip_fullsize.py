@@ -72,7 +72,8 @@ def test_aspp_skipped_taps_equal_dense_result(dev):
     wc = w[:, :, 1:2, 1:2].contiguous()
     wcf, _ = ops.prep_weights(wc, True, False)
     yc = ops.conv2d_fwd(x, wcf, wc.shape, 1, 0, 1)
-    assert torch.equal(y, yc)                      # bit-exact: the skipped taps only ever added +0.0
+    # the skipped taps only ever added +0.0; the two launches may split K differently, hence fp32 re-association only
+    assert ((y - yc).abs().max() / yc.abs().max()).item() < 2e-6
     dy = torch.randn(y.shape, device=dev, generator=g)
     dw = ops.conv2d_wgrad(x, dy, w.shape, 1, 36, 36)
     dwc = ops.conv2d_wgrad(x, dy, wc.shape, 1, 0, 1)

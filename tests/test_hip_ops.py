@@ -43,7 +43,9 @@ CONV_CASES = [
     (3, 64, 9, 11, 2, 1, 1, 0, 1),         # classifier[4]: Cout=2
     (2, 256, 8, 8, 21, 1, 1, 0, 1),        # aux head: Cout=21
     (4, 128, 1, 1, 37, 1, 1, 0, 1),        # fc as 1x1 conv on a 1x1 map
-    (2, 160, 14, 14, 192, 3, 1, 1, 1),     # Cout = 128 + 64 (two M tiles, second partial)
+    (2, 160, 14, 14, 192, 3, 1, 1, 1),     # Cout = 128 + 64 (two M tiles, second partial); small grid -> split-K
+    (8, 512, 14, 14, 512, 3, 1, 2, 2),     # CAM path layer4 3x3 at B=8: 25 pixel tiles -> split-K x3
+    (8, 1024, 14, 14, 2048, 1, 1, 0, 1),   # CAM path layer4.0 downsample
 ]
 
 
@@ -85,6 +87,16 @@ def test_conv_epilogue_scale_shift_residual_relu(dev):
     wf, _ = ops.prep_weights(w.to(dev), True, False)
     y = ops.conv2d_fwd(x.to(dev), wf, w.shape, 1, 1, 1, sc.to(dev), sh.to(dev), res.to(dev), True)
     assert_close(y, ref, what="fused epilogue")
+    # the same epilogue through the split-K path (tiny grid: partial sums in slabs, epilogue in the reduce kernel)
+    x2 = torch.randn(2, 64, 12, 12, generator=g)
+    w2 = torch.randn(128, 64, 3, 3, generator=g) * 0.1
+    sc2, sh2, res2 = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g), torch.randn(2, 128, 12, 12, generator=g)
+    ref2 = F.relu(F.conv2d(x2, w2, None, 1, 1, 1) * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1) + res2)
+    from weaklysuperviseddl_amd._lib import lib
+    assert lib().wsdl_conv2d_igemm_workspace(2, 64, 12, 12, 128, 3, 3, 1, 1, 1, 0) > 0
+    wf2, _ = ops.prep_weights(w2.to(dev), True, False)
+    y2 = ops.conv2d_fwd(x2.to(dev), wf2, w2.shape, 1, 1, 1, sc2.to(dev), sh2.to(dev), res2.to(dev), True)
+    assert_close(y2, ref2, what="fused epilogue, split-K")
     # strided output (channel slice of a wider tensor)
     wide = torch.zeros(2, 100, 10, 10, device=dev)
     ops.conv2d_fwd(x.to(dev), wf, w.shape, 1, 1, 1, out=wide[:, 20:84])

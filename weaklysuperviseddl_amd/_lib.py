@@ -18,12 +18,13 @@ SIGNATURES = {
     "wsdl_target_arch": (C.c_char_p, []),
     "wsdl_set_option": (_i, [C.c_char_p, _i]),
     "wsdl_prof_enable": (_i, [_i]),
-    "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll)] + [C.POINTER(C.c_double)] * 4),
     "wsdl_prof_reset": (_i, []),
     "wsdl_prof_class_name": (C.c_char_p, [_i]),
     "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp]),
-    "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _vp]),
+    "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp, _sz, _vp]),
+    "wsdl_conv2d_igemm_workspace": (_sz, [_i] * 11),
+    "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _vp, _sz, _vp]),
     "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _sz, _vp]),
     "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),

@@ -48,7 +48,7 @@ struct ProfScope {
     int cls;
     hipStream_t s;
     void* slot;
-    ProfScope(int cls, hipStream_t s, double work, double work_executed = -1.0);
+    ProfScope(int cls, hipStream_t s, double work, double work_executed = -1.0, double bytes = 0.0);
     ~ProfScope();
 };
 

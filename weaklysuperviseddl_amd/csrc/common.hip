@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 
 struct ProfRec {
     hipEvent_t start, stop;
-    double work, executed;
+    double work, executed, bytes;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -26,12 +26,14 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
 
 bool prof_enabled() { return g_prof_on; }
 
-ProfScope::ProfScope(int c, hipStream_t st, double work, double work_executed) : cls(c), s(st), slot(nullptr) {
+ProfScope::ProfScope(int c, hipStream_t st, double work, double work_executed, double bytes)
+    : cls(c), s(st), slot(nullptr) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.work = work;
     r.executed = work_executed >= 0.0 ? work_executed : work;
+    r.bytes = bytes;
     if (!g_free_events.empty()) {
         r.start = g_free_events.back().first;
         r.stop = g_free_events.back().second;
@@ -62,11 +64,11 @@ const char* wsdl_target_arch(void) { return "gfx950"; }
 
 const char* wsdl_prof_class_name(int cls) {
     static const char* names[WSDL_PROF_NCLASSES] = {
-        "conv_igemm_fast_kernel<128, 128, 2>", "conv_igemm_kernel<128, 128, 2, false>",
-        "conv_igemm_fast_kernel<128, 64, 2>", "conv_igemm_kernel<128, 64, 2, false>",
-        "conv_igemm_fast_kernel<64, 256, 1>", "conv_igemm_kernel<64, 256, 1, false>",
-        "conv_igemm_fast_kernel<64, 128, 1>", "conv_igemm_kernel<64, 128, 1, false>",
-        "conv_wgrad_kernel<128, 128, 2>", "conv_wgrad_kernel<64, 128, 1>", "conv_wgrad_fast_kernel<128, 128, 2>",
+        "conv_igemm_fast_kernel<128, 128, 2, 16>", "conv_igemm_kernel<128, 128, 2, false>",
+        "conv_igemm_fast_kernel<128, 64, 2, 32>", "conv_igemm_kernel<128, 64, 2, false>",
+        "conv_igemm_fast_kernel<64, 256, 1, 16>", "conv_igemm_kernel<64, 256, 1, false>",
+        "conv_igemm_fast_kernel<64, 128, 1, 32>", "conv_igemm_kernel<64, 128, 1, false>",
+        "conv_wgrad_kernel<128, 128, 2>", "conv_wgrad_kernel<64, 128, 1>", "conv_wgrad_fast_kernel<128, 128, 2, 16>",
         "pairwise_kernel", "layercam_partial_kernel"};
     return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
 }
@@ -87,10 +89,10 @@ int wsdl_prof_reset(void) {
 }
 
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,
-                      double* total_work_executed) {
+                      double* total_work_executed, double* total_bytes) {
     WSDL_REQUIRE(cls >= 0 && cls < WSDL_PROF_NCLASSES, "prof class %d out of range", cls);
     std::lock_guard<std::mutex> lk(wsdl::g_prof_mu);
-    double ms = 0.0, work = 0.0, exe = 0.0;
+    double ms = 0.0, work = 0.0, exe = 0.0, byt = 0.0;
     for (auto& r : wsdl::g_prof[cls]) {
         WSDL_HIP_CHECK(hipEventSynchronize(r.stop));
         float t = 0.f;
@@ -98,11 +100,13 @@ int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* to
         ms += t;
         work += r.work;
         exe += r.executed;
+        byt += r.bytes;
     }
     if (launches) *launches = (long long)wsdl::g_prof[cls].size();
     if (total_ms) *total_ms = ms;
     if (total_work) *total_work = work;
     if (total_work_executed) *total_work_executed = exe;
+    if (total_bytes) *total_bytes = byt;
     return WSDL_OK;
 }
 

@@ -40,6 +40,8 @@ struct ConvP {
     int relu, accumulate;
     int P;  // B*OH*OW
     unsigned x_bytes;   // extent of x in bytes (buffer descriptor; < 2^31 for the fast path)
+    int ksplit;         // > 1: gridDim.z blocks share a tile's K chunks and write raw partial sums to `slab`
+    float* slab;        // [ksplit][Cout][P]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -333,7 +335,11 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
             ++nv;
         }
     }
-    const int nq = nv * cpt;
+    const int nq_all = nv * cpt;
+    // split-K: this block's share of the tile's (valid) chunks
+    const int q0 = p.ksplit > 1 ? (int)((long long)nq_all * blockIdx.z / p.ksplit) : 0;
+    const int q1 = p.ksplit > 1 ? (int)((long long)nq_all * (blockIdx.z + 1) / p.ksplit) : nq_all;
+    const int nq = q1 - q0;
     __syncthreads();
 
     // weights: per-thread constant byte offsets inside one [BK][Cout] slab
@@ -356,18 +362,22 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
     u32x4 ra[A_F4];
     unsigned rb[B_PER];
     // load cursor: valid-tap index / chunk inside the tap, and this thread's byte offset for the tap
-    int ld_vi = -1, ld_c = cpt, ld_tap = 0;
+    int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
     unsigned voff_b = kOOB;
     const unsigned chan_step = (unsigned)(B_STEP * HW) * 4u;     // bytes between this thread's k rows
+    auto set_tap = [&](int vi) {
+        ld_tap = __builtin_amdgcn_readfirstlane(vtaps[vi]);       // block-uniform: keep it scalar
+        int sp;
+        const bool ok = tap_src(ld_tap, sp);
+        voff_b = ok ? (img_off + (unsigned)sp) * 4u : kOOB;
+    };
+    if (nq > 0) set_tap(ld_vi);
 
     auto load_next = [&]() {                   // issues the loads of the next chunk in sequence
         if (ld_c == cpt) {
             ld_c = 0;
             ++ld_vi;
-            ld_tap = __builtin_amdgcn_readfirstlane(vtaps[ld_vi]);   // block-uniform: keep it scalar
-            int sp;
-            const bool ok = tap_src(ld_tap, sp);
-            voff_b = ok ? (img_off + (unsigned)sp) * 4u : kOOB;
+            set_tap(ld_vi);
         }
         const int k0 = ld_tap * p.Cin + ld_c * BK;
         const unsigned soff_a = (unsigned)(k0 * p.Cout) * 4u;
@@ -418,6 +428,22 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
         __syncthreads();
     }
 
+    if (p.ksplit > 1) {     // raw partial sums; conv_splitk_reduce_kernel applies the epilogue
+        float* sl = p.slab + (long long)blockIdx.z * p.Cout * p.P;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
+            if (opix >= p.P) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co < p.Cout) sl[(long long)co * p.P + opix] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue (same as the generic kernel)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -443,6 +469,27 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
                 yb[off] = v;
             }
         }
+    }
+}
+
+// y = epilogue(sum_z slab[z][co][pix]) for the split-K launches (fixed summation order)
+__global__ void conv_splitk_reduce_kernel(ConvP p) {
+    const long long total = (long long)p.Cout * p.P;
+    const int OHOW = p.OH * p.OW;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx / p.P), pix = (int)(idx - (long long)co * p.P);
+        float v = 0.f;
+        for (int z = 0; z < p.ksplit; ++z) v += p.slab[(long long)z * total + idx];
+        const int ob = pix / OHOW, orp = pix - ob * OHOW;
+        if (p.scale) v *= p.scale[co];
+        if (p.shift) v += p.shift[co];
+        const long long off = (long long)co * OHOW + orp;
+        if (p.res) v += p.res[(long long)ob * p.res_bs + off];
+        float* y = p.y + (long long)ob * p.y_bs + off;
+        if (p.accumulate) v += *y;
+        if (p.relu) v = fmaxf(v, 0.f);
+        *y = v;
     }
 }
 
@@ -947,6 +994,7 @@ int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half 
 
 template <int BM, int BN, int WM, int BK>
 void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
+    grid.z = p.ksplit > 1 ? p.ksplit : 1;
     constexpr size_t static_lds = 2 * BK * (BM + BN) * sizeof(float) + 64 * sizeof(int);
     static std::once_flag once;
     std::call_once(once, [] {
@@ -973,7 +1021,31 @@ void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
 // Tile choice: 128x128 (64x64 per wave) when that already gives every CU ~2 blocks; otherwise halve the
 // pixel tile (128x64) so small-map layers (Cout 256 at 32x32: 256 -> 512 blocks) keep two waves per SIMD and
 // the tap-skipping imbalance averages out.  Cout <= 64: 64x256 / 64x128.
-int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
+// Split-K for grids that cannot fill the chip (small batches of small maps, e.g. the CAM path at B=8: 14x14 maps
+// give 25 pixel tiles): returns the number of K slices (1 = no split).  Only the fast path supports it.
+int igemm_ksplit(int P, int Cout, int Cin, int T) {
+    if (Cin % 32 != 0 || Cout % 4 != 0 || Cout <= 64) return 1;
+    const long long blocks = (long long)wsdl::cdiv(P, 64) * wsdl::cdiv(Cout, 128);       // 128x64 tile
+    const int nq = T * (Cin / 32);
+    if (blocks >= 160 || nq < 8) return 1;
+    long long s = 320 / blocks;
+    if (s > nq / 4) s = nq / 4;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : (int)s;
+}
+
+int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_t ws_bytes) {
+    ConvP p = p_in;
+    p.ksplit = 1;
+    p.slab = nullptr;
+    {
+        const int ks = igemm_ksplit(p.P, p.Cout, p.Cin, p.KH * p.KW);
+        if (ks > 1 && ws && ws_bytes >= (size_t)ks * p.Cout * p.P * sizeof(float) && p.x_bytes != 0 &&
+            (long long)p.K * p.Cout * 4 < (1ll << 31)) {
+            p.ksplit = ks;
+            p.slab = static_cast<float*>(ws);
+        }
+    }
     // fast path: K chunks inside one tap, 16-byte weight rows, 31-bit byte offsets
     const bool aligned = (p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
                          (long long)p.K * p.Cout * 4 < (1ll << 31);
@@ -982,15 +1054,21 @@ int launch_igemm(const ConvP& p, hipStream_t s, double flops) {
     if (p.Cout <= 64)
         cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
     else
-        cfg = (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant ? 0 : 1;
+        cfg = (p.ksplit == 1 && (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant) ? 0 : 1;
     double executed = flops;
     if (aligned && wsdl::prof_enabled()) executed = flops * igemm_executed_fraction(p, cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128);
-    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops, executed);
+    const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
+    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops, executed, bytes);
     switch (cfg) {
         case 0: launch_cfg<128, 128, 2>(p, s, aligned); break;
         case 1: launch_cfg<128, 64, 2>(p, s, aligned); break;
         case 2: launch_cfg<64, 256, 1>(p, s, aligned); break;
         default: launch_cfg<64, 128, 1>(p, s, aligned); break;
+    }
+    if (p.ksplit > 1) {
+        const long long total = (long long)p.Cout * p.P;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)),
+                           dim3(256), 0, s, p);
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -1051,7 +1129,7 @@ int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad, int
 int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Cin, int H, int W,
                     int Cout, int kh, int kw, int stride, int pad, int dil, const float* scale,
                     const float* shift, const float* residual, int relu, long long x_bs,
-                    long long y_bs, long long res_bs, wsdl_stream_t stream) {
+                    long long y_bs, long long res_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && wt_fwd && y, "conv2d_fwd: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
@@ -1069,12 +1147,12 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Ci
         const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4;
         p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;     // 0 -> generic kernel
     }
-    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
+    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
 }
 
 int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                      long long dy_bs, wsdl_stream_t stream) {
+                      long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && wt_dgrad && dx, "conv2d_dgrad: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
@@ -1093,7 +1171,17 @@ int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, 
         const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cout * OH * OW) * 4;
         p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
     }
-    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin);
+    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
+}
+
+size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
+                                   int pad, int dil, int dgrad) {
+    int OH, OW;
+    if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
+    // forward: P = B*OH*OW output pixels, Cout rows; dgrad: roles swapped
+    const int P = dgrad ? B * H * W : B * OH * OW, M = dgrad ? Cin : Cout, Kc = dgrad ? Cout : Cin;
+    const int ks = igemm_ksplit(P, M, Kc, kh * kw);
+    return ks > 1 ? (size_t)ks * M * P * sizeof(float) : 0;
 }
 
 size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
@@ -1136,7 +1224,8 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         if (wsdl::prof_enabled() && Cin % 128 == 0)     // tiles inside one tap: all-padding pixel chunks are skipped
             executed = flops * wgrad_executed_fraction(p.P, OH, OW, H, W, kh, kw, stride, pad, dil);
         wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
-                             s, flops, executed);
+                             s, flops, executed,
+                             4.0 * ((double)B * Cin * H * W + (double)p.P * Cout + (double)S * Cout * p.N));
         constexpr size_t lds64 = 2 * (64 + 128) * 33 * sizeof(float), lds128 = 2 * (128 + 128) * 33 * sizeof(float);
         static std::once_flag once;
         static hipError_t attr_rc = hipSuccess;

@@ -109,8 +109,11 @@ def conv_bn(x, conv, bn, relu, residual=None):
         raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
     if bn.training:
         bn._pending_steps += 1      # momentum is fixed, so the counter never feeds the arithmetic
+    cache = None
+    if not bn.training:
+        cache = conv.__dict__.setdefault("_wsdl_cache", {})     # eval mode: keep derived tensors (keyed on versions/epoch)
     return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
-                           conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training)
+                           conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache)
 
 
 class FusedSequential(nn.Sequential):

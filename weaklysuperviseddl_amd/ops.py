@@ -48,6 +48,19 @@ def _planes(t, name="tensor"):
 
 _ws_cache = {}
 
+# Parameters / BN statistics are also written by raw-pointer kernels (Adam step, train-mode running statistics),
+# which torch's tensor version counters cannot see.  Every such writer bumps PARAM_EPOCH; eval-mode caches of
+# derived tensors (re-laid-out weights, folded BN scale/shift) are keyed on (PARAM_EPOCH, tensor._version, data_ptr).
+PARAM_EPOCH = [0]
+
+
+def bump_param_epoch():
+    PARAM_EPOCH[0] += 1
+
+
+def _cache_key(*tensors):
+    return (PARAM_EPOCH[0],) + tuple((t._version, t.data_ptr()) for t in tensors)
+
 
 def workspace(nbytes, device):
     """Stream-ordered scratch: one growing buffer per (device, stream)."""
@@ -99,8 +112,11 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
         residual, res_bs = _planes(residual, "residual")
         if tuple(residual.shape) != (B, Cout, OH, OW):
             raise WsdlError("conv2d: residual shape mismatch")
+    nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 0)
+    ws = workspace(nws, x.device) if nws else None
     check(lib().wsdl_conv2d_fwd(_p(x), _p(wt_fwd), _p(out), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
-                                _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs, _stream()))
+                                _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs,
+                                _p(ws), ws.numel() if ws is not None else 0, _stream()))
     return out
 
 
@@ -109,8 +125,11 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     B, Cin, H, W = xshape
     Cout, _, kh, kw = wshape
     dx = accumulate_into if accumulate_into is not None else torch.empty(xshape, device=dy.device, dtype=torch.float32)
+    nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 1)
+    ws = workspace(nws, dy.device) if nws else None
     check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
-                                  int(accumulate_into is not None), dy_bs, _stream()))
+                                  int(accumulate_into is not None), dy_bs, _p(ws), ws.numel() if ws is not None else 0,
+                                  _stream()))
     return dx
 
 
@@ -261,9 +280,15 @@ class _ConvAffineAct(torch.autograd.Function):
     """y = act(scale*conv(x,w) + shift + residual): eval-mode (folded) BN, conv bias, Linear."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, relu, shift_is_param):
+    def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, relu, shift_is_param, cache=None):
         need_dx = x.requires_grad
-        wf, wd = prep_weights(weight, True, need_dx)
+        key = _cache_key(weight) if cache is not None else None
+        if cache is not None and cache.get("prep_key") == key and (cache["prep"][1] is not None or not need_dx):
+            wf, wd = cache["prep"]                      # eval mode, weights untouched since the last call
+        else:
+            wf, wd = prep_weights(weight, True, need_dx)
+            if cache is not None:
+                cache["prep_key"], cache["prep"] = key, (wf, wd)
         y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None, shift_is_param)
         ctx.params = (weight, shift if shift_is_param else None)
@@ -302,7 +327,7 @@ class _ConvAffineAct(torch.autograd.Function):
             else:
                 dshift = bias_grad(dconv)
         dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil) if ctx.needs_input_grad[0] else None
-        return dx, dw, None, dshift, dres, None, None, None, None, None
+        return dx, dw, None, dshift, dres, None, None, None, None, None, None
 
 
 class _MaxPool3x3s2(torch.autograd.Function):
@@ -502,12 +527,19 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ functional API
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
-                momentum=0.1, eps=1e-5, training=True):
+                momentum=0.1, eps=1e-5, training=True, cache=None):
     if training:
+        bump_param_epoch()          # running statistics are about to be rewritten behind torch's back
         return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
                                 bool(relu), momentum, eps)
-    scale, shift = bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
-    return _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False)
+    key = _cache_key(gamma, beta, running_mean, running_var) if cache is not None else None
+    if cache is not None and cache.get("fold_key") == key:
+        scale, shift = cache["fold"]
+    else:
+        scale, shift = bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+        if cache is not None:
+            cache["fold_key"], cache["fold"] = key, (scale, shift)
+    return _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False, cache)
 
 
 def conv_bias_act(x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, residual=None):
@@ -670,6 +702,6 @@ def prof_class_name(cls):
 
 
 def prof_collect(cls):
-    n, ms, work, exe = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0)
-    check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work), C.byref(exe)))
-    return n.value, ms.value, work.value, exe.value
+    n, ms, work, exe, byt = C.c_longlong(0), C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    check(lib().wsdl_prof_collect(int(cls), C.byref(n), C.byref(ms), C.byref(work), C.byref(exe), C.byref(byt)))
+    return n.value, ms.value, work.value, exe.value, byt.value

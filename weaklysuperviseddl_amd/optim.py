@@ -64,6 +64,7 @@ class FlatAdam:
         if self.pre_step_hook is not None:
             self.pre_step_hook()
         self.step_count += 1
+        ops.bump_param_epoch()          # parameters change behind torch's version counters
         if self.flat_param.is_cuda:
             ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
