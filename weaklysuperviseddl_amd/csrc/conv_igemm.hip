@@ -64,6 +64,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
     __shared__ float As[2][BK * BM];
     __shared__ float Bs[2][BK * BN];
     __shared__ int vtaps[64];                      // ids of the taps that touch at least one real pixel
+    constexpr int kTab = ALIGNED ? 1 : 1024;
+    __shared__ int ktab[kTab][2];                  // unaligned path: k -> (ci*HW, (ti*bh) << 16 | (tj*bh & 0xffff))
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -72,6 +74,16 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
     const int n0 = blockIdx.x * BN;
     const int OHOW = p.OH * p.OW;
     const int HW = p.H * p.W;
+    const bool use_tab = !ALIGNED && p.K <= kTab;
+    if (use_tab) {
+        for (int k = tid; k < p.K; k += kThreads) {
+            const int tp = k / p.Cin, ci = k - tp * p.Cin;
+            const int ti = tp / p.KW, tj = tp - ti * p.KW;
+            ktab[k][0] = ci * HW;
+            ktab[k][1] = (int)(((unsigned)(ti * p.bh) << 16) | ((unsigned)(tj * p.bh) & 0xffffu));
+        }
+        __syncthreads();
+    }
 
     // ---- per-thread gather state for the B (activation) tile
     const int pl = tid % BN, kr = tid / BN;
@@ -176,7 +188,24 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
             for (int e = 0; e < B_PER; ++e) {
                 const int k = k0 + kr + e * B_STEP;
                 float v = 0.f;
-                if (pix_ok && k < p.K) {
+                if (use_tab) {
+                    // decode table in LDS: no integer divisions per gathered element (7x7 stem: K = 147)
+                    if (pix_ok && k < p.K) {
+                        const int cioff = ktab[k][0], sh2 = ktab[k][1];
+                        const int nh = poh * p.ah + (sh2 >> 16) + p.ch;
+                        const int nw = pow_ * p.ah + (int)(short)(sh2 & 0xffff) + p.ch;
+                        if (nh >= 0 && nw >= 0) {
+                            int ih = nh, iw = nw;
+                            bool ok = true;
+                            if (p.sh != 1) {
+                                ih = nh / p.sh;
+                                iw = nw / p.sh;
+                                ok = ih * p.sh == nh && iw * p.sh == nw;
+                            }
+                            if (ok && ih < p.H && iw < p.W) v = xb[(long long)cioff + ih * p.W + iw];
+                        }
+                    }
+                } else if (pix_ok && k < p.K) {
                     const int tp = k / p.Cin, ci = k - tp * p.Cin;
                     const int ti = tp / p.KW, tj = tp - ti * p.KW;
                     const int nh = poh * p.ah + ti * p.bh + p.ch;

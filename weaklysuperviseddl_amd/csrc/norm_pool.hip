@@ -7,17 +7,28 @@
 
 namespace {
 
-constexpr int kStatSplit = 32;  // partial sums per channel (fixed: results are bitwise reproducible)
+constexpr int kStatSplit = 32;  // max partial sums per channel (workspace stride); the count used is a fixed
+                                // function of (C, HW), so results stay bitwise reproducible
+
+// enough blocks to fill the chip, but not 65536 blocks of 6 KB each for C = 2048: ~2048 blocks in total,
+// slices a multiple of 4 pixels so the float4 path applies
+static int stat_splits(int C, int HW) {
+    int s = 2048 / C;
+    if (s < 1) s = 1;
+    if (s > kStatSplit) s = kStatSplit;
+    while (s > 1 && (HW % (4 * s)) != 0) --s;
+    return s;
+}
 
 // ws layout for BN: double part[C][kStatSplit][2] ; float coef[C][2]
 __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                 const float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ part, int B, int C,
-                                int HW, long long dy_bs, long long y_bs, int relu, int backward) {
+                                int HW, long long dy_bs, long long y_bs, int relu, int backward, int nsplit) {
     // forward : part = (sum x, sum x^2) ; backward: part = (sum dy', sum dy'*xhat), dy' = dy*[y>0]
     __shared__ double sm[16];
     const int c = blockIdx.x, s = blockIdx.y;
-    const int slice = (HW + kStatSplit - 1) / kStatSplit;
+    const int slice = (HW + nsplit - 1) / nsplit;
     const int r0 = s * slice;
     const int len = min(slice, HW - r0);
     double a0 = 0.0, a1 = 0.0;
@@ -75,11 +86,11 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
                                        float* __restrict__ save_invstd, float* __restrict__ rmean,
                                        float* __restrict__ rvar, float momentum, float eps, long long n,
-                                       int C) {
+                                       int C, int nsplit) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < kStatSplit; ++s) {
+    for (int s = 0; s < nsplit; ++s) {
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
         s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
     }
@@ -132,11 +143,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coef, long long n,
-                                       int C, int accumulate) {
+                                       int C, int accumulate, int nsplit) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < kStatSplit; ++s) {
+    for (int s = 0; s < nsplit; ++s) {
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
         s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
     }
@@ -376,10 +387,11 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     double* part = static_cast<double*>(ws);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kStatSplit), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
-                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0);
+    const int ns = stat_splits(C, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
+                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, save_mean,
-                       save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, C);
+                       save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, C, ns);
     hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, save_mean,
                        save_invstd, residual, y, C, HW, y_bs, relu, B * C);
     WSDL_LAUNCH_CHECK();
@@ -403,10 +415,11 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     hipStream_t s = wsdl::as_stream(stream);
     double* part = static_cast<double*>(ws);
     float* coef = reinterpret_cast<float*>(part + (size_t)C * kStatSplit * 2);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, kStatSplit), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
-                       part, B, C, HW, dy_bs, y_bs, relu, 1);
+    const int ns = stat_splits(C, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
+                       part, B, C, HW, dy_bs, y_bs, relu, 1, ns);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, gamma,
-                       save_invstd, dgamma, dbeta, coef, (long long)B * HW, C, accumulate_param_grads);
+                       save_invstd, dgamma, dbeta, coef, (long long)B * HW, C, accumulate_param_grads, ns);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, coef, dx, dres, C, HW, dy_bs, y_bs, relu, B * C);
     WSDL_LAUNCH_CHECK();
