@@ -1106,8 +1106,19 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
 // split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
 int g_wgrad_blocks = 768;   // target number of workgroups of a weight-gradient launch (tiles x pixel splits)
 
-int wgrad_splits(int Cout, int N, int P) {
-    const int BM = Cout <= 64 ? 64 : 128, BN = 128;
+// tile of the weight-gradient GEMM: the buffer-descriptor kernel needs Cout % BM == 0 and Cin % BN == 0
+void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
+    const int bm = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 0);
+    const int bn = Cin % 128 == 0 ? 128 : (Cin % 64 == 0 ? 64 : 0);
+    *fast = bm != 0 && bn != 0;
+    *BM = *fast ? bm : (Cout <= 64 ? 64 : 128);
+    *BN = *fast ? bn : 128;
+}
+
+int wgrad_splits(int Cout, int Cin, int N, int P) {
+    int BM, BN;
+    bool fast;
+    wgrad_tile(Cout, Cin, &BM, &BN, &fast);
     const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
     long long s = (g_wgrad_blocks + tiles - 1) / tiles;
@@ -1115,6 +1126,12 @@ int wgrad_splits(int Cout, int N, int P) {
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     return (int)s;
+}
+
+template <int BM, int BN, int WM>
+void launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
+    dim3 grid(p.N / BN, p.Cout / BM, S);
+    hipLaunchKernelGGL((conv_wgrad_fast_kernel<BM, BN, WM, 16>), grid, dim3(kThreads), 2 * (BM + BN) * 17 * sizeof(float), s, p);
 }
 
 }  // namespace
@@ -1218,7 +1235,7 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     int OH, OW;
     if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
     const int N = kh * kw * Cin;
-    return (size_t)wgrad_splits(Cout, N, B * OH * OW) * Cout * N * sizeof(float);
+    return (size_t)wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
 }
 
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
@@ -1235,7 +1252,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     p.N = kh * kw * Cin; p.P = B * OH * OW;
     p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
-    const int S = wgrad_splits(Cout, p.N, p.P);
+    const int S = wgrad_splits(Cout, Cin, p.N, p.P);
     const size_t need = (size_t)S * Cout * p.N * sizeof(float);
     if (ws_bytes < need) {
         wsdl::set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
@@ -1246,11 +1263,14 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     hipStream_t s = wsdl::as_stream(stream);
     const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4;
     const long long dyb = ((long long)(B - 1) * p.dy_bs + (long long)Cout * OH * OW) * 4;
-    const bool fast = Cout % 128 == 0 && Cin % 128 == 0 && xb < (1ll << 31) && dyb < (1ll << 31);
+    int tBM, tBN;
+    bool fast;
+    wgrad_tile(Cout, Cin, &tBM, &tBN, &fast);
+    WSDL_REQUIRE(!fast || (xb < (1ll << 31) && dyb < (1ll << 31)), "conv2d_wgrad: tensors above 2 GiB are not supported");
     {
         const double flops = 2.0 * p.P * (double)Cout * p.N;
         double executed = flops;
-        if (wsdl::prof_enabled() && Cin % 128 == 0)     // tiles inside one tap: all-padding pixel chunks are skipped
+        if (wsdl::prof_enabled() && fast)     // tiles inside one tap: all-padding pixel chunks are skipped
             executed = flops * wgrad_executed_fraction(p.P, OH, OW, H, W, kh, kw, stride, pad, dil);
         wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
                              s, flops, executed,
@@ -1272,14 +1292,15 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         if (fast) {
             p.x_bytes = (unsigned)xb;
             p.dy_bytes = (unsigned)dyb;
-            dim3 grid(p.N / 128, Cout / 128, S);
             // 16-pixel chunks (35 KB of LDS, 4 workgroups per CU) beat 32-pixel chunks (68 KB, 2 per CU) on all but two
             // ASPP shapes (profiles/r01_notes.md)
-            if (g_wgrad_bk != 32)
-                hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 16>), grid, dim3(kThreads),
-                                   2 * (128 + 128) * 17 * sizeof(float), s, p);
-            else
+            if (tBM == 128 && tBN == 128 && g_wgrad_bk == 32) {
+                dim3 grid(p.N / 128, Cout / 128, S);
                 hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 32>), grid, dim3(kThreads), lds128, s, p);
+            } else if (tBM == 128 && tBN == 128) launch_wgrad_fast<128, 128, 2>(p, s, S);
+            else if (tBM == 128) launch_wgrad_fast<128, 64, 2>(p, s, S);
+            else if (tBN == 128) launch_wgrad_fast<64, 128, 1>(p, s, S);
+            else launch_wgrad_fast<64, 64, 2>(p, s, S);
         } else if (Cout <= 64) {
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1>), grid, dim3(kThreads), lds64, s, p);

@@ -87,6 +87,9 @@ class GradBucketReducer:
             return
         self._launched[b] = True
         view = self.opt.flat_grad[self.bounds[b]:self.bounds[b + 1]]
+        if view.is_cuda:
+            from . import ops
+            ops.join_side_stream(view.device)        # this bucket's weight gradients come from the side stream
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):

@@ -219,6 +219,42 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
 
 
 # ------------------------------------------------------------------------------------------ autograd
+# Weight gradients are only consumed by the optimiser step, so they run on a side HIP stream: the MFMA-bound
+# wgrad kernels overlap the HBM-bound BatchNorm backward / gradient-reduce kernels of the main chain.
+OVERLAP_WGRAD = [True]
+_side_streams = {}
+
+
+def side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_stream(device):
+    """Make the current stream wait for everything queued on the side stream (before the optimiser step / a
+    gradient all-reduce reads the flat gradient buffer)."""
+    st = _side_streams.get(device)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
+def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink):
+    """d(param) = wgrad(x, dconv) written straight into param.grad (a slice of the flat gradient buffer)."""
+    accumulate = not sink.take_fresh(param)
+    if OVERLAP_WGRAD[0]:
+        main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
+        side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
+        with torch.cuda.stream(side):
+            conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate)
+        x.record_stream(side)                       # keep the caching allocator from recycling them early
+        dconv.record_stream(side)
+    else:
+        conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate)
+    sink.grad_ready(param)
+
+
 def _sink_of(param):
     """Parameters owned by a FlatAdam carry ``_wsdl_grad_sink``: their gradient is written by the kernels
     straight into the optimiser's flat gradient buffer (no autograd accumulation pass, no extra add)."""
@@ -263,8 +299,7 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
             if sw is not None:
-                conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=pw.grad, accumulate=not sw.take_fresh(pw))
-                sw.grad_ready(pw)
+                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw)
             else:
                 dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil)
         dx = None
@@ -313,8 +348,7 @@ class _ConvAffineAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
             if sw is not None and tuple(pw.grad.shape) == tuple(wshape):
-                conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=pw.grad, accumulate=not sw.take_fresh(pw))
-                sw.grad_ready(pw)
+                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw)
             else:
                 dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil)
         dshift = None

@@ -53,6 +53,8 @@ class FlatAdam:
             h(p)
 
     def zero_grad(self, set_to_none=False):
+        if self.flat_grad.is_cuda:
+            ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
         self.flat_grad.zero_()
         for k in self._fresh:
             self._fresh[k] = True
@@ -63,6 +65,8 @@ class FlatAdam:
     def step(self):
         if self.pre_step_hook is not None:
             self.pre_step_hook()
+        if self.flat_param.is_cuda:
+            ops.join_side_stream(self.flat_param.device)     # weight gradients are produced on the side stream
         self.step_count += 1
         ops.bump_param_epoch()          # parameters change behind torch's version counters
         if self.flat_param.is_cuda:
