@@ -753,10 +753,24 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
     const int chunk_end = min(chunk_begin + p.chunks_per_split * (32 / BK), total_chunks);
 
     // decode this thread's pixel of chunk c: byte offsets into dy / x (kOOB when padding / past the end)
+    const bool row_chunks = (p.OW % BK) == 0;      // a chunk never crosses an output row: decode it in scalars
     auto decode = [&](int c, unsigned& va, unsigned& vb) {
-        const int pix = c * BK + px;
         va = kOOB;
         vb = kOOB;
+        if (row_chunks) {
+            // c is block-uniform, so row / image index and the row's validity under the tap are SALU work;
+            // per lane only the column remains (P is a multiple of OW, so no ragged tail)
+            const int first = c * BK;
+            const int grow = first / p.OW, ow = first - grow * p.OW + px;
+            const int pb = grow / p.OH, oh = grow - pb * p.OH;
+            const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
+            const unsigned img_a = (unsigned)((long long)pb * p.dy_bs) + (unsigned)(oh * p.OW);
+            va = (img_a + (unsigned)ow + a_row) * 4u;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                vb = ((unsigned)((long long)pb * p.x_bs) + (unsigned)(ih * p.W) + (unsigned)iw + b_row) * 4u;
+            return;
+        }
+        const int pix = c * BK + px;
         if (pix < p.P) {
             const int pb = pix / OHOW, rp = pix - pb * OHOW;
             const int oh = rp / p.OW, ow = rp - oh * p.OW;
