@@ -1135,10 +1135,19 @@ int wgrad_splits(int Cout, int Cin, int N, int P) {
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
     const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
-    long long s = (g_wgrad_blocks + tiles - 1) / tiles;
-    if (s > chunks / 8) s = chunks / 8;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
+    long long s0 = (g_wgrad_blocks + tiles - 1) / tiles;
+    const long long smax = std::max<long long>(1, std::min<long long>(256, chunks / 8));
+    if (s0 > smax) s0 = smax;
+    if (s0 < 1) s0 = 1;
+    // among split counts near the target pick the one whose block count fills whole rounds of 256 CUs best
+    // (720 blocks = 2.8 per CU run at the pace of the CUs holding 3)
+    long long s = s0;
+    double best = 0.0;
+    for (long long c = std::max<long long>(1, s0 - 1); c <= std::min<long long>(smax, s0 + 3); ++c) {
+        const long long blocks = tiles * c, rounds = (blocks + kNumCU - 1) / kNumCU;
+        const double eff = (double)blocks / (double)(rounds * kNumCU);
+        if (eff > best + 0.02) { best = eff; s = c; }
+    }
     return (int)s;
 }
 
