@@ -210,6 +210,15 @@ int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
  * KL(softmax(X) || S) with log(X+1e-8), reduction 'batchmean', and its gradient wrt softmax(X). */
 int wsdl_kl_div_fwd_bwd(const float* xn, const float* s, float* loss, float* dxn, size_t n, int batch,
                         void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* Batched refinement: the same step for N images at once, every per-image scalar kept on the
+ * device.  kl_div_per_image: loss[i] = sum_i target*(log target - log(xn+1e-8)) over image i (reduction
+ * 'batchmean' of the reference's (1,C,H,W) call), dxn = -target/(xn+1e-8).  refine_combine:
+ * out = dkl + lambda*kl_i/(nc_scale*nc_i + 1e-6) * nc_scale * dnc  - the reference's dynamic weight
+ * (AlternatingDirectionCutLoss.py:748) without its two host synchronisations per step. */
+int wsdl_kl_div_per_image_fwd_bwd(const float* xn, const float* s, float* loss, float* dxn, int N,
+                                  size_t per_image, void* ws, size_t ws_bytes, wsdl_stream_t stream);
+int wsdl_refine_combine(const float* dkl, const float* dnc, const float* kl, const float* nc, float lambda,
+                        float nc_scale, float* out, int N, size_t per_image, wsdl_stream_t stream);
 /* softmax over C of (B,C,HW) and its backward */
 int wsdl_softmax_fwd(const float* x, float* y, int B, int C, int HW, wsdl_stream_t stream);
 int wsdl_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int HW, wsdl_stream_t stream);

@@ -62,6 +62,44 @@ def refine_pseudo_mask(model, image, mask, lambda_boundary=0.1, threshold=0.5, l
     return (Xf[0, 1] > threshold).float()
 
 
+def refine_pseudo_masks_batched(model, images, masks, lambda_boundary=0.1, threshold=0.5, lr=1e-2, num_steps=20,
+                                sigma_color=0.1, window_size=5):
+    """``refine_pseudo_mask`` for N images at once: images (N,3,H,W), masks (N,H,W) with
+    foreground = 255 -> (N,H,W) float masks.  Same arithmetic per image as the reference's per-image loop
+    (AlternatingDirectionCutLoss.py:803-810); each step is six kernel launches for the whole batch and no host
+    synchronisation (the reference: ~2 x 24 x 14 tiny kernels and two ``.item()`` syncs per image and step)."""
+    import ctypes as C
+    from .._lib import lib, check
+    device = next(model.parameters()).device
+    images = images.to(device).contiguous()
+    N, _, H, W = images.shape
+    model.eval()
+    with torch.no_grad():
+        S = ops.softmax_channels(model(images)["out"]).contiguous()
+        fg = (masks.to(device) == 255)
+        X = torch.stack([~fg, fg], dim=1).to(torch.float32).contiguous()
+        Xn, dkl, dnc, dXn, dX = (torch.empty_like(X) for _ in range(5))
+        m, v = torch.zeros_like(X), torch.zeros_like(X)
+        kl = torch.empty(N, device=device)
+        nc = torch.empty(N, device=device)
+        per = 2 * H * W
+        ws = ops.workspace(max(lib().wsdl_pairwise_workspace(N, H, W), N * 64 * 4, lib().wsdl_reduce_workspace()), device)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        for step in range(1, num_steps + 1):
+            check(lib().wsdl_softmax_fwd(p(X), p(Xn), N, 2, H * W, st))
+            check(lib().wsdl_kl_div_per_image_fwd_bwd(p(Xn), p(S), p(kl), p(dkl), N, per, p(ws), ws.numel(), st))
+            # NCut on the already-softmaxed X (softmax applied again inside, as the reference does - D8);
+            # normalise=1 gives sum/(H*W*K) per image, the reference divides by K*C: nc_scale = 1/C
+            check(lib().wsdl_pairwise_affinity_loss_fwd_bwd(p(Xn), p(images), p(nc), p(dnc), N, 2, H, W, int(window_size),
+                                                            float(sigma_color), 0.0, 1, 1, p(ws), ws.numel(), st))
+            check(lib().wsdl_refine_combine(p(dkl), p(dnc), p(kl), p(nc), float(lambda_boundary), 0.5, p(dXn), N, per, st))
+            check(lib().wsdl_softmax_bwd(p(Xn), p(dXn), p(dX), N, 2, H * W, st))
+            ops.adam_step_flat(X.view(-1), dX.view(-1), m.view(-1), v.view(-1), lr, 0.9, 0.999, 1e-8, step)
+        check(lib().wsdl_softmax_fwd(p(X), p(Xn), N, 2, H * W, st))
+        return (Xn[:, 1] > threshold).float()
+
+
 def train_model(model, optimizer, train_loader, num_epochs=3, device="cuda", log=print):
     """CE-only epochs (the reference's ``train_model``; criterion is nn.CrossEntropyLoss())."""
     model.train()

@@ -4,6 +4,6 @@ from .LayerCAM import LayerCAMGenerator  # noqa: F401
 from .PsuedoMasks import generate_pseudo_masks, keep_largest, generate  # noqa: F401
 from .SegmentationModel import SegmentationModel, build_segmentation_model, train_step, evaluate_model  # noqa: F401
 from .AlternatingDirectionCutLoss import (  # noqa: F401
-    LocalNormalizedCutLoss, compute_affinities, refine_pseudo_mask, train_model)
+    LocalNormalizedCutLoss, compute_affinities, refine_pseudo_mask, refine_pseudo_masks_batched, train_model)
 from .AlternatingDirectionBoundaryLoss import ConstrainToBoundaryLossSingle  # noqa: F401
 from .ExtraUtilities import compute_iou_and_acc  # noqa: F401

@@ -316,6 +316,33 @@ __global__ void kl_div_kernel(const float* __restrict__ xn, const float* __restr
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// per-image KL: grid (blocks, N); part[(img*gridDim.x + blockIdx.x)]
+__global__ void kl_div_image_kernel(const float* __restrict__ xn, const float* __restrict__ s,
+                                    float* __restrict__ part, float* __restrict__ dxn, size_t per_image) {
+    __shared__ float sm[16];
+    const size_t base = (size_t)blockIdx.y * per_image;
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_image; i += (size_t)gridDim.x * blockDim.x) {
+        const float t = s[base + i], xe = xn[base + i] + 1e-8f;
+        acc += (t > 0.f ? t * logf(t) : 0.f) - t * logf(xe);
+        if (dxn) dxn[base + i] = -t / xe;
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+
+// out = dkl + coef_i * dnc with coef_i = lambda * kl_i / (nc_i + 1e-6), all per image, all on the device
+__global__ void refine_combine_kernel(const float* __restrict__ dkl, const float* __restrict__ dnc,
+                                      const float* __restrict__ kl, const float* __restrict__ nc, float lambda,
+                                      float nc_scale, float* __restrict__ out, size_t per_image) {
+    const int img = blockIdx.y;
+    const float ncv = nc[img] * nc_scale;
+    const float coef = lambda * (kl[img] / (ncv + 1e-6f)) * nc_scale;
+    const size_t base = (size_t)img * per_image;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per_image; i += (size_t)gridDim.x * blockDim.x)
+        out[base + i] = dkl[base + i] + coef * dnc[base + i];
+}
+
 __global__ void softmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW,
                                    long long npix) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix;
@@ -479,6 +506,32 @@ int wsdl_kl_div_fwd_bwd(const float* xn, const float* s, float* loss, float* dxn
     float* part = static_cast<float*>(ws);
     hipLaunchKernelGGL(kl_div_kernel, dim3(blocks), dim3(256), 0, st, xn, s, part, dxn, n, 1.f / (float)batch);
     hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, st, part, blocks, 1, 1.f / (float)batch, loss);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_kl_div_per_image_fwd_bwd(const float* xn, const float* s, float* loss, float* dxn, int N,
+                                  size_t per_image, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+    WSDL_REQUIRE(xn && s && loss && ws && N > 0 && N <= 65535 && per_image > 0, "kl_div_per_image: bad arguments");
+    int blocks = (int)std::min<size_t>((per_image + 255) / 256, 64);
+    if (ws_bytes < (size_t)N * blocks * sizeof(float)) {
+        wsdl::set_error("kl_div_per_image: workspace too small");
+        return WSDL_EWORKSPACE;
+    }
+    hipStream_t st = wsdl::as_stream(stream);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(kl_div_image_kernel, dim3(blocks, N), dim3(256), 0, st, xn, s, part, dxn, per_image);
+    hipLaunchKernelGGL(finalize_sum_kernel, dim3(N), dim3(256), 0, st, part, blocks, N, 1.f, loss);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_refine_combine(const float* dkl, const float* dnc, const float* kl, const float* nc, float lambda,
+                        float nc_scale, float* out, int N, size_t per_image, wsdl_stream_t stream) {
+    WSDL_REQUIRE(dkl && dnc && kl && nc && out && N > 0 && N <= 65535 && per_image > 0, "refine_combine: bad arguments");
+    int blocks = (int)std::min<size_t>((per_image + 255) / 256, 256);
+    hipLaunchKernelGGL(refine_combine_kernel, dim3(blocks, N), dim3(256), 0, wsdl::as_stream(stream), dkl, dnc, kl, nc,
+                       lambda, nc_scale, out, per_image);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
