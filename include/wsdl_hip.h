@@ -201,6 +201,11 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
                            float alpha, int variant, float* cam, float thresh, uint8_t* mask,
                            void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
+/* classic CAM normalisation (CAMGenerator.generate_all_cams, TraditionalModel/AlternatingDirectionCutLoss.py:343-372):
+ * y = (relu(x) - min) / (max + 1e-8) per plane; the class-weighted channel sum itself is wsdl_conv2d_fwd with
+ * fc.weight as a 1x1 kernel. */
+int wsdl_plane_relu_minmax(const float* x, float* y, int planes, int hw, wsdl_stream_t stream);
+
 /* ---- optimiser: torch.optim.Adam defaults (TraditionalModel/SegmentationModel.py:91,109-111) -
  * one launch over a flat parameter / gradient buffer; grad_scale folds the 1/world_size of DP. */
 int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,

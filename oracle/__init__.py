@@ -34,7 +34,7 @@ from .losses import (  # noqa: F401
     compute_affinities,
     pairwise_affinity_loss,
 )
-from .layercam import LayerCAMGenerator, layercam_epilogue  # noqa: F401
+from .layercam import LayerCAMGenerator, CAMGenerator, layercam_epilogue  # noqa: F401
 from .pseudo_masks import keep_largest, cam_to_mask, generate_pseudo_masks  # noqa: F401
 from .refine import refine_pseudo_mask  # noqa: F401
 from .metrics import compute_iou_and_acc  # noqa: F401

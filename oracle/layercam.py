@@ -90,3 +90,28 @@ class LayerCAMGenerator:
             return layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant)
 
     __call__ = generate
+
+
+class CAMGenerator:
+    """Classic fc-weight CAM for every class - reference AlternatingDirectionCutLoss.py:320-403
+    (``einsum("c,chw->hw")`` per class, ReLU, per-class min-max; ``generate_bg_cam``: masked max over the valid
+    classes, ``1 - (1 - max)**alpha`` background map, both bilinearly resized to 224x224)."""
+
+    def __init__(self, model):
+        self.model = model.eval()
+
+    def generate_all_cams(self, image_tensor):
+        with torch.no_grad():
+            _logits, feats = self.model(image_tensor.unsqueeze(0))
+            f = feats[-1][0]                                                   # (Cf,h,w)
+            cams = F.relu(torch.einsum("kc,chw->khw", self.model.fc.weight, f))
+            return _minmax_(cams)
+
+    def generate_bg_cam(self, image_tensor, valid_class_indices, alpha=1.0, out_hw=(224, 224)):
+        cams = self.generate_all_cams(image_tensor)
+        keep = torch.zeros(cams.shape[0], 1, 1, dtype=cams.dtype)
+        keep[list(valid_class_indices)] = 1.0
+        max_obj = (cams * keep).max(dim=0).values
+        m_bg = 1.0 - ((1.0 - max_obj).clamp(min=0.0) ** alpha)
+        up = lambda t: F.interpolate(t[None, None], size=tuple(out_hw), mode="bilinear", align_corners=False)[0, 0]
+        return up(m_bg), up(max_obj)

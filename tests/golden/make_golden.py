@@ -154,6 +154,15 @@ def gen_layercam():
         out[f"{vname}_cam_argmax"] = cam.numpy()
     np.savez_compressed(f"{HERE}/layercam.npz", **out)
     print("layercam.npz", len(out))
+    # classic CAM (fc-weight CAM for every class) - AlternatingDirectionCutLoss.py:320-403
+    cam_cls = lift(f"{REF}/AlternatingDirectionCutLoss.py", {"CAMGenerator"})["CAMGenerator"]
+    cg = cam_cls(net)
+    co = {"image": imgs[1].numpy()}
+    co["all_cams"] = cg.generate_all_cams(imgs[1]).numpy()                      # (7,14,14)
+    m_bg, max_obj = cg.generate_bg_cam(imgs[1], [1, 4], alpha=2.0)
+    co["m_bg"], co["max_obj"] = m_bg.numpy(), max_obj.numpy()                   # (224,224) each
+    np.savez_compressed(f"{HERE}/classic_cam.npz", **co)
+    print("classic_cam.npz", len(co))
 
 
 def gen_refine_and_metrics():

@@ -111,6 +111,17 @@ def test_layercam_generator_hooks(golden):
     _close(gen(imgs[1], class_idx=torch.tensor([4]), alpha=0.5), g["notebook_cam_1_a0.5"], rel=1e-4)
 
 
+def test_classic_cam(golden):
+    g, gl = golden("classic_cam"), golden("layercam")
+    net = _Toy()
+    net.load_state_dict({k[6:]: T(gl[k]) for k in gl.files if k.startswith("state/")})
+    cg = oracle.CAMGenerator(net)
+    _close(cg.generate_all_cams(T(g["image"])), g["all_cams"], rel=1e-5)
+    m_bg, max_obj = cg.generate_bg_cam(T(g["image"]), [1, 4], alpha=2.0)
+    _close(m_bg, g["m_bg"], rel=1e-5)
+    _close(max_obj, g["max_obj"], rel=1e-5)
+
+
 def test_keep_largest_bit_exact(golden):
     g = golden("keep_largest")
     names = [k[3:] for k in g.files if k.startswith("in_")]

@@ -114,3 +114,35 @@ class LayerCAMGenerator:
         return self.generate_batch(x, float(alpha), class_idx)
 
     __call__ = generate
+
+
+class CAMGenerator:
+    """Classic fc-weight CAM (reference TraditionalModel/AlternatingDirectionCutLoss.py:320-403).
+
+    ``generate_all_cams(image (3,H,W)) -> (num_classes, h, w)``: the per-class ``einsum("c,chw->hw")`` loop of the
+    reference is ONE 1x1 convolution of layer4's features with ``fc.weight`` (37 x 2048 . 2048 x hw on the MFMA
+    kernel), followed by the ReLU + per-class min-max kernel.  ``generate_bg_cam`` mirrors the reference: masked
+    max over the valid classes, ``1 - (1 - max)**alpha``, both maps bilinearly resized to 224 x 224."""
+
+    def __init__(self, model):
+        self.model = model.eval()
+
+    @torch.no_grad()
+    def generate_all_cams_batch(self, images):
+        _logits, feats = self.model(images)
+        f = feats[-1]
+        w = self.model.fc.weight
+        raw = ops.conv_bias_act(f, w.reshape(w.shape[0], w.shape[1], 1, 1))      # (B, classes, h, w)
+        return ops.plane_relu_minmax(raw)
+
+    def generate_all_cams(self, image_tensor):
+        return self.generate_all_cams_batch(image_tensor.unsqueeze(0))[0]
+
+    @torch.no_grad()
+    def generate_bg_cam(self, image_tensor, valid_class_indices, alpha=1.0, out_hw=(224, 224)):
+        cams = self.generate_all_cams(image_tensor)
+        idx = torch.as_tensor(list(valid_class_indices), device=cams.device, dtype=torch.long)
+        max_obj = cams.index_select(0, idx).amax(dim=0).clamp(min=0.0)          # masked-out classes contribute 0
+        m_bg = 1.0 - ((1.0 - max_obj).clamp(min=0.0) ** alpha)
+        both = ops.bilinear_resize(torch.stack([m_bg, max_obj]).unsqueeze(0).contiguous(), out_hw)[0]
+        return both[0], both[1]

@@ -94,6 +94,22 @@ __global__ void layercam_normalise_kernel(CamLayers L, float* __restrict__ ws, f
     }
 }
 
+// y = minmax(relu(x)) per plane: c -= min; c /= (max + 1e-8)   (classic CAM, one block per (image, class) plane)
+__global__ void plane_relu_minmax_kernel(const float* __restrict__ x, float* __restrict__ y, int hw) {
+    __shared__ float sm[32];
+    const float* xp = x + (long long)blockIdx.x * hw;
+    float* yp = y + (long long)blockIdx.x * hw;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) {
+        const float v = fmaxf(xp[p], 0.f);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    block_minmax(mn, mx, sm);
+    const float den = (mx - mn) + 1e-8f;
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) yp[p] = (fmaxf(xp[p], 0.f) - mn) / den;
+}
+
 __device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
     float s = scale * ((float)o + 0.5f) - 0.5f;
     if (s < 0.f) s = 0.f;
@@ -222,6 +238,13 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(layercam_upsample_kernel, dim3(gx, B), dim3(256), 0, s, L, wsf, cam,
                        thresh >= 0.f ? mask : nullptr, outH, outW, alpha, variant, thresh);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_plane_relu_minmax(const float* x, float* y, int planes, int hw, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && y && planes > 0 && hw > 0, "plane_relu_minmax: bad arguments");
+    hipLaunchKernelGGL(plane_relu_minmax_kernel, dim3(planes), dim3(256), 0, wsdl::as_stream(stream), x, y, hw);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

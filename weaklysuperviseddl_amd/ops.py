@@ -662,6 +662,15 @@ def layercam_epilogue(acts, grads, out_hw=(224, 224), alpha=1.0, variant="modula
     return (cam, mask) if thresh is not None else cam
 
 
+def plane_relu_minmax(x):
+    """(..., h, w) -> per-plane (relu(x) - min) / (max + 1e-8)."""
+    x = _dense(x, "x")
+    hw = x.shape[-1] * x.shape[-2]
+    y = torch.empty_like(x)
+    check(lib().wsdl_plane_relu_minmax(_p(x), _p(y), x.numel() // hw, hw, _stream()))
+    return y
+
+
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     for t in (p, g, m, v):
         _req(t, "adam buffer")
