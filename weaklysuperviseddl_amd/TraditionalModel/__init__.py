@@ -7,3 +7,4 @@ from .AlternatingDirectionCutLoss import (  # noqa: F401
     LocalNormalizedCutLoss, compute_affinities, refine_pseudo_mask, refine_pseudo_masks_batched, train_model)
 from .AlternatingDirectionBoundaryLoss import ConstrainToBoundaryLossSingle  # noqa: F401
 from .ExtraUtilities import compute_iou_and_acc  # noqa: F401
+from .SegmentationDataset import PseudoSegmentationDataset  # noqa: F401
