@@ -8,6 +8,7 @@ True]`` (layer4 dilated, stride-16 features), every trunk parameter frozen, a tr
 randomly initialised as torchvision does; ``load_state_dict`` accepts the reference's checkpoints
 (keys ``layer0.0.weight`` ... ``fc.bias``).
 """
+import torch
 import torch.nn as nn
 
 from .. import nn as wnn
@@ -32,3 +33,34 @@ class FrozenResNetCAM(nn.Module):
         f4 = self.layer4(f3)
         logits = self.fc(self.avgpool(f4).flatten(1))
         return logits, [f2, f3, f4]
+
+
+def train_fc_only(model, dataloader, device="cuda", epochs=10, lr=1e-3, log=print):
+    """Stage 0: reference AlternatingDirectionCutLoss.py:116-141 / ClassificationModel.py:70-106.
+
+    Adam(lr=1e-3) on ``fc`` only with ``nn.CrossEntropyLoss``; ``model.train()`` as in the reference, so the frozen
+    trunk's BatchNorm layers normalise with batch statistics and their running statistics keep drifting.
+    Per-batch host reads of loss / accuracy are replaced by device accumulators read once per epoch."""
+    from .. import ops
+    from ..optim import FlatAdam
+    model.to(device)
+    model.train()
+    opt = FlatAdam(list(model.fc.parameters()), lr=lr)
+    for epoch in range(epochs):
+        tot_loss = torch.zeros((), device=device)
+        correct = torch.zeros((), device=device, dtype=torch.long)
+        total = 0
+        for imgs, (labels, _) in dataloader:
+            imgs, labels = imgs.to(device), torch.as_tensor(labels).to(device)
+            logits, _ = model(imgs)
+            loss = ops.cross_entropy(logits.reshape(logits.shape[0], -1, 1, 1), labels.reshape(-1, 1, 1).long())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            tot_loss += loss.detach() * imgs.size(0)
+            correct += (logits.detach().argmax(dim=1) == labels).sum()
+            total += imgs.size(0)
+        if log:
+            log(f"Epoch {epoch + 1}/{epochs} - Loss: {tot_loss.item() / total:.4f} - Acc: {100 * correct.item() / total:.2f}%")
+    model.eval()
+    return model

@@ -1,5 +1,5 @@
 """Drop-in surfaces mirroring the reference's ``TraditionalModel/`` modules (same public names)."""
-from .ClassificationModel import FrozenResNetCAM  # noqa: F401
+from .ClassificationModel import FrozenResNetCAM, train_fc_only  # noqa: F401
 from .LayerCAM import LayerCAMGenerator, CAMGenerator  # noqa: F401
 from .PsuedoMasks import generate_pseudo_masks, keep_largest, generate  # noqa: F401
 from .SegmentationModel import SegmentationModel, build_segmentation_model, train_step, evaluate_model  # noqa: F401
