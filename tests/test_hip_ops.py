@@ -46,6 +46,8 @@ CONV_CASES = [
     (2, 160, 14, 14, 192, 3, 1, 1, 1),     # Cout = 128 + 64 (two M tiles, second partial); small grid -> split-K
     (8, 512, 14, 14, 512, 3, 1, 2, 2),     # CAM path layer4 3x3 at B=8: 25 pixel tiles -> split-K x3
     (8, 1024, 14, 14, 2048, 1, 1, 0, 1),   # CAM path layer4.0 downsample
+    (3, 64, 32, 32, 128, 3, 1, 12, 12),    # ASPP-like on a 32x32 map: column bands [0,12) [12,20) [20,32)
+    (2, 128, 32, 40, 128, 3, 1, 24, 24),   # dilation 24, non-square map: bands [0,16) [16,24) [24,40)
 ]
 
 

@@ -42,6 +42,11 @@ struct ConvP {
     unsigned x_bytes;   // extent of x in bytes (buffer descriptor; < 2^31 for the fast path)
     int ksplit;         // > 1: gridDim.z blocks share a tile's K chunks and write raw partial sums to `slab`
     float* slab;        // [ksplit][Cout][P]
+    int ow0, own;       // output-column window: pixels are (b, oh, ow0 <= ow < ow0+own), P = B*OH*own
+    // column bands inside ONE launch (fast kernel): band i owns pixel tiles [b_tile0[i], b_tile0[i+1])
+    int nb;
+    int b_ow0[4], b_own[4], b_tile0[5];
+    int grid_x;         // host only: pixel tiles of the launch when banded (0 = cdiv(P, BN))
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +322,22 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int m0 = blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    // column bands: this block's band and its tile inside the band (scalar selects, no dynamic indexing: the
+    // window must stay in SGPRs or every buffer load below turns into a waterfall loop)
+    int w_ow0 = p.ow0, w_own = p.own, w_tile0 = 0;
+    if (p.nb > 1) {
+        w_ow0 = p.b_ow0[0];
+        w_own = p.b_own[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < p.nb && (int)blockIdx.x >= p.b_tile0[i]) {
+                w_ow0 = p.b_ow0[i];
+                w_own = p.b_own[i];
+                w_tile0 = p.b_tile0[i];
+            }
+    }
+    const int W_P = p.nb > 1 ? p.B * p.OH * w_own : p.P;
+    const int n0 = ((int)blockIdx.x - w_tile0) * BN;
     const int OHOW = p.OH * p.OW;
     const int HW = p.H * p.W;
 
@@ -327,13 +347,14 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
 
     const int pl = tid % BN, kr = tid / BN;
     const int pix = n0 + pl;
-    const bool pix_ok = pix < p.P;
+    const bool pix_ok = pix < W_P;
     int pb = 0, poh = 0, pow_ = 0;
+    const int OHW = p.OH * w_own;       // pixels of one image inside this block's column window
     if (pix_ok) {
-        pb = pix / OHOW;
-        const int r = pix - pb * OHOW;
-        poh = r / p.OW;
-        pow_ = r - poh * p.OW;
+        pb = pix / OHW;
+        const int r = pix - pb * OHW;
+        poh = r / w_own;
+        pow_ = w_ow0 + (r - poh * w_own);
     }
     const unsigned img_off = (unsigned)((long long)pb * p.x_bs) + (unsigned)(kr * HW);   // elements
 
@@ -458,17 +479,17 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
     }
 
     if (p.ksplit > 1) {     // raw partial sums; conv_splitk_reduce_kernel applies the epilogue
-        float* sl = p.slab + (long long)blockIdx.z * p.Cout * p.P;
+        float* sl = p.slab + (long long)blockIdx.z * p.Cout * W_P;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
-            if (opix >= p.P) continue;
+            if (opix >= W_P) continue;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co < p.Cout) sl[(long long)co * p.P + opix] = acc[i][j][r];
+                    if (co < p.Cout) sl[(long long)co * W_P + opix] = acc[i][j][r];
                 }
         }
         return;
@@ -477,9 +498,10 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
-        if (opix >= p.P) continue;
-        const int ob = opix / OHOW;
-        const int orp = opix - ob * OHOW;
+        if (opix >= W_P) continue;
+        const int ob = opix / OHW;
+        const int orr = opix - ob * OHW, ooh = orr / w_own;
+        const int orp = ooh * p.OW + w_ow0 + (orr - ooh * w_own);
         float* yb = p.y + (long long)ob * p.y_bs + orp;
         const float* rbp = p.res ? p.res + (long long)ob * p.res_bs + orp : nullptr;
 #pragma unroll
@@ -533,6 +555,10 @@ struct WgradP {
     int chunks_per_split;
     long long x_bs, dy_bs;
     unsigned x_bytes, dy_bytes;   // extents for the buffer-descriptor fast path (0 = not eligible)
+    int ow0, own;                 // output-column window (fast kernel): P = B*OH*own
+    int slab0;                    // first slab index of this launch
+    int nb, splits;               // column bands inside one launch: blockIdx.z = band * splits + split
+    int b_ow0[4], b_own[4], b_cps[4];   // per band: window and 32-pixel chunks per split
 };
 
 // Same pipeline as the forward kernel (LDS double buffer, one barrier per 32-pixel chunk).  When the
@@ -724,6 +750,20 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // column bands: blockIdx.z = band * splits + split (scalar selects keep the window in SGPRs)
+    int zsplit = blockIdx.z, w_ow0 = p.ow0, w_own = p.own, w_cps = p.chunks_per_split;
+    if (p.nb > 1) {
+        const int band = (int)blockIdx.z / p.splits;
+        zsplit = (int)blockIdx.z - band * p.splits;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i == band) {
+                w_ow0 = p.b_ow0[i];
+                w_own = p.b_own[i];
+                w_cps = p.b_cps[i];
+            }
+    }
+    const int W_P = p.nb > 1 ? p.B * p.OH * w_own : p.P;
     const int OHOW = p.OH * p.OW, HW = p.H * p.W;
     const int px = tid % BK, row0 = tid / BK;
 
@@ -748,12 +788,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
 
     unsigned ra[A_PER], rb[B_PER];
     // p.chunks_per_split counts 32-pixel chunks; this kernel walks BK-pixel chunks
-    const int chunk_begin = blockIdx.z * p.chunks_per_split * (32 / BK);
-    const int total_chunks = (p.P + BK - 1) / BK;
-    const int chunk_end = min(chunk_begin + p.chunks_per_split * (32 / BK), total_chunks);
+    const int chunk_begin = zsplit * w_cps * (32 / BK);
+    const int total_chunks = (W_P + BK - 1) / BK;
+    const int chunk_end = min(chunk_begin + w_cps * (32 / BK), total_chunks);
 
     // decode this thread's pixel of chunk c: byte offsets into dy / x (kOOB when padding / past the end)
-    const bool row_chunks = (p.OW % BK) == 0;      // a chunk never crosses an output row: decode it in scalars
+    const bool row_chunks = (w_own % BK) == 0;     // a chunk never crosses an output row: decode it in scalars
+    const int OHW = p.OH * w_own;
     auto decode = [&](int c, unsigned& va, unsigned& vb) {
         va = kOOB;
         vb = kOOB;
@@ -761,7 +802,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
             // c is block-uniform, so row / image index and the row's validity under the tap are SALU work;
             // per lane only the column remains (P is a multiple of OW, so no ragged tail)
             const int first = c * BK;
-            const int grow = first / p.OW, ow = first - grow * p.OW + px;
+            const int grow = first / w_own, ow = w_ow0 + first - grow * w_own + px;
             const int pb = grow / p.OH, oh = grow - pb * p.OH;
             const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
             const unsigned img_a = (unsigned)((long long)pb * p.dy_bs) + (unsigned)(oh * p.OW);
@@ -771,9 +812,10 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
             return;
         }
         const int pix = c * BK + px;
-        if (pix < p.P) {
-            const int pb = pix / OHOW, rp = pix - pb * OHOW;
-            const int oh = rp / p.OW, ow = rp - oh * p.OW;
+        if (pix < W_P) {
+            const int pb = pix / OHW, rr = pix - pb * OHW;
+            const int oh = rr / w_own, ow = w_ow0 + (rr - oh * w_own);
+            const int rp = oh * p.OW + ow;
             va = ((unsigned)((long long)pb * p.dy_bs) + (unsigned)rp + a_row) * 4u;
             const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
             if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
@@ -839,7 +881,7 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
         cur ^= 1;
     }
 
-    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.N;
+    float* slab = p.slab + (long long)(p.slab0 + blockIdx.z) * p.Cout * p.N;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * (NI * 32) + j * 32 + l31;
@@ -977,15 +1019,46 @@ int check_geom(int B, int Cin, int H, int W, int Cout, int kh, int kw, int strid
 
 // Fraction of the nominal K-chunks a launch really executes (profiling only): mirrors the kernels' skip
 // rule - a tap is skipped for a pixel tile when every pixel of the tile reads padding under that tap.
+// Column bands: the output columns split where the set of in-range column taps changes (ASPP dilation 12 on a
+// 32-wide map: [0,12) [12,20) [20,32)).  Launching each band separately makes tap validity uniform along a
+// tile's columns, so the tile-level skip also removes the column padding taps.  Only when every band is >= 8
+// pixels wide and the stride-1 / no-subsampling gather applies.
+struct Band { int ow0, own; };
+int column_bands(int OW, int W, int ah, int bh, int ch, int sh, int KW, Band* out /* >= 8 */) {
+    out[0] = Band{0, OW};
+    if (sh != 1 || ah != 1 || KW < 2 || KW > 3 || (bh < 8 && bh > -8)) return 1;
+    int cuts[8], nc = 0;
+    for (int j = 0; j < KW; ++j) {
+        const int o = j * bh + ch;                 // iw = ow + o
+        const int lo = -o, hi = W - o;             // valid: lo <= ow < hi
+        if (lo > 0 && lo < OW) cuts[nc++] = lo;
+        if (hi > 0 && hi < OW) cuts[nc++] = hi;
+    }
+    if (nc == 0) return 1;
+    std::sort(cuts, cuts + nc);
+    nc = (int)(std::unique(cuts, cuts + nc) - cuts);
+    if (nc > 3) return 1;
+    int prev = 0, n = 0;
+    Band tmp[8];
+    for (int i = 0; i <= nc; ++i) {
+        const int end = i < nc ? cuts[i] : OW;
+        if (end - prev < 8) return 1;
+        tmp[n++] = Band{prev, end - prev};
+        prev = end;
+    }
+    for (int i = 0; i < n; ++i) out[i] = tmp[i];
+    return n;
+}
+
 double igemm_executed_fraction(const ConvP& p, int BN) {
-    const int T = p.KH * p.KW, OHOW = p.OH * p.OW;
+    const int T = p.KH * p.KW, OHW = p.OH * p.own;
     long long done = 0, all = 0;
     for (int n0 = 0; n0 < p.P; n0 += BN) {
         for (int t = 0; t < T; ++t) {
             const int ti = t / p.KW, tj = t % p.KW;
             bool any = false;
             for (int pix = n0; pix < n0 + BN && pix < p.P && !any; ++pix) {
-                const int r = pix % OHOW, oh = r / p.OW, ow = r % p.OW;
+                const int r = pix % OHW, oh = r / p.own, ow = p.ow0 + r % p.own;
                 const int nh = oh * p.ah + ti * p.bh + p.ch, nw = ow * p.ah + tj * p.bh + p.ch;
                 if (nh < 0 || nw < 0 || nh % p.sh || nw % p.sh) continue;
                 any = nh / p.sh < p.H && nw / p.sh < p.W;
@@ -997,15 +1070,16 @@ double igemm_executed_fraction(const ConvP& p, int BN) {
     return all ? (double)done / (double)all : 1.0;
 }
 
-double wgrad_executed_fraction(int P, int OH, int OW, int H, int W, int KH, int KW, int stride, int pad, int dil) {
-    const int T = KH * KW, OHOW = OH * OW;
+double wgrad_executed_fraction(int P, int OH, int ow0, int own, int H, int W, int KH, int KW, int stride, int pad,
+                               int dil, int BK) {
+    const int T = KH * KW, OHW = OH * own;
     long long done = 0, all = 0;
-    for (int c0 = 0; c0 < P; c0 += 32) {
+    for (int c0 = 0; c0 < P; c0 += BK) {
         for (int t = 0; t < T; ++t) {
             const int dh = (t / KW) * dil - pad, dw = (t % KW) * dil - pad;
             bool any = false;
-            for (int pix = c0; pix < c0 + 32 && pix < P && !any; ++pix) {
-                const int r = pix % OHOW, ih = (r / OW) * stride + dh, iw = (r % OW) * stride + dw;
+            for (int pix = c0; pix < c0 + BK && pix < P && !any; ++pix) {
+                const int r = pix % OHW, ih = (r / own) * stride + dh, iw = (ow0 + r % own) * stride + dw;
                 any = ih >= 0 && ih < H && iw >= 0 && iw < W;
             }
             done += any;
@@ -1051,7 +1125,7 @@ void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
 
 template <int BM, int BN, int WM>
 void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
-    dim3 grid(wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
+    dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
     if (aligned) {
         if (BM * BN <= 128 * 64 && g_bk32 && p.Cin % 32 == 0)
             launch_fast<BM, BN, WM, 32>(p, s, grid);
@@ -1077,10 +1151,16 @@ int igemm_ksplit(int P, int Cout, int Cin, int T) {
     return s < 2 ? 1 : (int)s;
 }
 
+int g_col_bands = 1;   // launch dilated convs per output-column band (see column_bands)
+
 int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_t ws_bytes) {
     ConvP p = p_in;
     p.ksplit = 1;
     p.slab = nullptr;
+    p.ow0 = 0;
+    p.own = p.OW;
+    p.nb = 1;
+    p.grid_x = 0;
     {
         const int ks = igemm_ksplit(p.P, p.Cout, p.Cin, p.KH * p.KW);
         if (ks > 1 && ws && ws_bytes >= (size_t)ks * p.Cout * p.P * sizeof(float) && p.x_bytes != 0 &&
@@ -1098,15 +1178,41 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
     else
         cfg = (p.ksplit == 1 && (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant) ? 0 : 1;
+    // column bands (fast path, no split-K): one launch per band, each with uniform column-tap validity
+    Band bands[8];
+    int nb = 1;
+    bands[0] = Band{0, p.OW};
+    if (aligned && p.ksplit == 1 && g_col_bands) nb = column_bands(p.OW, p.W, p.ah, p.bh, p.ch, p.sh, p.KW, bands);
+    const int bn_tile = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128;
     double executed = flops;
-    if (aligned && wsdl::prof_enabled()) executed = flops * igemm_executed_fraction(p, cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128);
+    if (aligned && wsdl::prof_enabled()) {
+        executed = 0.0;
+        for (int i = 0; i < nb; ++i) {
+            ConvP q = p;
+            q.ow0 = bands[i].ow0; q.own = bands[i].own; q.P = p.B * p.OH * q.own;
+            executed += flops * ((double)q.own / p.OW) * igemm_executed_fraction(q, bn_tile);
+        }
+    }
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
     wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops, executed, bytes);
-    switch (cfg) {
-        case 0: launch_cfg<128, 128, 2>(p, s, aligned); break;
-        case 1: launch_cfg<128, 64, 2>(p, s, aligned); break;
-        case 2: launch_cfg<64, 256, 1>(p, s, aligned); break;
-        default: launch_cfg<64, 128, 1>(p, s, aligned); break;
+    {
+        ConvP q = p;
+        q.nb = nb;
+        int tiles = 0;
+        for (int i = 0; i < nb && nb > 1; ++i) {
+            q.b_ow0[i] = bands[i].ow0;
+            q.b_own[i] = bands[i].own;
+            q.b_tile0[i] = tiles;
+            tiles += wsdl::cdiv((long long)p.B * p.OH * bands[i].own, bn_tile);
+        }
+        q.b_tile0[nb > 1 ? nb : 0] = tiles;
+        q.grid_x = nb > 1 ? tiles : 0;
+        switch (cfg) {
+            case 0: launch_cfg<128, 128, 2>(q, s, aligned); break;
+            case 1: launch_cfg<128, 64, 2>(q, s, aligned); break;
+            case 2: launch_cfg<64, 256, 1>(q, s, aligned); break;
+            default: launch_cfg<64, 128, 1>(q, s, aligned); break;
+        }
     }
     if (p.ksplit > 1) {
         const long long total = (long long)p.Cout * p.P;
@@ -1166,6 +1272,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "occupancy_cap")) { g_occ_cap = value; return WSDL_OK; }
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
+    if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1253,12 +1360,24 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
     return ks > 1 ? (size_t)ks * M * P * sizeof(float) : 0;
 }
 
+// column bands of a weight-gradient launch (fast kernel only): same rule as the forward kernel
+int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int pad, int dil, Band* bands) {
+    int BM, BN;
+    bool fast;
+    wgrad_tile(Cout, Cin, &BM, &BN, &fast);
+    bands[0] = Band{0, OW};
+    if (!fast || !g_col_bands || stride != 1) return 1;
+    return column_bands(OW, W, 1, dil, -pad, 1, kw, bands);
+}
+
 size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
                                    int pad, int dil) {
     int OH, OW;
     if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
     const int N = kh * kw * Cin;
-    return (size_t)wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
+    Band bands[8];
+    const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
+    return (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
 }
 
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
@@ -1276,7 +1395,12 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
     const int S = wgrad_splits(Cout, Cin, p.N, p.P);
-    const size_t need = (size_t)S * Cout * p.N * sizeof(float);
+    Band bands[8];
+    const int nb = (g_wgrad_bk == 32) ? 1 : wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
+    if (nb == 1) bands[0] = Band{0, OW};
+    const int S_total = nb * S;
+    p.ow0 = 0; p.own = OW; p.slab0 = 0; p.nb = 1; p.splits = S;
+    const size_t need = (size_t)S_total * Cout * p.N * sizeof(float);
     if (ws_bytes < need) {
         wsdl::set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
         return WSDL_EWORKSPACE;
@@ -1293,11 +1417,16 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     {
         const double flops = 2.0 * p.P * (double)Cout * p.N;
         double executed = flops;
-        if (wsdl::prof_enabled() && fast)     // tiles inside one tap: all-padding pixel chunks are skipped
-            executed = flops * wgrad_executed_fraction(p.P, OH, OW, H, W, kh, kw, stride, pad, dil);
+        if (wsdl::prof_enabled() && fast) {   // tiles inside one tap: all-padding pixel chunks are skipped
+            executed = 0.0;
+            for (int i = 0; i < nb; ++i)
+                executed += flops * ((double)bands[i].own / OW) *
+                            wgrad_executed_fraction(B * OH * bands[i].own, OH, bands[i].ow0, bands[i].own, H, W, kh, kw,
+                                                    stride, pad, dil, g_wgrad_bk == 32 ? 32 : 16);
+        }
         wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
                              s, flops, executed,
-                             4.0 * ((double)B * Cin * H * W + (double)p.P * Cout + (double)S * Cout * p.N));
+                             4.0 * ((double)B * Cin * H * W + (double)p.P * Cout + (double)S_total * Cout * p.N));
         constexpr size_t lds64 = 2 * (64 + 128) * 33 * sizeof(float), lds128 = 2 * (128 + 128) * 33 * sizeof(float);
         static std::once_flag once;
         static hipError_t attr_rc = hipSuccess;
@@ -1320,10 +1449,20 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             if (tBM == 128 && tBN == 128 && g_wgrad_bk == 32) {
                 dim3 grid(p.N / 128, Cout / 128, S);
                 hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 32>), grid, dim3(kThreads), lds128, s, p);
-            } else if (tBM == 128 && tBN == 128) launch_wgrad_fast<128, 128, 2>(p, s, S);
-            else if (tBM == 128) launch_wgrad_fast<128, 64, 2>(p, s, S);
-            else if (tBN == 128) launch_wgrad_fast<64, 128, 1>(p, s, S);
-            else launch_wgrad_fast<64, 64, 2>(p, s, S);
+            } else {
+                WgradP q = p;                            // ONE launch: blockIdx.z = band * S + split
+                q.nb = nb;
+                q.splits = S;
+                for (int i = 0; i < nb && nb > 1; ++i) {
+                    q.b_ow0[i] = bands[i].ow0;
+                    q.b_own[i] = bands[i].own;
+                    q.b_cps[i] = wsdl::cdiv(wsdl::cdiv((long long)B * OH * bands[i].own, 32), S);
+                }
+                if (tBM == 128 && tBN == 128) launch_wgrad_fast<128, 128, 2>(q, s, S_total);
+                else if (tBM == 128) launch_wgrad_fast<128, 64, 2>(q, s, S_total);
+                else if (tBN == 128) launch_wgrad_fast<64, 128, 1>(q, s, S_total);
+                else launch_wgrad_fast<64, 64, 2>(q, s, S_total);
+            }
         } else if (Cout <= 64) {
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1>), grid, dim3(kThreads), lds64, s, p);
@@ -1336,11 +1475,11 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     const long long total = (long long)Cout * p.N;
     const int T = kh * kw;
     if (T >= 2 && T <= 16 && Cout <= 65535) {
-        hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw, S,
-                           Cout, Cin, T, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw,
+                           S_total, Cout, Cin, T, accumulate);
     } else {
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S, Cout, Cin, T, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate);
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;

@@ -88,8 +88,15 @@ class GradBucketReducer:
         self._launched[b] = True
         view = self.opt.flat_grad[self.bounds[b]:self.bounds[b + 1]]
         if view.is_cuda:
+            # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
+            # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
             from . import ops
-            ops.join_side_stream(view.device)        # this bucket's weight gradients come from the side stream
+            main, side = torch.cuda.current_stream(view.device), ops.side_stream(view.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append(work)
+            return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
