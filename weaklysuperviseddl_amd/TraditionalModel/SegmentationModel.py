@@ -112,7 +112,11 @@ def train_step(model, optimizer, images, masks, extra_loss=None):
 
 def make_optimizer(model, lr=1e-4):
     """torch.optim.Adam(model.parameters(), lr) semantics on one flat buffer / one kernel launch."""
-    return FlatAdam([p for p in model.parameters() if p.requires_grad], lr=lr)
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=lr)
+    convs = [m for m in model.modules() if isinstance(m, wnn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda]
+    if convs:
+        opt.post_step_hook = lambda: ops.prefetch_weight_layouts(convs)
+    return opt
 
 
 @torch.no_grad()

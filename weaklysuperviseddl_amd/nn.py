@@ -30,7 +30,8 @@ class Conv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x):
-        return ops.conv_bias_act(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        return ops.conv_bias_act(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                 cache=self.__dict__.setdefault("_wsdl_cache", {}))
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, "
@@ -109,9 +110,7 @@ def conv_bn(x, conv, bn, relu, residual=None):
         raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
     if bn.training:
         bn._pending_steps += 1      # momentum is fixed, so the counter never feeds the arithmetic
-    cache = None
-    if not bn.training:
-        cache = conv.__dict__.setdefault("_wsdl_cache", {})     # eval mode: keep derived tensors (keyed on versions/epoch)
+    cache = conv.__dict__.setdefault("_wsdl_cache", {})         # derived tensors, keyed on versions / epochs
     return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                            conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache)
 

@@ -51,15 +51,55 @@ _ws_cache = {}
 # Parameters / BN statistics are also written by raw-pointer kernels (Adam step, train-mode running statistics),
 # which torch's tensor version counters cannot see.  Every such writer bumps PARAM_EPOCH; eval-mode caches of
 # derived tensors (re-laid-out weights, folded BN scale/shift) are keyed on (PARAM_EPOCH, tensor._version, data_ptr).
-PARAM_EPOCH = [0]
+PARAM_EPOCH = [0]      # parameters rewritten by the Adam kernel
+STATS_EPOCH = [0]      # BN running statistics rewritten by a train-mode forward
 
 
 def bump_param_epoch():
     PARAM_EPOCH[0] += 1
 
 
+def bump_stats_epoch():
+    STATS_EPOCH[0] += 1
+
+
 def _cache_key(*tensors):
-    return (PARAM_EPOCH[0],) + tuple((t._version, t.data_ptr()) for t in tensors)
+    return (PARAM_EPOCH[0], STATS_EPOCH[0]) + tuple((t._version, t.data_ptr()) for t in tensors)
+
+
+def _weight_key(w):
+    return (PARAM_EPOCH[0], w._version, w.data_ptr())
+
+
+def _cached_prep(cache, weight, need_dx):
+    """(wt_fwd, wt_dgrad) from the module cache when the weights have not changed since they were laid out (eval
+    mode, or prefetched on the side stream right after the optimiser step); otherwise lay them out now."""
+    if cache is not None and cache.get("prep_key") == _weight_key(weight) and (cache["prep"][1] is not None or not need_dx):
+        ev = cache.get("prep_event")
+        if ev is not None:
+            torch.cuda.current_stream(weight.device).wait_event(ev)
+        return cache["prep"]
+    wf, wd = prep_weights(weight, True, need_dx)
+    if cache is not None:
+        cache["prep_key"], cache["prep"], cache["prep_event"] = _weight_key(weight), (wf, wd), None
+    return wf, wd
+
+
+def prefetch_weight_layouts(convs):
+    """Lay out next step's weights on the side stream (called right after the optimiser step): the ~0.6 ms of
+    re-layout kernels leave the forward chain; each conv waits on its own event."""
+    if not convs:
+        return
+    dev = convs[0].weight.device
+    main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for m in convs:
+            cache = m.__dict__.setdefault("_wsdl_cache", {})
+            wf, wd = prep_weights(m.weight, True, True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            cache["prep_key"], cache["prep"], cache["prep_event"] = _weight_key(m.weight), (wf, wd), ev
 
 
 def workspace(nbytes, device):
@@ -269,8 +309,8 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil, relu,
-                momentum, eps):
-        wf, wd = prep_weights(weight, True, x.requires_grad)
+                momentum, eps, cache=None):
+        wf, wd = _cached_prep(cache, weight, x.requires_grad)
         conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil)
         y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
                                        residual, relu)
@@ -308,7 +348,7 @@ class _ConvBNAct(torch.autograd.Function):
                 raise WsdlError("conv backward: dgrad weights were not prepared")
             dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil)
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                dres, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None)
 
 
 class _ConvAffineAct(torch.autograd.Function):
@@ -317,13 +357,7 @@ class _ConvAffineAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, relu, shift_is_param, cache=None):
         need_dx = x.requires_grad
-        key = _cache_key(weight) if cache is not None else None
-        if cache is not None and cache.get("prep_key") == key and (cache["prep"][1] is not None or not need_dx):
-            wf, wd = cache["prep"]                      # eval mode, weights untouched since the last call
-        else:
-            wf, wd = prep_weights(weight, True, need_dx)
-            if cache is not None:
-                cache["prep_key"], cache["prep"] = key, (wf, wd)
+        wf, wd = _cached_prep(cache, weight, need_dx)
         y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None, shift_is_param)
         ctx.params = (weight, shift if shift_is_param else None)
@@ -563,9 +597,9 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
                 momentum=0.1, eps=1e-5, training=True, cache=None):
     if training:
-        bump_param_epoch()          # running statistics are about to be rewritten behind torch's back
+        bump_stats_epoch()          # running statistics are about to be rewritten behind torch's back
         return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
-                                bool(relu), momentum, eps)
+                                bool(relu), momentum, eps, cache)
     key = _cache_key(gamma, beta, running_mean, running_var) if cache is not None else None
     if cache is not None and cache.get("fold_key") == key:
         scale, shift = cache["fold"]
@@ -576,8 +610,8 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, 
     return _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False, cache)
 
 
-def conv_bias_act(x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, residual=None):
-    return _ConvAffineAct.apply(x, weight, None, bias, residual, stride, pad, dil, bool(relu), bias is not None)
+def conv_bias_act(x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, residual=None, cache=None):
+    return _ConvAffineAct.apply(x, weight, None, bias, residual, stride, pad, dil, bool(relu), bias is not None, cache)
 
 
 def linear(x, weight, bias=None):

@@ -36,6 +36,7 @@ class FlatAdam:
                 p.data = view
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
         self.pre_step_hook = None      # e.g. wait for the gradient all-reduce
+        self.post_step_hook = None     # e.g. prefetch next step's weight layouts on the side stream
         # direct gradient delivery: the HIP backward kernels write each parameter's gradient straight into
         # its flat_grad slice (ops._sink_of); `_fresh` = not yet written since zero_grad (first write overwrites)
         self._fresh = {id(p): True for p in self.params}
@@ -74,3 +75,5 @@ class FlatAdam:
                                self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
+        if self.post_step_hook is not None:
+            self.post_step_hook()
