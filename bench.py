@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cam", action="store_true")
     ap.add_argument("--cam-only", action="store_true", help="only the secondary CAM ms/img measurement (profiling aid)")
+    ap.add_argument("--serial", action="store_true",
+                    help="no side-stream overlap anywhere: every kernel has the chip to itself (profiling aid; the "
+                         "roofline pass always runs like this)")
     args = ap.parse_args()
 
     from weaklysuperviseddl_amd import ops
@@ -157,6 +160,8 @@ def main():
     if args.cam_only:
         print(json.dumps({"cam": cam_bench(torch.device("cuda", 0), iters=10)}), flush=True)
         return
+    if args.serial:
+        ops.OVERLAP_WGRAD[0] = False
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
@@ -224,7 +229,7 @@ def main():
             step()
         torch.cuda.synchronize()
         ops.prof_enable(False)
-        ops.OVERLAP_WGRAD[0] = True
+        ops.OVERLAP_WGRAD[0] = not args.serial
     if rank == 0 and not args.no_roofline:
         kernels = []
         for c in range(ops.PROF_NCLASSES):
