@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
                 }
                 const int tp = tq + (jy - R) * TW + (jx - R);
                 const float d0 = i0 - lds[tp], d1 = i1 - lds[TS + tp], d2 = i2 - lds[2 * TS + tp];
-                const float cc = expf(-(d0 * d0 + d1 * d1 + d2 * d2) * inv2sc);
+                const float cc = __expf(-(d0 * d0 + d1 * d1 + d2 * d2) * inv2sc);   // v_exp_f32: 2 instructions, ~1 ulp
                 const float wf = wyF[jy] * wxF[jx], wr = wyR[jy] * wxR[jx];
                 af[k] = wf * cc;
                 ab[k] = (wf + wr) * cc;
