@@ -6,6 +6,9 @@ tensor the call raises.  ``oracle/`` is never imported from here.
 import ctypes as C
 import os
 
+import torch  # noqa: F401  (first: libwsdl_hip.so must bind to the HIP runtime PyTorch-ROCm has loaded, not to a
+#                            second copy of libamdhip64 - two runtimes in one process do not share devices / streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libwsdl_hip.so")
 
