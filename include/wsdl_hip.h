@@ -72,16 +72,22 @@ int wsdl_prof_reset(void);
  * Square kernels, one stride / padding / dilation for both spatial dims, groups = 1.
  *   OH = (H + 2*pad - dil*(kh-1) - 1)/stride + 1 (same for OW).                                   */
 
-/* Re-layout w[Cout][Cin][kh][kw] for the kernels: wt_fwd[(tap*Cin+ci)][Cout], wt_dgrad[(tap*Cout+co)][Cin].
- * Either destination may be NULL. */
-int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad,
+/* Re-layout w[Cout][Cin][kh][kw] for the kernels.  The layout buffers are opaque to the caller; their size
+ * comes from wsdl_conv2d_weight_layout_bytes (dgrad = 0: forward layout, 1: input-gradient layout):
+ *   plain  (fp32 MFMA kernels)      : wt_fwd[(tap*Cin+ci)][Cout], wt_dgrad[(tap*Cout+co)][Cin]  fp32;
+ *   split  (bf16x3 kernels, used when the contracted channel count % 16 == 0 and kh*kw <= 9):
+ *            [(k/16)][row][h|m|l][k%16] bf16, every weight split exactly into three bf16 pieces.
+ * *is_plain (optional) tells which one the current options select; for a plain 1x1 kernel the dgrad layout
+ * equals w itself.  Either destination of prep_weights may be NULL. */
+size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dgrad, int* is_plain);
+int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad,
                              int Cout, int Cin, int kh, int kw, wsdl_stream_t stream);
 
 /* y = act( scale[co]*conv(x) + shift[co] + residual ), any of scale/shift/residual may be NULL
  * (scale NULL = 1, shift NULL = 0).  relu != 0 applies max(.,0).  x_bs / y_bs / res_bs: batch strides
  * in elements (0 = dense).  Folded eval-mode BatchNorm, conv bias and the Linear layer (a 1x1 conv on
  * a 1x1 map) all go through scale/shift. */
-int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y,
+int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y,
                     int B, int Cin, int H, int W, int Cout, int kh, int kw,
                     int stride, int pad, int dil,
                     const float* scale, const float* shift, const float* residual, int relu,
@@ -93,7 +99,7 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
                                    int stride, int pad, int dil, int dgrad);
 
 /* dx = conv_transpose(dy, w)  (+ dx if accumulate).  dy is (B,Cout,OH,OW) with batch stride dy_bs. */
-int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx,
+int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate,
                       long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream);

@@ -66,13 +66,13 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--scale", type=int, default=1, help="2 = 512x512 inputs")
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names to run")
-    ap.add_argument("--opt", default="", help="name=value library option, e.g. occupancy_cap=0")
+    ap.add_argument("--opt", default="", help="name=value[,name=value] library options, e.g. conv_split=0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.opt:
-        from weaklysuperviseddl_amd._lib import lib, check
-        k, v = args.opt.split("=")
-        check(lib().wsdl_set_option(k.encode(), int(v)))
+        for kv in args.opt.split(","):
+            k, v = kv.split("=")
+            ops.set_option(k, v)
     B = args.batch
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     print(f"{'shape':24s} {'pass':6s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  x count")

@@ -24,6 +24,7 @@ SIGNATURES = {
     "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll)] + [C.POINTER(C.c_double)] * 4),
     "wsdl_prof_reset": (_i, []),
     "wsdl_prof_class_name": (C.c_char_p, [_i]),
+    "wsdl_conv2d_weight_layout_bytes": (_sz, [_i, _i, _i, _i, _i, C.POINTER(_i)]),
     "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp, _sz, _vp]),
     "wsdl_conv2d_igemm_workspace": (_sz, [_i] * 11),

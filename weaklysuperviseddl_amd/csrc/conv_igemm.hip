@@ -544,6 +544,8 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
     }
 }
 
+#include "conv_split.h"
+
 // ---------------------------------------------------------------------------------------------
 struct WgradP {
     const float* x;
@@ -1123,10 +1125,29 @@ void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
     hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), pad, s, p);
 }
 
+// bf16x3-split kernels (conv_split.h): which (rows, K-channels, taps) shapes use them.  A function of the
+// weight shape alone, so the layout kernel and the convolution agree on what the layout buffer holds.
+int g_conv_split = 1;
+int g_split_bk32 = 0;
+bool split_eligible(int rows, int kc, int T) {
+    return g_conv_split && kc % 16 == 0 && T <= 9 && (long long)T * kc * rows * 6 < (1ll << 31);
+}
+
+template <int BM, int BN, int WM, int BK>
+void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
+    grid.z = p.ksplit > 1 ? p.ksplit : 1;
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
+}
+
 template <int BM, int BN, int WM>
-void launch_cfg(const ConvP& p, hipStream_t s, bool aligned) {
+void launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
-    if (aligned) {
+    if (split) {
+        if (g_split_bk32 && BM * BN <= 128 * 64 && p.Cin % 32 == 0)
+            launch_split<BM, BN, WM, 32>(p, s, grid);
+        else
+            launch_split<BM, BN, WM, 16>(p, s, grid);
+    } else if (aligned) {
         if (BM * BN <= 128 * 64 && g_bk32 && p.Cin % 32 == 0)
             launch_fast<BM, BN, WM, 32>(p, s, grid);
         else
@@ -1170,8 +1191,14 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         }
     }
     // fast path: K chunks inside one tap, 16-byte weight rows, 31-bit byte offsets
-    const bool aligned = (p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
-                         (long long)p.K * p.Cout * 4 < (1ll << 31);
+    const bool split = split_eligible(p.Cout, p.Cin, p.KH * p.KW);     // p.wt then holds the split layout
+    if (split && p.x_bytes == 0) {
+        wsdl::set_error("conv: activation extent >= 2 GiB is not supported by the split-bf16 kernels "
+                        "(wsdl_set_option(\"conv_split\", 0) selects the fp32 kernels)");
+        return WSDL_EINVAL;
+    }
+    const bool aligned = split || ((p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
+                                   (long long)p.K * p.Cout * 4 < (1ll << 31));
     const long long kWant = g_tile_threshold;   // blocks below which the smaller tile is used (256 CUs x 2.5)
     int cfg;                           // 0: 128x128, 1: 128x64, 2: 64x256, 3: 64x128
     if (p.Cout <= 64)
@@ -1208,10 +1235,10 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         q.b_tile0[nb > 1 ? nb : 0] = tiles;
         q.grid_x = nb > 1 ? tiles : 0;
         switch (cfg) {
-            case 0: launch_cfg<128, 128, 2>(q, s, aligned); break;
-            case 1: launch_cfg<128, 64, 2>(q, s, aligned); break;
-            case 2: launch_cfg<64, 256, 1>(q, s, aligned); break;
-            default: launch_cfg<64, 128, 1>(q, s, aligned); break;
+            case 0: launch_cfg<128, 128, 2>(q, s, aligned, split); break;
+            case 1: launch_cfg<128, 64, 2>(q, s, aligned, split); break;
+            case 2: launch_cfg<64, 256, 1>(q, s, aligned, split); break;
+            default: launch_cfg<64, 128, 1>(q, s, aligned, split); break;
         }
     }
     if (p.ksplit > 1) {
@@ -1273,36 +1300,58 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
+    if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
     return WSDL_EINVAL;
 }
 
-int wsdl_conv2d_prep_weights(const float* w, float* wt_fwd, float* wt_dgrad, int Cout, int Cin,
+size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dgrad, int* is_plain) {
+    const int T = kh * kw;
+    const bool split = dgrad ? split_eligible(Cin, Cout, T) : split_eligible(Cout, Cin, T);
+    if (is_plain) *is_plain = split ? 0 : 1;
+    const size_t n = (size_t)Cout * Cin * T;
+    return split ? n * 6 : n * 4;
+}
+
+int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int Cout, int Cin,
                              int kh, int kw, wsdl_stream_t stream) {
     WSDL_REQUIRE(w && (wt_fwd || wt_dgrad), "prep_weights: null pointer");
     WSDL_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "prep_weights: bad shape");
     const long long total = (long long)Cout * Cin * kh * kw;
     const int T = kh * kw;
-    if (T <= 9 && Cout <= 65535 * 32) {
+    const bool fwd_split = wt_fwd && split_eligible(Cout, Cin, T);
+    const bool dg_split = wt_dgrad && split_eligible(Cin, Cout, T);
+    float* pf = fwd_split ? nullptr : static_cast<float*>(wt_fwd);
+    float* pd = dg_split ? nullptr : static_cast<float*>(wt_dgrad);
+    if (fwd_split || dg_split) {
         dim3 grid(wsdl::cdiv(Cin, 32), wsdl::cdiv(Cout, 32));
-        if (T == 1)
-            hipLaunchKernelGGL((prep_weights_tiled_kernel<1>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, wt_fwd,
-                               wt_dgrad, Cout, Cin, T);
-        else
-            hipLaunchKernelGGL((prep_weights_tiled_kernel<9>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, wt_fwd,
-                               wt_dgrad, Cout, Cin, T);
-    } else {
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), w,
-                           wt_fwd, wt_dgrad, Cout, Cin, T);
+        hipLaunchKernelGGL(prep_weights_split_kernel, grid, dim3(256), 0, wsdl::as_stream(stream), w,
+                           fwd_split ? static_cast<unsigned char*>(wt_fwd) : nullptr,
+                           dg_split ? static_cast<unsigned char*>(wt_dgrad) : nullptr, Cout, Cin, T);
+    }
+    if (pf || pd) {
+        if (T <= 9 && Cout <= 65535 * 32) {
+            dim3 grid(wsdl::cdiv(Cin, 32), wsdl::cdiv(Cout, 32));
+            if (T == 1)
+                hipLaunchKernelGGL((prep_weights_tiled_kernel<1>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, pf,
+                                   pd, Cout, Cin, T);
+            else
+                hipLaunchKernelGGL((prep_weights_tiled_kernel<9>), grid, dim3(32, 8), 0, wsdl::as_stream(stream), w, pf,
+                                   pd, Cout, Cin, T);
+        } else {
+            const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+            hipLaunchKernelGGL(prep_weights_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), w, pf, pd,
+                               Cout, Cin, T);
+        }
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
 
-int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Cin, int H, int W,
+int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin, int H, int W,
                     int Cout, int kh, int kw, int stride, int pad, int dil, const float* scale,
                     const float* shift, const float* residual, int relu, long long x_bs,
                     long long y_bs, long long res_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
@@ -1310,7 +1359,7 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Ci
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
     ConvP p{};
-    p.x = x; p.wt = wt_fwd; p.y = y; p.scale = scale; p.shift = shift; p.res = residual;
+    p.x = x; p.wt = static_cast<const float*>(wt_fwd); p.y = y; p.scale = scale; p.shift = shift; p.res = residual;
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.KH = kh; p.KW = kw;
     p.ah = stride; p.bh = dil; p.ch = -pad; p.sh = 1;
     p.K = kh * kw * Cin;
@@ -1326,14 +1375,14 @@ int wsdl_conv2d_fwd(const float* x, const float* wt_fwd, float* y, int B, int Ci
     return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
 }
 
-int wsdl_conv2d_dgrad(const float* dy, const float* wt_dgrad, float* dx, int B, int Cin, int H, int W,
+int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                       long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && wt_dgrad && dx, "conv2d_dgrad: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
     ConvP p{};
-    p.x = dy; p.wt = wt_dgrad; p.y = dx;
+    p.x = dy; p.wt = static_cast<const float*>(wt_dgrad); p.y = dx;
     // roles swap: "input" is dY (Cout channels, OH x OW), "output" is dX (Cin channels, H x W)
     p.B = B; p.Cin = Cout; p.H = OH; p.W = OW; p.Cout = Cin; p.OH = H; p.OW = W; p.KH = kh; p.KW = kw;
     p.ah = 1; p.bh = -dil; p.ch = pad; p.sh = stride;

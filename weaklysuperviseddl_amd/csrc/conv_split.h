@@ -1,0 +1,341 @@
+// conv_split.h - the implicit-GEMM convolution on the bf16 matrix core with fp32-equivalent accuracy
+// (included by conv_igemm.hip inside its anonymous namespace; shares ConvP and the host-side tile logic).
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand is split exactly into
+// three bf16 pieces  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 3 x 8 significant bits
+// cover fp32's 24), and a product a*b is evaluated as the six partial products whose weight is >= 2^-16:
+//     a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms
+// (am*bl, al*bm, al*bl) are <= 2^-23 |a*b| together: the size of ONE fp32 rounding, while an fp32 fma chain of
+// length K makes K of them.  Six bf16 MFMAs replace sixteen fp32-MFMA-equivalents of issue time: 2.67x the
+// arithmetic peak at unchanged accuracy (tests/test_hip_ops.py measures both kernels against fp64).
+//
+// Data path: weights are split once per optimiser step by the layout kernel ([k/16][row][piece][16] bf16, so a
+// K-chunk of a row tile is one contiguous run copied to LDS with 16-byte loads); activations are split by the
+// loading thread between the global load and the LDS store (11 VALU ops per pair, hidden under the MFMAs of
+// the other resident wave).  LDS rows are  (BK/16) x [h|m|l] x 16 bf16  + 16 bytes of padding: a row stride that
+// is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots
+// of the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> packed bf16 pairs of the three pieces
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    f32x2 v = {x0, x1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    f32x2 r = {x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u)};
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    f32x2 s = {r[0] - __builtin_bit_cast(float, m << 16), r[1] - __builtin_bit_cast(float, m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2));
+}
+
+constexpr int kSplitK16Bytes = 96;   // one row's 16 k values: 3 pieces x 16 bf16
+
+template <int BM, int BN, int WM, int BK>
+__global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) {
+    constexpr int WN = 4 / WM;
+    constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
+    static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
+    static_assert(BK == 16 || BK == 32, "K chunk");
+    constexpr int KS = BK / 16;                          // MFMA k-steps per chunk
+    constexpr int ROW = KS * kSplitK16Bytes + 16;        // LDS row stride in bytes (odd multiple of 16)
+    constexpr int A_UPS = BM * 6;                        // 16-byte units of one k16 slab of the row tile
+    constexpr int A_U = (KS * A_UPS + kThreads - 1) / kThreads;   // units per thread per chunk
+    constexpr bool A_EXACT = A_U * kThreads == KS * A_UPS;
+    constexpr int B_STEP = kThreads / BN;                // threads sharing one pixel
+    constexpr int B_PER = BK / B_STEP;                   // consecutive k (input channels) per thread
+    static_assert(B_PER == 4 || B_PER == 8 || B_PER == 16 || B_PER == 32, "B tile");
+    constexpr unsigned kOOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][BM * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * ROW];
+    __shared__ int vtaps[64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int m0 = blockIdx.y * BM;
+    int w_ow0 = p.ow0, w_own = p.own, w_tile0 = 0;
+    if (p.nb > 1) {
+        w_ow0 = p.b_ow0[0];
+        w_own = p.b_own[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < p.nb && (int)blockIdx.x >= p.b_tile0[i]) {
+                w_ow0 = p.b_ow0[i];
+                w_own = p.b_own[i];
+                w_tile0 = p.b_tile0[i];
+            }
+    }
+    const int W_P = p.nb > 1 ? p.B * p.OH * w_own : p.P;
+    const int n0 = ((int)blockIdx.x - w_tile0) * BN;
+    const int OHOW = p.OH * p.OW;
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (p.K / 16) * p.Cout * kSplitK16Bytes, 0x00020000);
+
+    const int pl = tid % BN, kr = tid / BN;
+    const int pix = n0 + pl;
+    const bool pix_ok = pix < W_P;
+    int pb = 0, poh = 0, pow_ = 0;
+    const int OHW = p.OH * w_own;
+    if (pix_ok) {
+        pb = pix / OHW;
+        const int r = pix - pb * OHW;
+        poh = r / w_own;
+        pow_ = w_ow0 + (r - poh * w_own);
+    }
+    const unsigned img_off = (unsigned)((long long)pb * p.x_bs) + (unsigned)(kr * B_PER * HW);   // elements
+
+    auto tap_src = [&](int t, int& sp) {
+        const int ti = t / p.KW, tj = t - ti * p.KW;
+        const int nh = poh * p.ah + ti * p.bh + p.ch;
+        const int nw = pow_ * p.ah + tj * p.bh + p.ch;
+        bool ok = pix_ok && nh >= 0 && nw >= 0;
+        int ih = nh, iw = nw;
+        if (p.sh != 1) {
+            ih = nh / p.sh;
+            iw = nw / p.sh;
+            ok = ok && (ih * p.sh == nh) && (iw * p.sh == nw);
+        }
+        ok = ok && ih < p.H && iw < p.W;
+        sp = ih * p.W + iw;
+        return ok;
+    };
+
+    const int T = p.KH * p.KW;
+    const int cpt = p.Cin / BK;
+    int nv = 0;
+    for (int t = 0; t < T; ++t) {
+        int sp;
+        const bool ok = tap_src(t, sp);
+        if (__syncthreads_or(ok)) {
+            if (tid == 0) vtaps[nv] = t;
+            ++nv;
+        }
+    }
+    const int nq_all = nv * cpt;
+    const int q0 = p.ksplit > 1 ? (int)((long long)nq_all * blockIdx.z / p.ksplit) : 0;
+    const int q1 = p.ksplit > 1 ? (int)((long long)nq_all * (blockIdx.z + 1) / p.ksplit) : nq_all;
+    const int nq = q1 - q0;
+    __syncthreads();
+
+    // weights: unit u of the chunk = (k-step, row, 16-byte part); a k16 slab of the row tile is contiguous
+    unsigned voff_a[A_U], lds_a[A_U];
+#pragma unroll
+    for (int e = 0; e < A_U; ++e) {
+        const int u = tid + e * kThreads;
+        const int ks = u / A_UPS, v = u - ks * A_UPS;
+        const int row = v / 6, part = v - row * 6;
+        voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
+                        ? (unsigned)(ks * p.Cout * kSplitK16Bytes + (m0 * 6 + v) * 16) : kOOB;
+        lds_a[e] = (unsigned)(row * ROW + ks * kSplitK16Bytes + part * 16);
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[A_U];
+    unsigned rb[B_PER];
+    int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
+    unsigned voff_b = kOOB;
+    auto set_tap = [&](int vi) {
+        ld_tap = __builtin_amdgcn_readfirstlane(vtaps[vi]);
+        int sp;
+        const bool ok = tap_src(ld_tap, sp);
+        voff_b = ok ? (img_off + (unsigned)sp) * 4u : kOOB;
+    };
+    if (nq > 0) set_tap(ld_vi);
+
+    auto load_next = [&]() {
+        if (ld_c == cpt) {
+            ld_c = 0;
+            ++ld_vi;
+            set_tap(ld_vi);
+        }
+        const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
+        const unsigned soff_a = (unsigned)(c16 * p.Cout * kSplitK16Bytes);
+#pragma unroll
+        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+        const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e)
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
+        ++ld_c;
+    };
+    // this thread's k run [kr*B_PER, kr*B_PER + B_PER) inside the chunk -> (k-step, offset inside the 16)
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < A_U; ++e)
+            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
+        unsigned hp[B_PER / 2], mp[B_PER / 2], lp[B_PER / 2];
+#pragma unroll
+        for (int e = 0; e < B_PER / 2; ++e)
+            split3(__builtin_bit_cast(float, rb[2 * e]), __builtin_bit_cast(float, rb[2 * e + 1]), hp[e], mp[e], lp[e]);
+        unsigned char* rowp = &Bs[buf][pl * ROW];
+        if constexpr (B_PER == 4) {
+            const int k = kr * 4, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
+            *reinterpret_cast<u32x2*>(rowp + off) = u32x2{hp[0], hp[1]};
+            *reinterpret_cast<u32x2*>(rowp + off + 32) = u32x2{mp[0], mp[1]};
+            *reinterpret_cast<u32x2*>(rowp + off + 64) = u32x2{lp[0], lp[1]};
+        } else {
+#pragma unroll
+            for (int g = 0; g < B_PER / 8; ++g) {
+                const int k = kr * B_PER + g * 8, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
+                *reinterpret_cast<u32x4*>(rowp + off) = u32x4{hp[4 * g], hp[4 * g + 1], hp[4 * g + 2], hp[4 * g + 3]};
+                *reinterpret_cast<u32x4*>(rowp + off + 32) = u32x4{mp[4 * g], mp[4 * g + 1], mp[4 * g + 2], mp[4 * g + 3]};
+                *reinterpret_cast<u32x4*>(rowp + off + 64) = u32x4{lp[4 * g], lp[4 * g + 1], lp[4 * g + 2], lp[4 * g + 3]};
+            }
+        }
+    };
+
+    if (nq > 0) {
+        load_next();
+        store_tiles(0);
+        if (nq > 1) load_next();
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    for (int q = 0; q < nq; ++q) {
+        const int cur = q & 1;
+        if (q + 1 < nq) store_tiles(cur ^ 1);
+        if (q + 2 < nq) load_next();
+        const unsigned char* Ab = As[cur] + (wm * (MI * 32) + l31) * ROW + lh * 16;
+        const unsigned char* Bb = Bs[cur] + (wn * (NI * 32) + l31) * ROW + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    a[i][c] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    b[j][c] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    if (p.ksplit > 1) {
+        float* sl = p.slab + (long long)blockIdx.z * p.Cout * W_P;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
+            if (opix >= W_P) continue;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (co < p.Cout) sl[(long long)co * W_P + opix] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
+        if (opix >= W_P) continue;
+        const int ob = opix / OHW;
+        const int orr = opix - ob * OHW, ooh = orr / w_own;
+        const int orp = ooh * p.OW + w_ow0 + (orr - ooh * w_own);
+        float* yb = p.y + (long long)ob * p.y_bs + orp;
+        const float* rbp = p.res ? p.res + (long long)ob * p.res_bs + orp : nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.scale) v *= p.scale[co];
+                if (p.shift) v += p.shift[co];
+                const long long off = (long long)co * OHOW;
+                if (rbp) v += rbp[off];
+                if (p.accumulate) v += yb[off];
+                if (p.relu) v = fmaxf(v, 0.f);
+                yb[off] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight layout for the split kernels: w[co][ci][tap] ->
+//   fwd  : [ (tap*Cin + ci) / 16 ][ co ][ piece ][ ci % 16 ]      (rows = co,  Cin  % 16 == 0)
+//   dgrad: [ (tap*Cout + co) / 16 ][ ci ][ piece ][ co % 16 ]     (rows = ci,  Cout % 16 == 0)
+// One thread converts 8 consecutive k of one row and writes three 16-byte runs.
+__global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ fwd,
+                                          unsigned char* __restrict__ dg, int Cout, int Cin, int T) {
+    // a block stages w[co0..co0+31][ci0..ci0+31][all taps] like prep_weights_tiled_kernel (T <= 9)
+    constexpr int LDT = 32 * 9 + 1;
+    __shared__ float tile[32 * LDT];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int nci = min(32, Cin - ci0), nco = min(32, Cout - co0);
+    const int run = nci * T;
+    for (int r = tid >> 5; r < nco; r += 8) {
+        const float* src = w + ((long long)(co0 + r) * Cin + ci0) * T;
+        for (int j = tid & 31; j < run; j += 32) tile[r * LDT + j] = src[j];
+    }
+    __syncthreads();
+    if (fwd) {
+        // items: (tap, g = 8-run of ci, co) with co fastest
+        const int ng = nci / 8, items = T * ng * nco;
+        for (int it = tid; it < items; it += blockDim.x) {
+            const int col = it % nco, rest = it / nco, g = rest % ng, tap = rest / ng;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                split3(tile[col * LDT + (g * 8 + 2 * e) * T + tap], tile[col * LDT + (g * 8 + 2 * e + 1) * T + tap],
+                       h[e], m[e], l[e]);
+            const int k = tap * Cin + ci0 + g * 8;
+            unsigned char* dst = fwd + ((long long)(k / 16) * Cout + co0 + col) * kSplitK16Bytes + (k % 16) * 2;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(dst + 32) = u32x4{m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    }
+    if (dg) {
+        const int ng = nco / 8, items = T * ng * nci;
+        for (int it = tid; it < items; it += blockDim.x) {
+            const int cil = it % nci, rest = it / nci, g = rest % ng, tap = rest / ng;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                split3(tile[(g * 8 + 2 * e) * LDT + cil * T + tap], tile[(g * 8 + 2 * e + 1) * LDT + cil * T + tap],
+                       h[e], m[e], l[e]);
+            const int k = tap * Cout + co0 + g * 8;
+            unsigned char* dst = dg + ((long long)(k / 16) * Cin + ci0 + cil) * kSplitK16Bytes + (k % 16) * 2;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<u32x4*>(dst + 32) = u32x4{m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+        }
+    }
+}

@@ -117,15 +117,29 @@ def conv_out_hw(H, W, k, stride, pad, dil):
 
 
 # ------------------------------------------------------------------------------------------ raw ops
+def set_option(name, value):
+    """wsdl_set_option + invalidation of every cached weight layout (options such as "conv_split" change what the
+    layout buffers hold)."""
+    check(lib().wsdl_set_option(name.encode(), int(value)))
+    bump_param_epoch()
+
+
+def _layout_buffer(w, dgrad):
+    import ctypes
+    Cout, Cin, kh, kw = w.shape
+    plain = ctypes.c_int(0)
+    nbytes = lib().wsdl_conv2d_weight_layout_bytes(Cout, Cin, kh, kw, int(dgrad), ctypes.byref(plain))
+    if plain.value and dgrad and kh * kw == 1:
+        return w.detach().reshape(Cout, Cin), False        # [tap*Cout+co][ci] of a 1x1 kernel IS w's own layout
+    return torch.empty(nbytes // 4, device=w.device, dtype=torch.float32), True
+
+
 def prep_weights(w, want_fwd=True, want_dgrad=True):
+    """Opaque layout buffers (wt_fwd, wt_dgrad) for conv2d_fwd / conv2d_dgrad (include/wsdl_hip.h)."""
     w = _dense(w, "weight")
     Cout, Cin, kh, kw = w.shape
-    wf = torch.empty(kh * kw * Cin, Cout, device=w.device, dtype=torch.float32) if want_fwd else None
-    if want_dgrad and kh * kw == 1:
-        wd, make_wd = w.detach().reshape(Cout, Cin), False     # [tap*Cout+co][ci] of a 1x1 kernel IS w's own layout
-    else:
-        wd = torch.empty(kh * kw * Cout, Cin, device=w.device, dtype=torch.float32) if want_dgrad else None
-        make_wd = want_dgrad
+    wf = _layout_buffer(w, False)[0] if want_fwd else None
+    wd, make_wd = _layout_buffer(w, True) if want_dgrad else (None, False)
     if want_fwd or make_wd:
         check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd if make_wd else None), Cout, Cin, kh, kw, _stream()))
     return wf, wd
