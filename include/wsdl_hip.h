@@ -56,7 +56,12 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (fo
        WSDL_PROF_WGRAD_128x128 = 8,    /* conv_wgrad_kernel<128,128,2> */
        WSDL_PROF_WGRAD_64x128 = 9,     /* conv_wgrad_kernel<64,128,1>  */
        WSDL_PROF_WGRAD_FAST_128x128 = 10,  /* conv_wgrad_fast_kernel<128,128,2> */
-       WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12, WSDL_PROF_NCLASSES = 13 };
+       WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12,
+       /* bf16x3-split kernels (six bf16 MFMAs per fp32 product; work counted in fp32-equivalent FLOPs) */
+       WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16,1> (forward + dgrad launches) */
+       WSDL_PROF_SPLIT_128x64 = 14, WSDL_PROF_SPLIT_64x256 = 15, WSDL_PROF_SPLIT_64x128 = 16,
+       WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128> */
+       WSDL_PROF_NCLASSES = 18 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,
@@ -64,7 +69,13 @@ int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* to
                       double* total_bytes /* algorithmic HBM bytes: every operand read once, result written once */);
 int wsdl_prof_reset(void);
 
-/* ---- convolution: implicit GEMM on v_mfma_f32_32x32x2_f32 -----------------------------------
+/* ---- convolution: implicit GEMM on the matrix cores -------------------------------------------
+ * Two arithmetic paths with the same fp32-level accuracy (tools/conv_accuracy.py, tests/test_hip_ops.py):
+ *   fp32 : v_mfma_f32_32x32x2_f32, exact fp32 fma chains;
+ *   split: every fp32 operand is split exactly into three bf16 pieces and a product is six
+ *          v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (dropped terms <= 2^-23 |a*b|);
+ *          used whenever the contracted channel count is a multiple of 16 and kh*kw <= 9
+ *          (wsdl_set_option("conv_split", 0) / ("wgrad_split", 0) select the fp32 kernels everywhere).
  * Replaces the ATen conv2d forward / input-gradient / weight-gradient reached from
  *   torchvision ResNet-50 and DeepLabV3 convs called at TraditionalModel/ClassificationModel.py:29-33,
  *   TraditionalModel/SegmentationModel.py:102,110, TraditionalModel/AlternatingDirectionCutLoss.py:697-703,

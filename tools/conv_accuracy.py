@@ -1,6 +1,6 @@
 """Accuracy of the two convolution arithmetic paths against an fp64 reference (GPU, through the C ABI).
 
-For a handful of DeepLabV3-R50 shapes: forward and input-gradient results of
+For a handful of DeepLabV3-R50 shapes: forward, input-gradient and weight-gradient results of
   * the fp32-MFMA kernels            (wsdl_set_option("conv_split", 0)), and
   * the bf16x3-split kernels         (conv_split = 1: six bf16 MFMAs per product, conv_split.h)
 are compared with torch's fp64 convolution on the same device.  Reported: max |err| / max |ref| and
@@ -49,15 +49,18 @@ def main():
         ref = F.conv2d(x.double(), w.double(), None, s, pad, d)
         dy = torch.randn_like(ref, dtype=torch.float32)
         ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad, d)
+        ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, pad, d)
         res = {}
         for mode in (0, 1):
             ops.set_option("conv_split", mode)
+            ops.set_option("wgrad_split", mode)
             wf, wd = ops.prep_weights(w)
             y = ops.conv2d_fwd(x, wf, w.shape, s, pad, d)
             dx = ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d)
-            res[mode] = (errs(y, ref), errs(dx, ref_dx))
+            dw = ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)
+            res[mode] = (errs(y, ref), errs(dx, ref_dx), errs(dw, ref_dw))
         name = f"{Cin}->{Cout} k{k} s{s} d{d} {H}x{H} B{B}"
-        for i, ps in enumerate(("fwd", "dgrad")):
+        for i, ps in enumerate(("fwd", "dgrad", "wgrad")):
             f32, sp = res[0][i], res[1][i]
             print(f"{name:34s} {ps:6s} {f32[0]:10.2e} {f32[1]:10.2e} {sp[0]:10.2e} {sp[1]:10.2e}")
             worst = max(worst, sp[1] / f32[1])

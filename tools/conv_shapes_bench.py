@@ -92,7 +92,7 @@ def main():
                   "dgrad": lambda: ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d),
                   "wgrad": lambda: ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)}
         for pname, fn in passes.items():
-            if args.only and pname != args.only:
+            if args.only and pname not in args.only.split(","):
                 continue
             if "fwd only" in name and pname != "fwd":
                 continue

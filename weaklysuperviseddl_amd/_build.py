@@ -34,7 +34,8 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     bdir = os.path.join(CSRC, "build")
     os.makedirs(bdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "wsdl_hip.h")]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "wsdl_hip.h"))
     jobs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

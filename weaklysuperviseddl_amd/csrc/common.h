@@ -58,6 +58,11 @@ constexpr int kReduceSlots = 4096;
 }  // namespace wsdl
 
 // ------------------------------------------------------------------ device helpers
+// Barrier for LDS hand-offs inside K loops.  __syncthreads() carries a workgroup-scope fence that is address-space
+// agnostic, so the compiler drains vmcnt(0) in front of every s_barrier: global loads issued for LATER chunks are
+// waited for at each barrier and a register prefetch ring degenerates to one exposed memory round trip per chunk.
+// An LDS hand-off only needs the DS queue drained.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

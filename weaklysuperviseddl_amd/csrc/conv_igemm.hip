@@ -544,8 +544,6 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
     }
 }
 
-#include "conv_split.h"
-
 // ---------------------------------------------------------------------------------------------
 struct WgradP {
     const float* x;
@@ -562,6 +560,8 @@ struct WgradP {
     int nb, splits;               // column bands inside one launch: blockIdx.z = band * splits + split
     int b_ow0[4], b_own[4], b_cps[4];   // per band: window and 32-pixel chunks per split
 };
+
+#include "conv_split.h"
 
 // Same pipeline as the forward kernel (LDS double buffer, one barrier per 32-pixel chunk).  When the
 // block's N tile lies inside one tap, pixel chunks for which that tap reads only padding are skipped
@@ -1128,7 +1128,7 @@ void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
 // bf16x3-split kernels (conv_split.h): which (rows, K-channels, taps) shapes use them.  A function of the
 // weight shape alone, so the layout kernel and the convolution agree on what the layout buffer holds.
 int g_conv_split = 1;
-int g_split_bk32 = 0;
+int g_split_bk32 = 1;    // K chunk 32 on the small-tile split configurations
 bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && (long long)T * kc * rows * 6 < (1ll << 31);
 }
@@ -1136,7 +1136,8 @@ bool split_eligible(int rows, int kc, int T) {
 template <int BM, int BN, int WM, int BK>
 void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
+    // register prefetch distance 1: distances 2 and 3 measured equal (profiles/r01_notes.md)
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, 1>), grid, dim3(kThreads), 0, s, p);
 }
 
 template <int BM, int BN, int WM>
@@ -1221,7 +1222,8 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         }
     }
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
-    wsdl::ProfScope prof(WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s, flops, executed, bytes);
+    wsdl::ProfScope prof(split ? WSDL_PROF_SPLIT_128x128 + cfg : WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1), s,
+                         flops, executed, bytes);
     {
         ConvP q = p;
         q.nb = nb;
@@ -1262,14 +1264,36 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
     *BN = *fast ? bn : 128;
 }
 
+int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
+int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
+// dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
+// Cin <= 512 are faster on the fp32 kernel)
+bool wgrad_chunk32(int Cout, int Cin, int N) {
+    return g_wgrad_split && Cout % 128 == 0 && Cin % 128 == 0 && N / 128 >= 6;
+}
+
 int wgrad_splits(int Cout, int Cin, int N, int P) {
     int BM, BN;
     bool fast;
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
     const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
-    long long s0 = (g_wgrad_blocks + tiles - 1) / tiles;
     const long long smax = std::max<long long>(1, std::min<long long>(256, chunks / 8));
+    if (g_wgrad_force_s > 0) return (int)std::min<long long>(g_wgrad_force_s, smax);
+    if (wgrad_chunk32(Cout, Cin, N)) {
+        // two workgroups per CU (one 53 KB LDS image each): fill whole rounds of 512 slots
+        const long long slots = 2 * kNumCU;
+        long long best_s = 1;
+        double best = -1.0;
+        for (long long c = 1; c <= smax && tiles * c <= 5 * slots / 2; ++c) {
+            const long long blocks = tiles * c, rounds = (blocks + slots - 1) / slots;
+            double eff = (double)blocks / (double)(rounds * slots);
+            if (blocks < slots) eff *= 0.9;      // a partly filled single round also loses the co-resident partner
+            if (eff > best + 0.03) { best = eff; best_s = c; }
+        }
+        return (int)best_s;
+    }
+    long long s0 = (g_wgrad_blocks + tiles - 1) / tiles;
     if (s0 > smax) s0 = smax;
     if (s0 < 1) s0 = 1;
     // among split counts near the target pick the one whose block count fills whole rounds of 256 CUs best
@@ -1283,6 +1307,7 @@ int wgrad_splits(int Cout, int Cin, int N, int P) {
     }
     return (int)s;
 }
+
 
 template <int BM, int BN, int WM>
 void launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
@@ -1302,6 +1327,8 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1409,6 +1436,13 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
     return ks > 1 ? (size_t)ks * M * P * sizeof(float) : 0;
 }
 
+// bytes of the pre-split dY image of the 32-pixel-chunk weight-gradient kernel (0: kernel not used)
+size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
+    if (!wgrad_chunk32(Cout, Cin, N)) return 0;
+    const size_t n = (size_t)wsdl::cdiv(P, 16) * Cout * kSplitK16Bytes;
+    return n < (1ull << 31) ? n : 0;
+}
+
 // column bands of a weight-gradient launch (fast kernel only): same rule as the forward kernel
 int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int pad, int dil, Band* bands) {
     int BM, BN;
@@ -1416,6 +1450,7 @@ int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int pad, i
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
     bands[0] = Band{0, OW};
     if (!fast || !g_col_bands || stride != 1) return 1;
+    if (wgrad_chunk32(Cout, Cin, kw * kw * Cin)) return 1;     // 32-pixel-chunk kernel: no bands
     return column_bands(OW, W, 1, dil, -pad, 1, kw, bands);
 }
 
@@ -1426,7 +1461,8 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     const int N = kh * kw * Cin;
     Band bands[8];
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
-    return (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
+    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
+    return wsdl::align_up(slabs, 256) + wgrad_dys_bytes(Cout, Cin, N, B * OH * OW);
 }
 
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
@@ -1466,14 +1502,19 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     {
         const double flops = 2.0 * p.P * (double)Cout * p.N;
         double executed = flops;
+        const size_t dys_bytes = fast ? wgrad_dys_bytes(Cout, Cin, p.N, p.P) : 0;
+        const size_t dys_off = wsdl::align_up(need, 256);
+        const bool chunk32 = dys_bytes && ws_bytes >= dys_off + dys_bytes;
         if (wsdl::prof_enabled() && fast) {   // tiles inside one tap: all-padding pixel chunks are skipped
             executed = 0.0;
             for (int i = 0; i < nb; ++i)
                 executed += flops * ((double)bands[i].own / OW) *
                             wgrad_executed_fraction(B * OH * bands[i].own, OH, bands[i].ow0, bands[i].own, H, W, kh, kw,
-                                                    stride, pad, dil, g_wgrad_bk == 32 ? 32 : 16);
+                                                    stride, pad, dil, (chunk32 || g_wgrad_bk == 32) ? 32 : 16);
         }
-        wsdl::ProfScope prof(fast ? WSDL_PROF_WGRAD_FAST_128x128 : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
+        wsdl::ProfScope prof(chunk32 ? WSDL_PROF_WGRAD_SPLIT32
+                                     : fast ? WSDL_PROF_WGRAD_FAST_128x128
+                                            : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
                              s, flops, executed,
                              4.0 * ((double)B * Cin * H * W + (double)p.P * Cout + (double)S_total * Cout * p.N));
         constexpr size_t lds64 = 2 * (64 + 128) * 33 * sizeof(float), lds128 = 2 * (128 + 128) * 33 * sizeof(float);
@@ -1495,7 +1536,15 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             p.dy_bytes = (unsigned)dyb;
             // 16-pixel chunks (35 KB of LDS, 4 workgroups per CU) beat 32-pixel chunks (68 KB, 2 per CU) on all but two
             // ASPP shapes (profiles/r01_notes.md)
-            if (tBM == 128 && tBN == 128 && g_wgrad_bk == 32) {
+            if (chunk32) {
+                unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
+                const long long total = (long long)wsdl::cdiv(p.P, 16) * Cout;
+                hipLaunchKernelGGL(dy_split_kernel, dim3((int)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0,
+                                   s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P);
+                dim3 grid(p.N / 128, Cout / 128, S);
+                hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
+                                   (unsigned)dys_bytes);
+            } else if (tBM == 128 && tBN == 128 && g_wgrad_bk == 32) {
                 dim3 grid(p.N / 128, Cout / 128, S);
                 hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 32>), grid, dim3(kThreads), lds128, s, p);
             } else {

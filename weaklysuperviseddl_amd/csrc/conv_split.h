@@ -17,6 +17,7 @@
 // is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots
 // of the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
 #pragma once
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -35,7 +36,17 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 
 constexpr int kSplitK16Bytes = 96;   // one row's 16 k values: 3 pieces x 16 bf16
 
-template <int BM, int BN, int WM, int BK>
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// PD = chunks of global loads kept in flight in registers (prefetch distance): one K-chunk of MFMAs is ~770 cycles,
+// a fraction of the L2 / fabric latency, so one chunk in flight leaves the kernel latency-bound.
+template <int BM, int BN, int WM, int BK, int PD>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) {
     constexpr int WN = 4 / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -146,8 +157,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[A_U];
-    unsigned rb[B_PER];
+    u32x4 ra[PD][A_U];
+    unsigned rb[PD][B_PER];
     int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
     unsigned voff_b = kOOB;
     auto set_tap = [&](int vi) {
@@ -158,7 +169,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
     };
     if (nq > 0) set_tap(ld_vi);
 
-    auto load_next = [&]() {
+    auto load_next = [&](auto stage) {
+        constexpr int S = decltype(stage)::value;
         if (ld_c == cpt) {
             ld_c = 0;
             ++ld_vi;
@@ -167,22 +179,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
         const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
         const unsigned soff_a = (unsigned)(c16 * p.Cout * kSplitK16Bytes);
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+        for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
         const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
-            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
+            rb[S][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
         ++ld_c;
     };
     // this thread's k run [kr*B_PER, kr*B_PER + B_PER) inside the chunk -> (k-step, offset inside the 16)
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto stage) {
+        constexpr int S = decltype(stage)::value;
 #pragma unroll
         for (int e = 0; e < A_U; ++e)
-            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
+            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[S][e];
         unsigned hp[B_PER / 2], mp[B_PER / 2], lp[B_PER / 2];
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e)
-            split3(__builtin_bit_cast(float, rb[2 * e]), __builtin_bit_cast(float, rb[2 * e + 1]), hp[e], mp[e], lp[e]);
+            split3(__builtin_bit_cast(float, rb[S][2 * e]), __builtin_bit_cast(float, rb[S][2 * e + 1]), hp[e], mp[e], lp[e]);
         unsigned char* rowp = &Bs[buf][pl * ROW];
         if constexpr (B_PER == 4) {
             const int k = kr * 4, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
@@ -200,17 +213,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
         }
     };
 
+    // stage s of the register ring holds chunk 1 + s (mod PD); chunk 0 goes straight to LDS
     if (nq > 0) {
-        load_next();
-        store_tiles(0);
-        if (nq > 1) load_next();
+        load_next(std::integral_constant<int, 0>{});
+        store_tiles(0, std::integral_constant<int, 0>{});
+        static_for<PD>([&](auto s) {
+            if (1 + decltype(s)::value < nq) load_next(s);
+        });
     }
     __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
-    for (int q = 0; q < nq; ++q) {
-        const int cur = q & 1;
-        if (q + 1 < nq) store_tiles(cur ^ 1);
-        if (q + 2 < nq) load_next();
+    auto mfma_chunk = [&](int cur) {
         const unsigned char* Ab = As[cur] + (wm * (MI * 32) + l31) * ROW + lh * 16;
         const unsigned char* Bb = Bs[cur] + (wn * (NI * 32) + l31) * ROW + lh * 16;
 #pragma unroll
@@ -239,7 +252,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
+    };
+    for (int q = 0; q < nq; q += PD) {
+        static_for<PD>([&](auto s) {
+            const int qq = q + decltype(s)::value;
+            if (qq < nq) {                                   // block-uniform
+                const int cur = qq & 1;
+                if (qq + 1 < nq) store_tiles(cur ^ 1, s);    // stage s holds chunk qq + 1
+                if (qq + 1 + PD < nq) load_next(s);
+                mfma_chunk(cur);
+                lds_barrier();
+            }
+        });
     }
 
     if (p.ksplit > 1) {
@@ -337,5 +361,238 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
             *reinterpret_cast<u32x4*>(dst + 32) = u32x4{m[0], m[1], m[2], m[3]};
             *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix core: D[cout][n] = sum_pixel dY[cout][pixel] * Xg[n][pixel], 32-pixel chunks
+// (Cout % 128 == 0, Cin % 128 == 0, at least 6 N tiles; everything else stays on the fp32 kernels of conv_igemm.hip).
+//
+// A first version kept conv_wgrad_fast_kernel's 16-pixel chunks and split both operands in the kernel: no faster than
+// fp32.  What bounds it is the vector-memory pipe, not the matrix core: a 16-pixel chunk reads 64-byte half lines
+// (the other half is fetched again by the next chunk after the 32 KiB L1 has turned over), and both operands pay the
+// VALU split.  Here
+//   * a chunk is 32 consecutive pixels = one full 128-byte line per row, read by 32 adjacent lanes;
+//   * dY is split ONCE per launch by dy_split_kernel into the k16-major layout the forward kernel uses for its
+//     weights ([pixel/16][cout][h|m|l][16] bf16): every N tile of the launch (36 for a 3x3 on 512 channels)
+//     re-reads it with 16-byte loads and no arithmetic;
+//   * x is split in the kernel.  A lane holds ONE pixel of a row, the packed converts want a pixel PAIR per
+//     lane: lanes swap one value with their neighbour (DPP quad_perm) so that even lanes own the pair of one
+//     row and odd lanes the pair of the row below - 4 VALU ops per pair instead of a second, half-used load.
+__global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __restrict__ out, int B, int Cout,
+                                int OHOW, long long dy_bs, int P) {
+    // one thread: 16 consecutive pixels (linear index over b, oh, ow) of one channel
+    const int groups = (P + 15) / 16;
+    const long long total = (long long)groups * Cout;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(idx % groups), c = (int)(idx / groups);
+        float v[16];
+        const int p0 = g * 16;
+        if (OHOW % 16 == 0) {
+            const int b = p0 / OHOW, r = p0 - b * OHOW;
+            const float4* src = reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * OHOW + r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 q = src[e];
+                v[4 * e] = q.x; v[4 * e + 1] = q.y; v[4 * e + 2] = q.z; v[4 * e + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pix = p0 + e;
+                float t = 0.f;
+                if (pix < P) {
+                    const int b = pix / OHOW, r = pix - b * OHOW;
+                    t = dy[(long long)b * dy_bs + (long long)c * OHOW + r];
+                }
+                v[e] = t;
+            }
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) split3(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
+        u32x4* dst = reinterpret_cast<u32x4*>(out + ((long long)g * Cout + c) * kSplitK16Bytes);
+        dst[0] = u32x4{h[0], h[1], h[2], h[3]};
+        dst[1] = u32x4{h[4], h[5], h[6], h[7]};
+        dst[2] = u32x4{m[0], m[1], m[2], m[3]};
+        dst[3] = u32x4{m[4], m[5], m[6], m[7]};
+        dst[4] = u32x4{l[0], l[1], l[2], l[3]};
+        dst[5] = u32x4{l[4], l[5], l[6], l[7]};
+    }
+}
+
+constexpr int kW2Row = 2 * kSplitK16Bytes + 16;     // 208-byte LDS rows: 32 pixels x 3 pieces + padding
+
+// 256 threads, 64x64 wave tiles (12 operand reads per 24 MFMAs), ONE LDS image per workgroup (53 KB) and two
+// barriers per chunk, so two workgroups share a CU: while one converts / stores its next chunk, the other one's MFMAs
+// use the matrix cores.  The two rows of a lane pair are neighbours (208-byte stride: disjoint banks).
+// Variants measured and dropped (profiles/r01_notes.md): 512 threads with a double-buffered image (both waves of a
+// SIMD sit in the same phase), producer / consumer waves with a 3-deep register ring (the pure consumer loop - one
+// wave per SIMD, operand reads exposed after every barrier - already runs at half the MFMA rate).
+template <int BM, int BN>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP p, const unsigned char* __restrict__ dys,
+                                                                        unsigned dys_bytes) {
+    static_assert(BM == 128 && BN == 128, "tile");
+    constexpr int BK = 32, ROW = kW2Row;
+    constexpr int WN = 2, MI = 2, NI = 2;
+    constexpr int A_U = 2 * BM * 6 / kThreads;             // 6 16-byte units per thread per chunk
+    constexpr int B_PER = BN / 8;                          // 16 rows per thread: 8 half-waves x 32 pixels per pass
+    constexpr unsigned kOOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int zsplit = blockIdx.z, w_cps = p.chunks_per_split;
+    const int W_P = p.P;
+    const int OHOW = p.OH * p.OW, HW = p.H * p.W;
+    const int px = tid & 31, hw = tid >> 5;
+
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(dys), 0, (int)dys_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+
+    const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
+    const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
+    // this thread's x rows: 2*hw + (e & 1) + 16*(e >> 1): the two rows of a pair are neighbours
+    const unsigned b_row = (unsigned)((ci0 + 2 * hw) * HW);
+
+    unsigned voff_a[A_U], lds_a[A_U];
+#pragma unroll
+    for (int e = 0; e < A_U; ++e) {
+        const int u = tid + e * kThreads;
+        const int ks = u / (BM * 6), v = u - ks * (BM * 6);
+        const int row = v / 6, part = v - row * 6;
+        voff_a[e] = (unsigned)(ks * p.Cout * kSplitK16Bytes + (m0 * 6 + v) * 16);
+        lds_a[e] = (unsigned)(row * ROW + ks * kSplitK16Bytes + part * 16);
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[A_U];
+    unsigned rb[B_PER];
+    const int chunk_begin = zsplit * w_cps;
+    const int total_chunks = (W_P + BK - 1) / BK;
+    const int chunk_end = min(chunk_begin + w_cps, total_chunks);
+
+    const bool row_chunks = (p.OW % BK) == 0;
+    unsigned nvb = kOOB;
+    auto decode = [&](int c) {
+        nvb = kOOB;
+        if (row_chunks) {
+            const int first = c * BK;
+            const int grow = first / p.OW, ow = first - grow * p.OW + px;
+            const int pb = grow / p.OH, oh = grow - pb * p.OH;
+            const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                nvb = ((unsigned)((long long)pb * p.x_bs) + (unsigned)(ih * p.W) + (unsigned)iw + b_row) * 4u;
+            return;
+        }
+        const int pix = c * BK + px;
+        if (pix < W_P) {
+            const int pb = pix / OHOW, rr = pix - pb * OHOW;
+            const int oh = rr / p.OW, ow = rr - oh * p.OW;
+            const int ih = oh * p.stride + t_dh, iw = ow * p.stride + t_dw;
+            if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W)
+                nvb = ((unsigned)((long long)pb * p.x_bs) + (unsigned)(ih * p.W + iw) + b_row) * 4u;
+        }
+    };
+    auto next_valid = [&](int c) {
+        for (; c < chunk_end; ++c) {
+            decode(c);
+            if (__any(nvb != kOOB)) break;
+        }
+        return c;
+    };
+    auto load_tiles = [&](int c) {
+        const unsigned soff_a = (unsigned)(2 * c) * (unsigned)(p.Cout * kSplitK16Bytes);
+#pragma unroll
+        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+#pragma unroll
+        for (int e = 0; e < B_PER; ++e)
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
+    };
+    const bool even = (px & 1) == 0;
+    const int pair = px >> 1;
+    const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * kSplitK16Bytes + (pair & 7) * 4);
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + lds_a[e]) = ra[e];
+#pragma unroll
+        for (int i = 0; i < B_PER / 2; ++i) {
+            const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];
+            const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);
+            const unsigned x0 = even ? rb[2 * i] : recv;
+            const unsigned x1 = even ? recv : rb[2 * i + 1];
+            unsigned h, m, l;
+            split3(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), h, m, l);
+            unsigned char* d = Bs + st_b + i * 16 * ROW;
+            *reinterpret_cast<unsigned*>(d) = h;
+            *reinterpret_cast<unsigned*>(d + 32) = m;
+            *reinterpret_cast<unsigned*>(d + 64) = l;
+        }
+    };
+
+    const int l31 = lane & 31, lh = lane >> 5;
+    const unsigned char* Ab = As + (wm * 64 + l31) * ROW + lh * 16;
+    const unsigned char* Bb = Bs + (wn * 64 + l31) * ROW + lh * 16;
+    int c0 = next_valid(chunk_begin);
+    if (c0 < chunk_end) load_tiles(c0);
+    while (c0 < chunk_end) {
+        store_tiles();                                   // chunk c0: registers -> bf16 pieces -> LDS
+        const int c1 = next_valid(c0 + 1);
+        if (c1 < chunk_end) load_tiles(c1);              // in flight during this chunk's MFMAs
+        lds_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    a[i][c] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    b[j][c] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        lds_barrier();
+        c0 = c1;
+    }
+
+    float* slab = p.slab + (long long)(p.slab0 + blockIdx.z) * p.Cout * p.N;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                slab[(long long)co * p.N + n] = acc[i][j][r];
+            }
     }
 }

@@ -785,7 +785,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 13
+PROF_NCLASSES = 18
 
 
 def prof_class_name(cls):
