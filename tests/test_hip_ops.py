@@ -48,11 +48,28 @@ CONV_CASES = [
     (8, 1024, 14, 14, 2048, 1, 1, 0, 1),   # CAM path layer4.0 downsample
     (3, 64, 32, 32, 128, 3, 1, 12, 12),    # ASPP-like on a 32x32 map: column bands [0,12) [12,20) [20,32)
     (2, 128, 32, 40, 128, 3, 1, 24, 24),   # dilation 24, non-square map: bands [0,16) [16,24) [24,40)
+    (2, 128, 32, 32, 256, 3, 1, 1, 1),     # split weight gradient: 9 N tiles, 32-pixel chunks = whole rows
+    (3, 128, 9, 11, 256, 3, 1, 2, 2),      # same kernel, chunks straddling rows / images, ragged last chunk
+    (2, 256, 16, 16, 128, 3, 2, 1, 1),     # same kernel, stride 2
+    (2, 1024, 8, 8, 128, 1, 1, 0, 1),      # same kernel, 1x1 with 8 N tiles
 ]
 
 
+@pytest.fixture(params=["split", "fp32"])
+def arithmetic(request):
+    """Both convolution arithmetic paths: the bf16x3-split kernels (default where the shape allows) and the fp32-MFMA
+    kernels (wsdl_set_option conv_split / wgrad_split = 0)."""
+    from weaklysuperviseddl_amd import ops
+    on = int(request.param == "split")
+    ops.set_option("conv_split", on)
+    ops.set_option("wgrad_split", on)
+    yield request.param
+    ops.set_option("conv_split", 1)
+    ops.set_option("wgrad_split", 1)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(dev, case):
+def test_conv_fwd_dgrad_wgrad(dev, case, arithmetic):
     from weaklysuperviseddl_amd import ops
     B, Cin, H, W, Cout, k, s, p, d = case
     g = torch.Generator().manual_seed(sum(case))
@@ -76,6 +93,52 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     assert_close(dx2, 2 * xr.grad, what="dgrad accumulate")
     dw2 = ops.conv2d_wgrad(xd, dyd, w.shape, s, p, d, out=dw.clone(), accumulate=True)
     assert_close(dw2, 2 * wr.grad, what="wgrad accumulate")
+
+
+def test_split_arithmetic_is_fp32_accurate(dev):
+    """The bf16x3-split kernels claim fp32-level accuracy: against a float64 convolution their error must not exceed
+    the fp32-MFMA kernels' (exact fp32 fma chains) by more than a small factor, in every pass."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(77)
+    errs = {}
+    for Cin, Cout, k, s, d, H, B in [(256, 256, 3, 1, 2, 32, 2), (1024, 256, 1, 1, 1, 16, 4), (128, 128, 3, 2, 1, 32, 2)]:
+        pad = (k // 2) * d if k > 1 else 0
+        x = torch.randn(B, Cin, H, H, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+        ref = F.conv2d(x.double(), w.double(), None, s, pad, d)
+        dy = torch.randn(ref.shape, generator=g).to(dev)
+        ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad, d)
+        ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, pad, d)
+        for mode in (0, 1):
+            ops.set_option("conv_split", mode)
+            ops.set_option("wgrad_split", mode)
+            wf, wdg = ops.prep_weights(w)
+            outs = (ops.conv2d_fwd(x, wf, w.shape, s, pad, d), ops.conv2d_dgrad(dy, wdg, w.shape, x.shape, s, pad, d),
+                    ops.conv2d_wgrad(x, dy, w.shape, s, pad, d))
+            for name, o, r in zip(("fwd", "dgrad", "wgrad"), outs, (ref, ref_dx, ref_dw)):
+                rms = ((o.double() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()).item()
+                errs[(Cin, k, name, mode)] = rms
+    for (Cin, k, name, mode), e in errs.items():
+        assert e < 5e-6, (Cin, k, name, mode, e)
+        if mode == 1:
+            assert e < 3.0 * errs[(Cin, k, name, 0)] + 1e-8, (Cin, k, name, e, errs[(Cin, k, name, 0)])
+
+
+def test_weight_layout_sizes(dev):
+    """The opaque layout buffers: 4 bytes per weight (fp32 k-major) or 6 (three bf16 pieces), by shape and option."""
+    import ctypes
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd._lib import lib
+    plain = ctypes.c_int(-1)
+    n = 64 * 32 * 9
+    assert lib().wsdl_conv2d_weight_layout_bytes(64, 32, 3, 3, 0, ctypes.byref(plain)) == n * 6 and plain.value == 0
+    assert lib().wsdl_conv2d_weight_layout_bytes(64, 3, 7, 7, 0, ctypes.byref(plain)) == 64 * 3 * 49 * 4 and plain.value == 1
+    assert lib().wsdl_conv2d_weight_layout_bytes(2, 256, 1, 1, 1, ctypes.byref(plain)) == 2 * 256 * 4 and plain.value == 1
+    ops.set_option("conv_split", 0)
+    try:
+        assert lib().wsdl_conv2d_weight_layout_bytes(64, 32, 3, 3, 0, ctypes.byref(plain)) == n * 4 and plain.value == 1
+    finally:
+        ops.set_option("conv_split", 1)
 
 
 def test_conv_epilogue_scale_shift_residual_relu(dev):

@@ -1,0 +1,41 @@
+#!/bin/bash
+# Regenerates everything under profiles/ that depends on the kernels (run on the GPU box: gpurun -- tools/refresh_profiles.sh).
+# Output lands in gpurun_out/refresh/; copy what is to be judged into profiles/.
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/refresh
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+step() { echo "[refresh] $*" >&2; }
+
+step "bench (full: roofline + cam + cpu baseline)"
+python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
+
+step "rocprofv3 kernel stats, default (overlapped) run"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_default -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline > $O/bench_under_rocprof.txt 2>&1 || exit 1
+cp $(ls $O/kt_default/*/*kernel_stats.csv | head -1) $O/bench_n1_kernel_stats.csv
+
+step "rocprofv3 kernel stats, serial run"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_serial -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --serial > $O/bench_serial_under_rocprof.txt 2>&1 || exit 1
+cp $(ls $O/kt_serial/*/*kernel_stats.csv | head -1) $O/bench_n1_serial_kernel_stats.csv
+
+step "PMC calibration + traffic passes"
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/cal_f -- python3 $R/tools/pmc_calibrate.py > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/cal_w -- python3 $R/tools/pmc_calibrate.py > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/b_f -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/b_w -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 > /dev/null 2>&1 || exit 1
+python3 $R/tools/pmc_summarise.py $O/cal_f $O/cal_w $O/b_f $O/b_w $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || exit 1
+
+step "PMC: MFMA busy cycles of the whole step"
+rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/b_m -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 --serial > /dev/null 2>&1 || exit 1
+python3 $R/tools/pmc_table.py $O/b_m > $O/pmc_mfma_busy.txt 2>&1
+
+step "per-shape conv table"
+python3 $R/tools/conv_shapes_bench.py > $O/conv_shapes.txt 2>&1 || exit 1
+python3 $R/tools/conv_shapes_bench.py --opt conv_split=0,wgrad_split=0 > $O/conv_shapes_fp32.txt 2>&1 || exit 1
+python3 $R/tools/conv_accuracy.py > $O/conv_accuracy.txt 2>&1 || exit 1
+
+step "loss / CAM kernels, other configs"
+python3 $R/tools/loss_cam_bench.py > $O/loss_cam_kernels.txt 2>&1 || exit 1
+python3 $R/tools/configs_bench.py > $O/other_configs.txt 2>&1 || exit 1
+step done
