@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--pass", dest="which", default="fwd")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--opt", default="")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands (power / clock experiment)")
     a = ap.parse_args()
     for kv in [x for x in a.opt.split(",") if x]:
         k, v = kv.split("=")
@@ -31,6 +32,9 @@ def main():
     wf, wd = ops.prep_weights(w)
     OH, OW = ops.conv_out_hw(H, H, k, s, pad, d)
     dy = torch.randn(B, Cout, OH, OW, device=dev)
+    if a.zeros:
+        x.zero_(); w.zero_(); dy.zero_()
+        wf, wd = ops.prep_weights(w)
     for _ in range(a.reps):
         if a.which == "fwd":
             ops.conv2d_fwd(x, wf, w.shape, s, pad, d)

@@ -104,7 +104,7 @@ class Linear(nn.Module):
         return ops.linear(x, self.weight, self.bias)
 
 
-def conv_bn(x, conv, bn, relu, residual=None):
+def conv_bn(x, conv, bn, relu, residual=None, passthrough=False):
     """conv -> bn (batch stats when bn.training, folded running stats otherwise) -> +residual -> relu."""
     if conv.bias is not None:
         raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
@@ -112,7 +112,8 @@ def conv_bn(x, conv, bn, relu, residual=None):
         bn._pending_steps += 1      # momentum is fixed, so the counter never feeds the arithmetic
     cache = conv.__dict__.setdefault("_wsdl_cache", {})         # derived tensors, keyed on versions / epochs
     return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
-                           conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache)
+                           conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache,
+                           passthrough)
 
 
 class FusedSequential(nn.Sequential):
@@ -148,8 +149,12 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        idt = x if self.downsample is None else self.downsample(x)
-        y = conv_bn(x, self.conv1, self.bn1, True)
+        if self.downsample is None:
+            # x feeds conv1 AND the identity branch: route the identity through conv1's node (see ops.conv_bn_act)
+            y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True)
+        else:
+            idt = self.downsample(x)
+            y = conv_bn(x, self.conv1, self.bn1, True)
         y = conv_bn(y, self.conv2, self.bn2, True)
         return conv_bn(y, self.conv3, self.bn3, True, residual=idt)   # relu(bn3(conv3) + identity)
 

@@ -323,7 +323,9 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil, relu,
-                momentum, eps, cache=None):
+                momentum, eps, cache=None, passthrough=False):
+        # passthrough: also hand x back as a second output (the identity branch of a bottleneck).  The gradient that
+        # arrives for it is then added inside the dgrad kernel's epilogue instead of by a separate autograd add.
         wf, wd = _cached_prep(cache, weight, x.requires_grad)
         conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil)
         y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
@@ -331,10 +333,12 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
         ctx.save_for_backward(x, conv, y if relu else None, gamma, mean, invstd, wd)
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dxres=None):
         x, conv, y, gamma, mean, invstd, wd = ctx.saved_tensors
         stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
         pw, pg, pb = ctx.params
@@ -360,9 +364,17 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if wd is None:
                 raise WsdlError("conv backward: dgrad weights were not prepared")
-            dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil)
+            into = None
+            if (dxres is not None and tuple(dxres.shape) == tuple(xshape) and dxres.is_contiguous()
+                    and dxres.dtype == torch.float32):
+                into = dxres        # the identity branch's gradient (a fresh BN-backward output): dx = dgrad(...) + it
+            dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into)
+            if into is None and dxres is not None:
+                dx = dx + dxres
+        elif dxres is not None:
+            dx = dxres
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                dres, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None)
 
 
 class _ConvAffineAct(torch.autograd.Function):
@@ -609,11 +621,13 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ functional API
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
-                momentum=0.1, eps=1e-5, training=True, cache=None):
+                momentum=0.1, eps=1e-5, training=True, cache=None, passthrough=False):
+    """passthrough=True returns (y, x'): x' is x routed through this node, to be used as the identity branch so that
+    its gradient is summed in the dgrad epilogue (train mode; eval mode returns x itself)."""
     if training:
         bump_stats_epoch()          # running statistics are about to be rewritten behind torch's back
         return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
-                                bool(relu), momentum, eps, cache)
+                                bool(relu), momentum, eps, cache, bool(passthrough))
     key = _cache_key(gamma, beta, running_mean, running_var) if cache is not None else None
     if cache is not None and cache.get("fold_key") == key:
         scale, shift = cache["fold"]
@@ -621,7 +635,8 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, 
         scale, shift = bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         if cache is not None:
             cache["fold_key"], cache["fold"] = key, (scale, shift)
-    return _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False, cache)
+    y = _ConvAffineAct.apply(x, weight, scale, shift, residual, stride, pad, dil, bool(relu), False, cache)
+    return (y, x) if passthrough else y
 
 
 def conv_bias_act(x, weight, bias=None, stride=1, pad=0, dil=1, relu=False, residual=None, cache=None):
