@@ -52,7 +52,14 @@ class ASPP(nn.Module):
         self.project = wnn.FusedSequential(*_cbr(len(branches) * cout, cout, 1), wnn.Dropout(0.5))
 
     def forward(self, x):
-        return self.project(ops.concat_channels([b(x) for b in self.convs]))
+        # x feeds five branches: chain it through the four conv nodes (ops.conv_bn_act passthrough) so that the five
+        # input gradients are summed inside the dgrad epilogues instead of by four 134 MB autograd adds
+        outs = []
+        for b in list(self.convs)[:-1]:
+            y, x = wnn.conv_bn(x, b[0], b[1], True, passthrough=True)
+            outs.append(y)
+        outs.append(self.convs[-1](x))
+        return self.project(ops.concat_channels(outs))
 
 
 class _Backbone(nn.Module):

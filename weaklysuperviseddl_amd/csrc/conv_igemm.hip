@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdint>
 #include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -913,6 +914,34 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
+// T == 1 (1x1 kernels: slab layout == dw layout): 16 bytes per thread, four slabs in flight per step.  The sum
+// order is fixed (pairs of pairs), so the result stays bitwise reproducible.
+__global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int S,
+                                         long long total4, int accumulate) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total4;
+         idx += (long long)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = 0;
+        for (; z + 4 <= S; z += 4) {
+            const float4 a = slab[(long long)z * total4 + idx], b = slab[(long long)(z + 1) * total4 + idx];
+            const float4 c = slab[(long long)(z + 2) * total4 + idx], d = slab[(long long)(z + 3) * total4 + idx];
+            s.x += (a.x + b.x) + (c.x + d.x);
+            s.y += (a.y + b.y) + (c.y + d.y);
+            s.z += (a.z + b.z) + (c.z + d.z);
+            s.w += (a.w + b.w) + (c.w + d.w);
+        }
+        for (; z < S; ++z) {
+            const float4 a = slab[(long long)z * total4 + idx];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        if (accumulate) {
+            const float4 o = dw[idx];
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        dw[idx] = s;
+    }
+}
+
 // Same sum for 2 <= T <= 16 with both sides coalesced: a block owns (co, 32 input channels); each tap's 32
 // slab values are read as one 128-byte run, the (ci,tap) transpose happens in LDS, and the 32*T results leave
 // as one contiguous run of dw.  blockDim = (32, 8); blockIdx = (Cin/32 tiles, Cout).
@@ -927,7 +956,11 @@ __global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float*
         float s = 0.f;
         if (ci0 + lane < Cin) {
             const long long idx = (long long)co * N + (long long)tap * Cin + ci0 + lane;
-            for (int z = 0; z < S; ++z) s += slab[(long long)z * total + idx];
+            int z = 0;
+            for (; z + 4 <= S; z += 4)      // four slabs in flight; fixed (pairs of pairs) order
+                s += (slab[(long long)z * total + idx] + slab[(long long)(z + 1) * total + idx]) +
+                     (slab[(long long)(z + 2) * total + idx] + slab[(long long)(z + 3) * total + idx]);
+            for (; z < S; ++z) s += slab[(long long)z * total + idx];
         }
         tile[lane * T + tap] = s;
     }
@@ -1575,6 +1608,10 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     if (T >= 2 && T <= 16 && Cout <= 65535) {
         hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw,
                            S_total, Cout, Cin, T, accumulate);
+    } else if (T == 1 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
+        const long long total4 = total / 4;
+        hipLaunchKernelGGL(wgrad_reduce_vec4_kernel, dim3((int)std::min<long long>((total4 + 255) / 256, 8192)), dim3(256), 0, s,
+                           reinterpret_cast<const float4*>(p.slab), reinterpret_cast<float4*>(dw), S_total, total4, accumulate);
     } else {
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate);

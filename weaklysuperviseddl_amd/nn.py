@@ -149,12 +149,11 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        if self.downsample is None:
-            # x feeds conv1 AND the identity branch: route the identity through conv1's node (see ops.conv_bn_act)
-            y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True)
-        else:
-            idt = self.downsample(x)
-            y = conv_bn(x, self.conv1, self.bn1, True)
+        # x feeds conv1 AND the identity / downsample branch: route the second use through conv1's node (see
+        # ops.conv_bn_act) so that the two input gradients are summed in conv1's dgrad epilogue
+        y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True)
+        if self.downsample is not None:
+            idt = self.downsample(idt)
         y = conv_bn(y, self.conv2, self.bn2, True)
         return conv_bn(y, self.conv3, self.bn3, True, residual=idt)   # relu(bn3(conv3) + identity)
 
