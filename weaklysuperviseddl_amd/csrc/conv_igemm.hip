@@ -1176,16 +1176,23 @@ void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
 template <int BM, int BN, int WM>
 void launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
+    constexpr bool kSmallTile = BM * BN <= 128 * 64;      // K chunks of 32 only where registers / LDS allow them
     if (split) {
-        if (g_split_bk32 && BM * BN <= 128 * 64 && p.Cin % 32 == 0)
-            launch_split<BM, BN, WM, 32>(p, s, grid);
-        else
-            launch_split<BM, BN, WM, 16>(p, s, grid);
+        if constexpr (kSmallTile) {
+            if (g_split_bk32 && p.Cin % 32 == 0) {
+                launch_split<BM, BN, WM, 32>(p, s, grid);
+                return;
+            }
+        }
+        launch_split<BM, BN, WM, 16>(p, s, grid);
     } else if (aligned) {
-        if (BM * BN <= 128 * 64 && g_bk32 && p.Cin % 32 == 0)
-            launch_fast<BM, BN, WM, 32>(p, s, grid);
-        else
-            launch_fast<BM, BN, WM, 16>(p, s, grid);
+        if constexpr (kSmallTile) {
+            if (g_bk32 && p.Cin % 32 == 0) {
+                launch_fast<BM, BN, WM, 32>(p, s, grid);
+                return;
+            }
+        }
+        launch_fast<BM, BN, WM, 16>(p, s, grid);
     } else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, false>), grid, dim3(kThreads), 0, s, p);
 }

@@ -20,7 +20,7 @@ static int stat_splits(int C, int HW) {
     return s;
 }
 
-// ws layout for BN: double part[C][kStatSplit][2] ; float coef[C][2]
+// ws layout for BN: double part[C][kStatSplit][2]
 __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                 const float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ part, int B, int C,
@@ -83,37 +83,37 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ save_mean,
-                                       float* __restrict__ save_invstd, float* __restrict__ rmean,
-                                       float* __restrict__ rvar, float momentum, float eps, long long n,
-                                       int C, int nsplit) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// y = act((x-mean)*invstd*gamma + beta + res); one block row per (b,c) plane.  The channel statistics are finished
+// here from the partial sums (a handful of doubles per plane, block-uniform) instead of by a separate 5-us launch;
+// the block that owns (b = 0, first column chunk) of a channel publishes save_mean / save_invstd and updates the
+// running statistics.
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const double* __restrict__ part,
+                                float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                long long n, int nsplit, const float* __restrict__ res,
+                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int b = plane / C, c = plane - b * C;
     double s0 = 0.0, s1 = 0.0;
     for (int s = 0; s < nsplit; ++s) {
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
         s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
     }
-    const double mean = s0 / (double)n;
-    double var = s1 / (double)n - mean * mean;
+    const double mean_d = s0 / (double)n;
+    double var = s1 / (double)n - mean_d * mean_d;
     if (var < 0.0) var = 0.0;
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) {
-        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    const float mu = (float)mean_d, istd = (float)(1.0 / sqrt(var + (double)eps));
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        save_mean[c] = mu;
+        save_invstd[c] = istd;
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        if (rvar) {
+            const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
     }
-}
-
-// y = act((x-mean)*invstd*gamma + beta + res); one block row per (b,c) plane
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ mean,
-                                const float* __restrict__ invstd, const float* __restrict__ res,
-                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes) {
-  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
-    const int b = plane / C, c = plane - b * C;
-    const float mu = mean[c], g = invstd[c] * gamma[c], be = beta[c];
+    const float g = istd * gamma[c], be = beta[c];
     const float* xp = x + (long long)plane * HW;
     const float* rp = res ? res + (long long)plane * HW : nullptr;
     float* yp = y + (long long)b * y_bs + (long long)c * HW;
@@ -140,33 +140,30 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef, long long n,
-                                       int C, int accumulate, int nsplit) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dx = gamma*invstd*(dy' - k0 - xhat*k1) ; dres = dy'
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ y, const float* __restrict__ gamma,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const double* __restrict__ part, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int accumulate, long long n, int nsplit,
+                                    float* __restrict__ dx,
+                                    float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
+                                    int relu, int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int b = plane / C, c = plane - b * C;
+    // finish the channel's two sums (sum dy', sum dy'*xhat) from the partials; one block publishes the parameter
+    // gradients (same arithmetic as the former finalize kernel: fixed order, double)
     double s0 = 0.0, s1 = 0.0;
     for (int s = 0; s < nsplit; ++s) {
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
         s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
     }
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
-    coef[2 * c + 0] = (float)(s0 / (double)n);   // mean(dy')
-    coef[2 * c + 1] = (float)(s1 / (double)n);   // mean(dy' * xhat)
-}
-
-// dx = gamma*invstd*(dy' - k0 - xhat*k1) ; dres = dy'
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                    const float* __restrict__ y, const float* __restrict__ gamma,
-                                    const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ coef, float* __restrict__ dx,
-                                    float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
-                                    int relu, int planes) {
-  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
-    const int b = plane / C, c = plane - b * C;
-    const float mu = mean[c], is = invstd[c], gi = gamma[c] * is, k0 = coef[2 * c], k1 = coef[2 * c + 1];
+    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
+    }
+    const float k0 = (float)(s0 / (double)n), k1 = (float)(s1 / (double)n);
+    const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
     const float* xp = x + (long long)plane * HW;
     const float* gp = dy + (long long)b * dy_bs + (long long)c * HW;
     const float* yp = relu ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
@@ -390,10 +387,9 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
                        nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, save_mean,
-                       save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, C, ns);
-    hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, save_mean,
-                       save_invstd, residual, y, C, HW, y_bs, relu, B * C);
+    hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, part, save_mean,
+                       save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, ns, residual, y, C,
+                       HW, y_bs, relu, B * C);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -414,14 +410,12 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     double* part = static_cast<double*>(ws);
-    float* coef = reinterpret_cast<float*>(part + (size_t)C * kStatSplit * 2);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
                        part, B, C, HW, dy_bs, y_bs, relu, 1, ns);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(wsdl::cdiv(C, 128)), dim3(128), 0, s, part, gamma,
-                       save_invstd, dgamma, dbeta, coef, (long long)B * HW, C, accumulate_param_grads, ns);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
-                       save_invstd, coef, dx, dres, C, HW, dy_bs, y_bs, relu, B * C);
+                       save_invstd, part, dgamma, dbeta, accumulate_param_grads, (long long)B * HW, ns, dx, dres, C, HW,
+                       dy_bs, y_bs, relu, B * C);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
