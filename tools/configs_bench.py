@@ -17,7 +17,7 @@ from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optim
 dev = torch.device("cuda:0")
 
 
-def run(B, S, extra, steps=5, warm=2):
+def run(B, S, extra, steps=12, warm=4):
     torch.manual_seed(0)
     model = build_segmentation_model().to(dev).train()
     opt = make_optimizer(model)
