@@ -1479,7 +1479,7 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
 // bytes of the pre-split dY image of the 32-pixel-chunk weight-gradient kernel (0: kernel not used)
 size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
     if (!wgrad_chunk32(Cout, Cin, N)) return 0;
-    const size_t n = (size_t)wsdl::cdiv(P, 16) * Cout * kSplitK16Bytes;
+    const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * kW2Row;
     return n < (1ull << 31) ? n : 0;
 }
 
@@ -1578,7 +1578,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             // ASPP shapes (profiles/r01_notes.md)
             if (chunk32) {
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
-                const long long total = (long long)wsdl::cdiv(p.P, 16) * Cout;
+                const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
                 hipLaunchKernelGGL(dy_split_kernel, dim3((int)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0,
                                    s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P);
                 dim3 grid(p.N / 128, Cout / 128, S);

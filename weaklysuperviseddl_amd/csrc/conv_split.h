@@ -373,23 +373,30 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
 // (the other half is fetched again by the next chunk after the 32 KiB L1 has turned over), and both operands pay the
 // VALU split.  Here
 //   * a chunk is 32 consecutive pixels = one full 128-byte line per row, read by 32 adjacent lanes;
-//   * dY is split ONCE per launch by dy_split_kernel into the k16-major layout the forward kernel uses for its
-//     weights ([pixel/16][cout][h|m|l][16] bf16): every N tile of the launch (36 for a 3x3 on 512 channels)
-//     re-reads it with 16-byte loads and no arithmetic;
+//   * dY is split ONCE per launch by dy_split_kernel into the kernel's own LDS row format
+//     ([pixel/32][cout][2 x [h|m|l] x 16 bf16 + 16 B pad] = 208 B rows): a row tile of a chunk is one contiguous
+//     26 KB run that every N tile of the launch (36 for a 3x3 on 512 channels) copies with 16-byte units - no
+//     arithmetic, no bank conflicts (the unpadded form cost 33 % of the LDS cycles in conflicts);
 //   * x is split in the kernel.  A lane holds ONE pixel of a row, the packed converts want a pixel PAIR per
 //     lane: lanes swap one value with their neighbour (DPP quad_perm) so that even lanes own the pair of one
 //     row and odd lanes the pair of the row below - 4 VALU ops per pair instead of a second, half-used load.
+constexpr int kW2Row = 2 * kSplitK16Bytes + 16;     // 208-byte LDS rows: 32 pixels x 3 pieces + padding
+
 __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __restrict__ out, int B, int Cout,
                                 int OHOW, long long dy_bs, int P) {
-    // one thread: 16 consecutive pixels (linear index over b, oh, ow) of one channel
-    const int groups = (P + 15) / 16;
+    // one thread: 16 consecutive pixels (linear index over b, oh, ow) of one channel; an even number of groups so that
+    // every 208-byte row is written in full (zeros past the last pixel)
+    const int groups = 2 * ((P + 31) / 32);
     const long long total = (long long)groups * Cout;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(idx % groups), c = (int)(idx / groups);
         float v[16];
         const int p0 = g * 16;
-        if (OHOW % 16 == 0) {
+        if (p0 >= P) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+        } else if (OHOW % 16 == 0) {
             const int b = p0 / OHOW, r = p0 - b * OHOW;
             const float4* src = reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * OHOW + r);
 #pragma unroll
@@ -412,7 +419,7 @@ __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __r
         unsigned h[8], m[8], l[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) split3(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
-        u32x4* dst = reinterpret_cast<u32x4*>(out + ((long long)g * Cout + c) * kSplitK16Bytes);
+        u32x4* dst = reinterpret_cast<u32x4*>(out + ((long long)(g >> 1) * Cout + c) * kW2Row + (g & 1) * kSplitK16Bytes);
         dst[0] = u32x4{h[0], h[1], h[2], h[3]};
         dst[1] = u32x4{h[4], h[5], h[6], h[7]};
         dst[2] = u32x4{m[0], m[1], m[2], m[3]};
@@ -421,8 +428,6 @@ __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __r
         dst[5] = u32x4{l[4], l[5], l[6], l[7]};
     }
 }
-
-constexpr int kW2Row = 2 * kSplitK16Bytes + 16;     // 208-byte LDS rows: 32 pixels x 3 pieces + padding
 
 // 256 threads, 64x64 wave tiles (12 operand reads per 24 MFMAs), ONE LDS image per workgroup (53 KB) and two
 // barriers per chunk, so two workgroups share a CU: while one converts / stores its next chunk, the other one's MFMAs
@@ -436,11 +441,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     static_assert(BM == 128 && BN == 128, "tile");
     constexpr int BK = 32, ROW = kW2Row;
     constexpr int WN = 2, MI = 2, NI = 2;
-    constexpr int A_U = 2 * BM * 6 / kThreads;             // 6 16-byte units per thread per chunk
+    constexpr int A_UNITS = BM * ROW / 16;                 // the dY image of a chunk is one contiguous run: 1664 units
+    constexpr int A_U = (A_UNITS + kThreads - 1) / kThreads;   // 7 per thread, the last one partial (LDS padded)
     constexpr int B_PER = BN / 8;                          // 16 rows per thread: 8 half-waves x 32 pixels per pass
     constexpr unsigned kOOB = 0x80000000u;
 
-    __shared__ __attribute__((aligned(16))) unsigned char As[BM * ROW];
+    __shared__ __attribute__((aligned(16))) unsigned char As[A_U * kThreads * 16];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[BN * ROW];
 
     const int tid = threadIdx.x;
@@ -462,14 +468,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     // this thread's x rows: 2*hw + (e & 1) + 16*(e >> 1): the two rows of a pair are neighbours
     const unsigned b_row = (unsigned)((ci0 + 2 * hw) * HW);
 
-    unsigned voff_a[A_U], lds_a[A_U];
+    // dY arrives in the LDS row format itself ([pixel/32][cout][208 B]): unit u of the row tile goes to byte 16 u of
+    // the image - consecutive lanes, consecutive 16 bytes on both sides, no bank conflicts
+    unsigned voff_a[A_U];
 #pragma unroll
     for (int e = 0; e < A_U; ++e) {
         const int u = tid + e * kThreads;
-        const int ks = u / (BM * 6), v = u - ks * (BM * 6);
-        const int row = v / 6, part = v - row * 6;
-        voff_a[e] = (unsigned)(ks * p.Cout * kSplitK16Bytes + (m0 * 6 + v) * 16);
-        lds_a[e] = (unsigned)(row * ROW + ks * kSplitK16Bytes + part * 16);
+        voff_a[e] = u < A_UNITS ? (unsigned)(m0 * ROW + u * 16) : kOOB;
     }
 
     f32x16 acc[MI][NI];
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
         return c;
     };
     auto load_tiles = [&](int c) {
-        const unsigned soff_a = (unsigned)(2 * c) * (unsigned)(p.Cout * kSplitK16Bytes);
+        const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
 #pragma unroll
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * kSplitK16Bytes + (pair & 7) * 4);
     auto store_tiles = [&]() {
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + lds_a[e]) = ra[e];
+        for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
 #pragma unroll
         for (int i = 0; i < B_PER / 2; ++i) {
             const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];
