@@ -1169,8 +1169,7 @@ bool split_eligible(int rows, int kc, int T) {
 template <int BM, int BN, int WM, int BK>
 void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
-    // register prefetch distance 1: distances 2 and 3 measured equal (profiles/r01_notes.md)
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, 1>), grid, dim3(kThreads), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
 }
 
 template <int BM, int BN, int WM>

@@ -17,7 +17,6 @@
 // is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots
 // of the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
 #pragma once
-#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -36,17 +35,10 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
 
 constexpr int kSplitK16Bytes = 96;   // one row's 16 k values: 3 pieces x 16 bf16
 
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 
-// PD = chunks of global loads kept in flight in registers (prefetch distance): one K-chunk of MFMAs is ~770 cycles,
-// a fraction of the L2 / fabric latency, so one chunk in flight leaves the kernel latency-bound.
-template <int BM, int BN, int WM, int BK, int PD>
+// One chunk of global loads is in flight in registers while the previous one is computed; deeper register rings
+// (2, 3 chunks) measured no faster - the kernel is power-limited, not latency-limited (profiles/r01_notes.md).
+template <int BM, int BN, int WM, int BK>
 __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) {
     constexpr int WN = 4 / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
@@ -157,8 +149,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[PD][A_U];
-    unsigned rb[PD][B_PER];
+    u32x4 ra[A_U];
+    unsigned rb[B_PER];
     int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
     unsigned voff_b = kOOB;
     auto set_tap = [&](int vi) {
@@ -169,8 +161,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
     };
     if (nq > 0) set_tap(ld_vi);
 
-    auto load_next = [&](auto stage) {
-        constexpr int S = decltype(stage)::value;
+    auto load_next = [&]() {
         if (ld_c == cpt) {
             ld_c = 0;
             ++ld_vi;
@@ -179,23 +170,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
         const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
         const unsigned soff_a = (unsigned)(c16 * p.Cout * kSplitK16Bytes);
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
         const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
-            rb[S][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
+            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
         ++ld_c;
     };
     // this thread's k run [kr*B_PER, kr*B_PER + B_PER) inside the chunk -> (k-step, offset inside the 16)
-    auto store_tiles = [&](int buf, auto stage) {
-        constexpr int S = decltype(stage)::value;
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < A_U; ++e)
-            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[S][e];
+            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
         unsigned hp[B_PER / 2], mp[B_PER / 2], lp[B_PER / 2];
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e)
-            split3(__builtin_bit_cast(float, rb[S][2 * e]), __builtin_bit_cast(float, rb[S][2 * e + 1]), hp[e], mp[e], lp[e]);
+            split3(__builtin_bit_cast(float, rb[2 * e]), __builtin_bit_cast(float, rb[2 * e + 1]), hp[e], mp[e], lp[e]);
         unsigned char* rowp = &Bs[buf][pl * ROW];
         if constexpr (B_PER == 4) {
             const int k = kr * 4, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
@@ -213,13 +203,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
         }
     };
 
-    // stage s of the register ring holds chunk 1 + s (mod PD); chunk 0 goes straight to LDS
     if (nq > 0) {
-        load_next(std::integral_constant<int, 0>{});
-        store_tiles(0, std::integral_constant<int, 0>{});
-        static_for<PD>([&](auto s) {
-            if (1 + decltype(s)::value < nq) load_next(s);
-        });
+        load_next();
+        store_tiles(0);
+        if (nq > 1) load_next();
     }
     __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
@@ -253,17 +240,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
                 }
         }
     };
-    for (int q = 0; q < nq; q += PD) {
-        static_for<PD>([&](auto s) {
-            const int qq = q + decltype(s)::value;
-            if (qq < nq) {                                   // block-uniform
-                const int cur = qq & 1;
-                if (qq + 1 < nq) store_tiles(cur ^ 1, s);    // stage s holds chunk qq + 1
-                if (qq + 1 + PD < nq) load_next(s);
-                mfma_chunk(cur);
-                lds_barrier();
-            }
-        });
+    for (int q = 0; q < nq; ++q) {
+        const int cur = q & 1;
+        if (q + 1 < nq) store_tiles(cur ^ 1);            // the registers hold chunk q + 1
+        if (q + 2 < nq) load_next();
+        mfma_chunk(cur);
+        lds_barrier();
     }
 
     if (p.ksplit > 1) {
