@@ -61,6 +61,33 @@ def test_conv_adjointness_full_size(dev, shape):
     assert ((y3 - (2 * y - y2)).abs().max() / y.abs().max()).item() < 1e-4     # fp32 rounding over K up to 18432
 
 
+def test_conv_tensors_beyond_2gib_are_processed_in_batch_slices(dev):
+    """The kernels address their input through 32-bit buffer offsets; a 3.2 GB activation batch must come out as if
+    every image had been convolved on its own (forward, input gradient, weight gradient)."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, C, H = 3, 64, 2048                                    # 3 x 1.07 GB
+    x = torch.randn(B, C, H, H, device=dev, generator=g)
+    assert x.numel() * 4 > (1 << 31)
+    w = torch.randn(C, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5
+    wf, wd = ops.prep_weights(w)
+    y = ops.conv2d_fwd(x, wf, w.shape, 1, 1, 1)
+    dy = torch.randn(B, C, H, H, device=dev, generator=g)
+    dx = ops.conv2d_dgrad(dy, wd, w.shape, x.shape, 1, 1, 1)
+    dw = ops.conv2d_wgrad(x, dy, w.shape, 1, 1, 1)
+    dw_sum = torch.zeros_like(dw)
+    for b in range(B):
+        yb = ops.conv2d_fwd(x[b:b + 1], wf, w.shape, 1, 1, 1)
+        assert (yb - y[b:b + 1]).abs().max().item() <= 1e-5 * y.abs().max().item()
+        dxb = ops.conv2d_dgrad(dy[b:b + 1], wd, w.shape, (1, C, H, H), 1, 1, 1)
+        assert (dxb - dx[b:b + 1]).abs().max().item() <= 1e-5 * dx.abs().max().item()
+        dw_sum += ops.conv2d_wgrad(x[b:b + 1], dy[b:b + 1], w.shape, 1, 1, 1)
+    assert (dw_sum - dw).abs().max().item() <= 1e-4 * dw.abs().max().item()
+    # and the first image against torch on the host's cheap path: a 64x64 crop corner of the output
+    ref = torch.nn.functional.conv2d(x[0:1, :, :66, :66].cpu(), w.cpu(), None, 1, 1, 1)[0, :, :64, :64]
+    assert (y[0, :, :64, :64].cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 def test_aspp_skipped_taps_equal_dense_result(dev):
     """Tap skipping is exact: a dilation-36 3x3 conv on a 32x32 map equals the 1x1 conv of its centre tap."""
     from weaklysuperviseddl_amd import ops

@@ -1291,6 +1291,33 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     return WSDL_OK;
 }
 
+// The buffer-descriptor kernels address the input tensor with 32-bit byte offsets.  A batch whose input extent
+// reaches 2 GiB (large batches of large maps - 288 GB of HBM invite them) is processed in batch slices that each
+// stay below it; a single image of >= 2 GiB falls through to launch_igemm's own handling.
+int launch_igemm_sliced(const ConvP& p, int img_out_pixels, long long img_in_elems, hipStream_t s, double flops,
+                        void* ws, size_t ws_bytes) {
+    const long long limit = (1ll << 31) - 4;
+    const long long whole = ((long long)(p.B - 1) * p.x_bs + img_in_elems) * 4;
+    if (whole <= limit || p.B == 1 || img_in_elems * 4 > limit) {
+        ConvP q = p;
+        q.x_bytes = whole <= limit ? (unsigned)whole : 0u;      // 0 -> generic kernel / error in launch_igemm
+        return launch_igemm(q, s, flops, ws, ws_bytes);
+    }
+    long long per = (limit / 4 - img_in_elems) / p.x_bs + 1;    // images per slice
+    if (per < 1) per = 1;
+    for (int b0 = 0; b0 < p.B; b0 += (int)per) {
+        ConvP q = p;
+        q.B = (int)std::min<long long>(per, p.B - b0);
+        q.P = q.B * img_out_pixels;
+        q.x = p.x + (long long)b0 * p.x_bs;
+        q.y = p.y + (long long)b0 * p.y_bs;
+        if (p.res) q.res = p.res + (long long)b0 * p.res_bs;
+        q.x_bytes = (unsigned)(((long long)(q.B - 1) * p.x_bs + img_in_elems) * 4);
+        if (int rc = launch_igemm(q, s, flops * q.B / p.B, ws, ws_bytes)) return rc;
+    }
+    return WSDL_OK;
+}
+
 // split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
 int g_wgrad_blocks = 768;   // target number of workgroups of a weight-gradient launch (tiles x pixel splits)
 
@@ -1434,11 +1461,8 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin
     p.res_bs = res_bs ? res_bs : (long long)Cout * OH * OW;
     WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
     p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
-    {
-        const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4;
-        p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;     // 0 -> generic kernel
-    }
-    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
+    return launch_igemm_sliced(p, OH * OW, (long long)Cin * H * W, wsdl::as_stream(stream),
+                               2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
 }
 
 int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, int Cin, int H, int W,
@@ -1458,11 +1482,8 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
     p.res_bs = p.y_bs;
     WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
     p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
-    {
-        const long long xb = ((long long)(B - 1) * p.x_bs + (long long)Cout * OH * OW) * 4;
-        p.x_bytes = xb < (1ll << 31) ? (unsigned)xb : 0u;
-    }
-    return launch_igemm(p, wsdl::as_stream(stream), 2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
+    return launch_igemm_sliced(p, H * W, (long long)Cout * OH * OW, wsdl::as_stream(stream),
+                               2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
 }
 
 size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
@@ -1537,7 +1558,22 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     int tBM, tBN;
     bool fast;
     wgrad_tile(Cout, Cin, &tBM, &tBN, &fast);
-    WSDL_REQUIRE(!fast || (xb < (1ll << 31) && dyb < (1ll << 31)), "conv2d_wgrad: tensors above 2 GiB are not supported");
+    if (fast && (xb >= (1ll << 31) || dyb >= (1ll << 31))) {
+        // 32-bit byte offsets in the buffer-descriptor kernels: process the batch in slices below 2 GiB, accumulating
+        const long long img = std::max((long long)Cin * H * W, (long long)Cout * OH * OW) * 4;
+        const long long bs = std::max(p.x_bs, p.dy_bs) * 4;
+        WSDL_REQUIRE(B > 1 && img < (1ll << 31), "conv2d_wgrad: a single image of 2 GiB or more is not supported");
+        long long per = ((1ll << 31) - 4 - img) / bs + 1;
+        if (per < 1) per = 1;
+        for (int b0 = 0; b0 < B; b0 += (int)per) {
+            const int nb_img = (int)std::min<long long>(per, B - b0);
+            if (int rc = wsdl_conv2d_wgrad(x + (long long)b0 * p.x_bs, dy + (long long)b0 * p.dy_bs, dw, nb_img, Cin, H, W,
+                                           Cout, kh, kw, stride, pad, dil, (accumulate || b0 > 0) ? 1 : 0, p.x_bs, p.dy_bs,
+                                           ws, ws_bytes, stream))
+                return rc;
+        }
+        return WSDL_OK;
+    }
     {
         const double flops = 2.0 * p.P * (double)Cout * p.N;
         double executed = flops;
