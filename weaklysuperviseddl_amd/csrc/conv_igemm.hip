@@ -1497,14 +1497,14 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
 }
 
 // bytes of the pre-split dY image of the 32-pixel-chunk weight-gradient kernel (0: kernel not used)
-size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
+static size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
     if (!wgrad_chunk32(Cout, Cin, N)) return 0;
     const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * kW2Row;
     return n < (1ull << 31) ? n : 0;
 }
 
 // column bands of a weight-gradient launch (fast kernel only): same rule as the forward kernel
-int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int pad, int dil, Band* bands) {
+static int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int pad, int dil, Band* bands) {
     int BM, BN;
     bool fast;
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
