@@ -148,12 +148,16 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cam", action="store_true")
     ap.add_argument("--cam-only", action="store_true", help="only the secondary CAM ms/img measurement (profiling aid)")
+    ap.add_argument("--opt", default="", help="library options name=value[,name=value] (A/B experiments, e.g. ksplit_big=0)")
     ap.add_argument("--serial", action="store_true",
                     help="no side-stream overlap anywhere: every kernel has the chip to itself (profiling aid; the "
                          "roofline pass always runs like this)")
     args = ap.parse_args()
 
     from weaklysuperviseddl_amd import ops
+    for kv in [x for x in args.opt.split(",") if x]:
+        k, v = kv.split("=")
+        ops.set_option(k, int(v))
     from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
     from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
     from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer

@@ -480,17 +480,21 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
     }
 
     if (p.ksplit > 1) {     // raw partial sums; conv_splitk_reduce_kernel applies the epilogue
-        float* sl = p.slab + (long long)blockIdx.z * p.Cout * W_P;
+        // slabs are indexed by the pixel's position in the whole output (b, oh, ow), not inside the block's column band
+        float* sl = p.slab + (long long)blockIdx.z * p.Cout * p.P;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
             if (opix >= W_P) continue;
+            const int ob = opix / OHW;
+            const int orr = opix - ob * OHW, ooh = orr / w_own;
+            const int gpix = ob * OHOW + ooh * p.OW + w_ow0 + (orr - ooh * w_own);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co < p.Cout) sl[(long long)co * W_P + opix] = acc[i][j][r];
+                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = acc[i][j][r];
                 }
         }
         return;
@@ -1201,10 +1205,16 @@ void launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
 // the tap-skipping imbalance averages out.  Cout <= 64: 64x256 / 64x128.
 // Split-K for grids that cannot fill the chip (small batches of small maps, e.g. the CAM path at B=8: 14x14 maps
 // give 25 pixel tiles): returns the number of K slices (1 = no split).  Only the fast path supports it.
-int igemm_ksplit(int P, int Cout, int Cin, int T) {
+int g_ksplit_big = 1;   // 128x128 tiles + 2 K slices for grids of 200..399 such tiles with K >= 2048 (instead of 128x64
+                        // tiles): aux 3x3 505 -> 435 us, layer3 3x3 139 -> 128 us; shorter K loses to the slab reduce
+int igemm_ksplit(int P, int Cout, int Cin, int T, int dil) {
     if (Cin % 32 != 0 || Cout % 4 != 0 || Cout <= 64) return 1;
     const long long blocks = (long long)wsdl::cdiv(P, 64) * wsdl::cdiv(Cout, 128);       // 128x64 tile
     const int nq = T * (Cin / 32);
+    if (g_ksplit_big) {
+        const long long b128 = (long long)wsdl::cdiv(P, 128) * wsdl::cdiv(Cout, 128);
+        if (b128 >= 200 && b128 < g_tile_threshold && nq >= 64) return 2;
+    }
     if (blocks >= 160 || nq < 8) return 1;
     long long s = 320 / blocks;
     if (s > nq / 4) s = nq / 4;
@@ -1223,7 +1233,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     p.nb = 1;
     p.grid_x = 0;
     {
-        const int ks = igemm_ksplit(p.P, p.Cout, p.Cin, p.KH * p.KW);
+        const int ks = igemm_ksplit(p.P, p.Cout, p.Cin, p.KH * p.KW, p.bh < 0 ? -p.bh : p.bh);
         if (ks > 1 && ws && ws_bytes >= (size_t)ks * p.Cout * p.P * sizeof(float) && p.x_bytes != 0 &&
             (long long)p.K * p.Cout * 4 < (1ll << 31)) {
             p.ksplit = ks;
@@ -1244,12 +1254,12 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     if (p.Cout <= 64)
         cfg = (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 64) >= kWant ? 2 : 3;
     else
-        cfg = (p.ksplit == 1 && (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) >= kWant) ? 0 : 1;
+        cfg = ((long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 128) * p.ksplit >= kWant) ? 0 : 1;
     // column bands (fast path, no split-K): one launch per band, each with uniform column-tap validity
     Band bands[8];
     int nb = 1;
     bands[0] = Band{0, p.OW};
-    if (aligned && p.ksplit == 1 && g_col_bands) nb = column_bands(p.OW, p.W, p.ah, p.bh, p.ch, p.sh, p.KW, bands);
+    if (aligned && g_col_bands) nb = column_bands(p.OW, p.W, p.ah, p.bh, p.ch, p.sh, p.KW, bands);
     const int bn_tile = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128;
     double executed = flops;
     if (aligned && wsdl::prof_enabled()) {
@@ -1393,6 +1403,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
@@ -1492,7 +1503,7 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
     if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
     // forward: P = B*OH*OW output pixels, Cout rows; dgrad: roles swapped
     const int P = dgrad ? B * H * W : B * OH * OW, M = dgrad ? Cin : Cout, Kc = dgrad ? Cout : Cin;
-    const int ks = igemm_ksplit(P, M, Kc, kh * kw);
+    const int ks = igemm_ksplit(P, M, Kc, kh * kw, dil);
     return ks > 1 ? (size_t)ks * M * P * sizeof(float) : 0;
 }
 

@@ -249,17 +249,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
     }
 
     if (p.ksplit > 1) {
-        float* sl = p.slab + (long long)blockIdx.z * p.Cout * W_P;
+        // slabs are indexed by the pixel's position in the whole output (b, oh, ow), not inside the block's column band
+        float* sl = p.slab + (long long)blockIdx.z * p.Cout * p.P;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
             if (opix >= W_P) continue;
+            const int ob = opix / OHW;
+            const int orr = opix - ob * OHW, ooh = orr / w_own;
+            const int gpix = ob * OHOW + ooh * p.OW + w_ow0 + (orr - ooh * w_own);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co < p.Cout) sl[(long long)co * W_P + opix] = acc[i][j][r];
+                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = acc[i][j][r];
                 }
         }
         return;
