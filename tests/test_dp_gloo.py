@@ -64,3 +64,72 @@ def test_bucketed_allreduce_world2(tmp_path):
     mine = torch.cat([got["grad"][o:o + n] for o, n in zip(got["offsets"], got["numels"])])
     assert torch.allclose(mine, total, rtol=1e-5, atol=1e-7)
     assert got["launched_early"] >= 1      # at least one bucket went out from a backward hook, before wait()
+
+
+class _TwoHeads(nn.Module):
+    """Trunk + main head + an auxiliary head whose output no loss uses (the DeepLabV3 aux classifier's situation)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(1)
+        self.trunk = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU())
+        self.head = nn.Conv2d(8, 2, 1)
+        self.aux = nn.Sequential(nn.Conv2d(8, 8, 3, padding=1), nn.Conv2d(8, 3, 1))
+
+    def forward(self, x):
+        f = self.trunk(x)
+        return self.head(f), self.aux(f)
+
+
+def _worker_unused(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
+    from weaklysuperviseddl_amd.optim import FlatAdam
+    torch.set_num_threads(1)
+    init_distributed(backend="gloo")
+    model = _TwoHeads()
+    opt = FlatAdam(list(model.parameters()), lr=1e-3)
+    red = GradBucketReducer(opt, num_buckets=2)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 8, 8, generator=g)[rank * 2:(rank + 1) * 2]
+    grads, early, excluded = [], [], []
+    for it in range(4):
+        opt.zero_grad()
+        main, aux = model(x)
+        loss = main.pow(2).mean()
+        if it == 3:
+            loss = loss + aux.pow(2).mean()       # the "unused" head turns up after having been cut out
+        loss.backward()
+        early.append(sum(red._launched))
+        excluded.append(len(red._excluded))
+        red.wait()
+        grads.append(opt.flat_grad.clone())
+    if rank == 0:
+        torch.save({"grads": grads, "early": early, "excluded": excluded, "offsets": opt.offsets,
+                    "numels": [p.numel() for p in opt.params]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_trailing_parameters_do_not_hold_the_last_bucket_back(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_unused, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 8, 8, generator=g)
+    for it in (0, 2, 3):
+        total = None
+        for r in range(2):
+            m = _TwoHeads()
+            main, aux = m(x[r * 2:(r + 1) * 2])
+            loss = main.pow(2).mean() + (aux.pow(2).mean() if it == 3 else 0.0)
+            loss.backward()
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in m.parameters()])
+            total = flat if total is None else total + flat
+        mine = torch.cat([got["grads"][it][o:o + n] for o, n in zip(got["offsets"], got["numels"])])
+        assert torch.allclose(mine, total, rtol=1e-5, atol=1e-7), it
+    # step 0 has to wait for the aux head (its bucket leaves at the join); from step 1 on the head is cut out and
+    # every bucket leaves from a backward hook
+    assert got["excluded"][0] == 0 and got["excluded"][1] == 4
+    assert got["early"][1] > got["early"][0] and got["early"][1] == 2

@@ -60,9 +60,16 @@ class GradBucketReducer:
         self.bucket_size = [0] * (len(bounds) - 1)
         for b in self.bucket_of:
             self.bucket_size[b] += 1
-        self._remaining = list(self.bucket_size)
         self._pending = []
         self._launched = [False] * len(self.bucket_size)
+        # Parameters that receive no gradient (the aux head: no loss of the reference uses it) would hold their
+        # bucket's collective back until the end of backward.  They are learnt from the previous step: unused
+        # parameters at either END of a bucket's range are cut out of its collective (so a gradient that does turn up
+        # for one of them later cannot race with it; it is reduced on its own at the join) and no longer waited for.
+        self._fired = set()
+        self._excluded = set()
+        self._range = [(self.bounds[b], self.bounds[b + 1]) for b in range(len(self.bucket_size))]
+        self._remaining = list(self.bucket_size)
         if self.world > 1:
             self._index = {id(p): i for i, p in enumerate(optimizer.params)}
             for i, p in enumerate(optimizer.params):
@@ -74,6 +81,9 @@ class GradBucketReducer:
         b = self.bucket_of[i]
 
         def hook(_p):
+            self._fired.add(i)
+            if i in self._excluded:            # reduced on its own at the join (not part of the bucket's collective)
+                return
             self._remaining[b] -= 1
             if self._remaining[b] == 0:
                 self._launch(b)
@@ -86,7 +96,10 @@ class GradBucketReducer:
         if self._launched[b]:
             return
         self._launched[b] = True
-        view = self.opt.flat_grad[self.bounds[b]:self.bounds[b + 1]]
+        lo, hi = self._range[b]
+        if hi <= lo:
+            return
+        view = self.opt.flat_grad[lo:hi]
         if view.is_cuda:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
@@ -100,12 +113,32 @@ class GradBucketReducer:
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
-        """Launch any bucket whose hooks did not all fire (unused parameters), then join."""
+        """Launch any bucket whose hooks did not all fire, reduce late gradients of excluded parameters, join, and
+        learn which parameters to leave out next step."""
+        opt = self.opt
         if self.world > 1:
             for b in range(len(self.bucket_size)):
                 self._launch(b)
+            for i in sorted(self._excluded & self._fired):
+                off, n = opt.offsets[i], opt.params[i].numel()
+                self._pending.append(dist.all_reduce(opt.flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
             for w in self._pending:
                 w.wait()
+            # next step: per bucket, drop the unused parameters before the first / after the last used one
+            self._excluded = set()
+            for b in range(len(self.bucket_size)):
+                idx = [i for i, bb in enumerate(self.bucket_of) if bb == b]
+                used = [i for i in idx if i in self._fired]
+                if not used:
+                    self._excluded.update(idx)
+                    self._range[b] = (self.bounds[b], self.bounds[b])
+                    self._remaining[b] = 0
+                    continue
+                first, last = used[0], used[-1]
+                self._excluded.update(i for i in idx if i < first or i > last)
+                self._range[b] = (opt.offsets[first], opt.offsets[last] + opt.params[last].numel())
+                self._remaining[b] = last - first + 1       # unused parameters INSIDE the range are still waited for
         self._pending = []
-        self._remaining = list(self.bucket_size)
+        self._fired = set()
         self._launched = [False] * len(self.bucket_size)
