@@ -272,7 +272,8 @@ def test_global_avgpool_and_linear(dev):
 
 
 @pytest.mark.parametrize("shape,size", [((2, 3, 4, 4), (32, 32)), ((1, 2, 14, 14), (224, 224)),
-                                        ((2, 5, 1, 1), (8, 8)), ((1, 2, 7, 9), (20, 31)), ((2, 2, 8, 8), (8, 8))])
+                                        ((2, 5, 1, 1), (8, 8)), ((1, 2, 7, 9), (20, 31)), ((2, 2, 8, 8), (8, 8)),
+                                        ((3, 4, 1, 1), (32, 32))])
 def test_bilinear_fwd_bwd(dev, shape, size):
     from weaklysuperviseddl_amd import ops
     g = torch.Generator().manual_seed(shape[2])

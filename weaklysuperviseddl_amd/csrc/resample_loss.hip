@@ -83,6 +83,41 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, float* __restr
     }
 }
 
+// Same sums for large up-sampling factors (8x logits -> image, the 1x1 -> 32x32 broadcast of the ASPP pooling
+// branch): an input pixel gathers hundreds of output pixels, so ONE WAVE works on it - lanes stride over the window,
+// fixed shuffle tree (deterministic).  The thread-per-pixel form above left 1 lane of 256 busy on the 1x1 maps.
+__global__ void bilinear_bwd_wave_kernel(const float* __restrict__ dy, float* __restrict__ dx, int C, int h, int w,
+                                         int H, int W, long long dy_bs, long long total) {
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long item = wave0; item < total; item += nwaves) {
+        const int plane = (int)(item / (h * w)), idx = (int)(item - (long long)plane * (h * w));
+        const int b = plane / C, c = plane - b * C;
+        const float* gp = dy + (long long)b * dy_bs + (long long)c * H * W;
+        const int ih = idx / w, iw = idx - ih * w;
+        int oh_lo = (int)floorf(((float)ih - 0.5f) / sh - 0.5f) - 1;
+        int oh_hi = (int)ceilf(((float)ih + 1.5f) / sh - 0.5f) + 1;
+        int ow_lo = (int)floorf(((float)iw - 0.5f) / sw - 0.5f) - 1;
+        int ow_hi = (int)ceilf(((float)iw + 1.5f) / sw - 0.5f) + 1;
+        oh_lo = max(oh_lo, 0); ow_lo = max(ow_lo, 0);
+        oh_hi = min(oh_hi, H - 1); ow_hi = min(ow_hi, W - 1);
+        const int nw = ow_hi - ow_lo + 1, n = (oh_hi - oh_lo + 1) * nw;
+        float s = 0.f;
+        for (int k = lane; k < n; k += 64) {
+            const int r = k / nw, oh = oh_lo + r, ow = ow_lo + (k - r * nw);
+            const Lerp a = src_index(oh, sh, h);
+            const float wh = (a.i0 == ih ? a.l0 : 0.f) + (a.i1 == ih ? a.l1 : 0.f);
+            const Lerp bb = src_index(ow, sw, w);
+            const float ww = (bb.i0 == iw ? bb.l0 : 0.f) + (bb.i1 == iw ? bb.l1 : 0.f);
+            s += wh * ww * gp[oh * W + ow];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dx[(long long)plane * h * w + idx] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------- reductions
 __global__ void finalize_sum_kernel(const float* __restrict__ part, int n, int groups, float scale,
                                     float* __restrict__ out) {
@@ -398,8 +433,15 @@ int wsdl_bilinear_bwd(const float* dy, float* dx, int B, int C, int h, int w, in
                       long long dy_bs, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && dx && B > 0 && C > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear_bwd: bad arguments");
     if (!dy_bs) dy_bs = (long long)C * H * W;
-    hipLaunchKernelGGL(bilinear_bwd_kernel, plane_grid(B * C, h * w), dim3(256), 0, wsdl::as_stream(stream), dy, dx,
-                       C, h, w, H, W, dy_bs, B * C);
+    if ((long long)H * W >= 32ll * h * w) {       // >= 32 contributions per input pixel on average: a wave per pixel
+        const long long total = (long long)B * C * h * w;
+        const int blocks = (int)std::min<long long>((total + 3) / 4, 16384);
+        hipLaunchKernelGGL(bilinear_bwd_wave_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), dy, dx, C, h, w,
+                           H, W, dy_bs, total);
+    } else {
+        hipLaunchKernelGGL(bilinear_bwd_kernel, plane_grid(B * C, h * w), dim3(256), 0, wsdl::as_stream(stream), dy, dx,
+                           C, h, w, H, W, dy_bs, B * C);
+    }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
