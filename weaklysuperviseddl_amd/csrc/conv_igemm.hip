@@ -549,6 +549,35 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
     }
 }
 
+// 16-byte form of the above for OH*OW % 4 == 0 (and 4-float-aligned batch strides): four pixels per thread
+__global__ void conv_splitk_reduce_vec4_kernel(ConvP p) {
+    const int OHOW = p.OH * p.OW;
+    const long long total = (long long)p.Cout * p.P, total4 = total / 4;
+    const float4* slab4 = reinterpret_cast<const float4*>(p.slab);
+    for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < total4;
+         i4 += (long long)gridDim.x * blockDim.x) {
+        const long long idx = i4 * 4;
+        const int co = (int)(idx / p.P), pix = (int)(idx - (long long)co * p.P);
+        float4 v = slab4[i4];
+        for (int z = 1; z < p.ksplit; ++z) {
+            const float4 t = slab4[(long long)z * total4 + i4];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const int ob = pix / OHOW, orp = pix - ob * OHOW;
+        if (p.scale) { const float sc = p.scale[co]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+        if (p.shift) { const float sh = p.shift[co]; v.x += sh; v.y += sh; v.z += sh; v.w += sh; }
+        const long long off = (long long)co * OHOW + orp;
+        if (p.res) {
+            const float4 r = *reinterpret_cast<const float4*>(p.res + (long long)ob * p.res_bs + off);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        float4* y = reinterpret_cast<float4*>(p.y + (long long)ob * p.y_bs + off);
+        if (p.accumulate) { const float4 o = *y; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *y = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 struct WgradP {
     const float* x;
@@ -1294,8 +1323,14 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     }
     if (p.ksplit > 1) {
         const long long total = (long long)p.Cout * p.P;
-        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)),
-                           dim3(256), 0, s, p);
+        const bool vec4 = (p.OH * p.OW) % 4 == 0 && p.y_bs % 4 == 0 && (!p.res || p.res_bs % 4 == 0) &&
+                          (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
+        if (vec4)
+            hipLaunchKernelGGL(conv_splitk_reduce_vec4_kernel, dim3((int)std::min<long long>((total / 4 + 255) / 256, 8192)),
+                               dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)),
+                               dim3(256), 0, s, p);
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
