@@ -52,6 +52,7 @@ CONV_CASES = [
     (3, 128, 9, 11, 256, 3, 1, 2, 2),      # same kernel, chunks straddling rows / images, ragged last chunk
     (2, 256, 16, 16, 128, 3, 2, 1, 1),     # same kernel, stride 2
     (2, 1024, 8, 8, 128, 1, 1, 0, 1),      # same kernel, 1x1 with 8 N tiles
+    (2, 256, 9, 7, 1024, 1, 1, 0, 1),      # 1x1 with 2 N tiles but 8 row tiles: role-swapped (dW^T) weight gradient
 ]
 
 

@@ -29,6 +29,7 @@ SHAPES = [  # Cin, Cout, k, stride, dil, H, B
     (256, 128, 1, 1, 1, 16, 4),
     (128, 512, 1, 1, 1, 8, 4),
     (2048, 256, 3, 1, 4, 14, 2),
+    (256, 1024, 1, 1, 1, 32, 2),    # role-swapped weight gradient
 ]
 
 

@@ -1420,6 +1420,33 @@ int wgrad_splits(int Cout, int Cin, int N, int P) {
 }
 
 
+// dw[co][ci] (+)= t[ci][co]: 32x32 tiles through LDS, both sides in 128-byte runs.  blockDim = (32, 8).
+__global__ void transpose_add_kernel(const float* __restrict__ t, float* __restrict__ dw, int Cout, int Cin,
+                                     int accumulate) {
+    __shared__ float tile[32][33];
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + threadIdx.x;
+        tile[r][threadIdx.x] = (ci < Cin && co < Cout) ? t[(long long)ci * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + threadIdx.x;
+        if (co < Cout && ci < Cin) {
+            const long long o = (long long)co * Cin + ci;
+            dw[o] = accumulate ? dw[o] + tile[threadIdx.x][r] : tile[threadIdx.x][r];
+        }
+    }
+}
+
+// 1x1 / stride 1 convolutions whose OWN weight gradient has too few N tiles for the split kernel (Cin <= 640) but
+// whose transpose has enough (Cout >= 768): the two operands are interchangeable there (no taps, no padding), so the
+// library computes dW^T = wgrad(dy as input, x as output gradient) - pre-splitting the SMALLER tensor x, re-read by
+// Cout/128 row tiles - and transposes the 1 M-element result.
+bool wgrad_role_swap(int Cin, int Cout, int kh, int kw, int stride, int pad) {
+    return kh == 1 && kw == 1 && stride == 1 && pad == 0 && !wgrad_chunk32(Cout, Cin, Cin) && wgrad_chunk32(Cin, Cout, Cout);
+}
+
 template <int BM, int BN, int WM>
 void launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
     dim3 grid(p.N / BN, p.Cout / BM, S);
@@ -1564,6 +1591,9 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
                                    int pad, int dil) {
     int OH, OW;
     if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
+    if (wgrad_role_swap(Cin, Cout, kh, kw, stride, pad))
+        return wsdl::align_up((size_t)Cout * Cin * sizeof(float), 256) +
+               wsdl_conv2d_wgrad_workspace(B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1);
     const int N = kh * kw * Cin;
     Band bands[8];
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
@@ -1578,6 +1608,19 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     WSDL_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
+    if (wgrad_role_swap(Cin, Cout, kh, kw, stride, pad)) {
+        const size_t t_bytes = wsdl::align_up((size_t)Cout * Cin * sizeof(float), 256);
+        WSDL_REQUIRE(ws_bytes > t_bytes, "conv2d_wgrad: workspace too small");
+        float* dwt = static_cast<float*>(ws);
+        if (int rc = wsdl_conv2d_wgrad(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
+                                       dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
+                                       static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream))
+            return rc;
+        hipLaunchKernelGGL(transpose_add_kernel, dim3(wsdl::cdiv(Cout, 32), wsdl::cdiv(Cin, 32)), dim3(32, 8), 0,
+                           wsdl::as_stream(stream), dwt, dw, Cout, Cin, accumulate);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     WgradP p{};
     p.x = x; p.dy = dy; p.slab = static_cast<float*>(ws);
     p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = OH; p.OW = OW; p.KH = kh; p.KW = kw;
