@@ -932,8 +932,9 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
 }
 
 // slab[z][co][tap*Cin+ci] summed over z in order -> dw[co][ci][tap]
+// live: bit t set = tap t has slab data (taps that read only padding everywhere are not computed by the split kernel)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                    int Cout, int Cin, int T, int accumulate) {
+                                    int Cout, int Cin, int T, int accumulate, unsigned long long live) {
     const long long total = (long long)Cout * Cin * T;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -941,7 +942,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         const int co = (int)(idx / N), n = (int)(idx - (long long)co * N);
         const int tap = n / Cin, ci = n - tap * Cin;
         float s = 0.f;
-        for (int z = 0; z < S; ++z) s += slab[(long long)z * total + idx];
+        if (tap >= 64 || ((live >> tap) & 1ull))
+            for (int z = 0; z < S; ++z) s += slab[(long long)z * total + idx];
         const long long o = ((long long)co * Cin + ci) * T + tap;
         dw[o] = accumulate ? dw[o] + s : s;
     }
@@ -979,7 +981,7 @@ __global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4
 // slab values are read as one 128-byte run, the (ci,tap) transpose happens in LDS, and the 32*T results leave
 // as one contiguous run of dw.  blockDim = (32, 8); blockIdx = (Cin/32 tiles, Cout).
 __global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                          int Cout, int Cin, int T, int accumulate) {
+                                          int Cout, int Cin, int T, int accumulate, unsigned long long live) {
     __shared__ float tile[32 * 16];
     const int ci0 = blockIdx.x * 32, co = blockIdx.y;
     const int lane = threadIdx.x, row = threadIdx.y;
@@ -987,7 +989,7 @@ __global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float*
     const long long N = (long long)Cin * T;
     for (int tap = row; tap < T; tap += 8) {
         float s = 0.f;
-        if (ci0 + lane < Cin) {
+        if (ci0 + lane < Cin && ((live >> tap) & 1ull)) {
             const long long idx = (long long)co * N + (long long)tap * Cin + ci0 + lane;
             int z = 0;
             for (; z + 4 <= S; z += 4)      // four slabs in flight; fixed (pairs of pairs) order
@@ -1383,15 +1385,30 @@ bool wgrad_chunk32(int Cout, int Cin, int N) {
     return g_wgrad_split && Cout % 128 == 0 && Cin % 128 == 0 && N / 128 >= 6;
 }
 
-int wgrad_splits(int Cout, int Cin, int N, int P) {
+// taps that read at least one in-range input pixel for some output pixel (bit t of the result); the others (dilation
+// >= map size: ASPP d36 on 32x32 maps keeps only the centre tap) contribute exact zeros
+unsigned long long live_taps(int H, int W, int OH, int OW, int kh, int kw, int stride, int pad, int dil) {
+    unsigned long long m = 0;
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) {
+            const int dh = i * dil - pad, dw = j * dil - pad, t = i * kw + j;
+            const bool dead = dh >= H || (OH - 1) * stride + dh < 0 || dw >= W || (OW - 1) * stride + dw < 0;
+            if (!dead && t < 64) m |= 1ull << t;
+        }
+    return m;
+}
+
+// n_live: N counted over live taps only (the split kernel's dead-tap workgroups exit at once)
+int wgrad_splits(int Cout, int Cin, int N, int P, int n_live) {
     int BM, BN;
     bool fast;
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
-    const long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
+    long long tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(N, BN);
     const int chunks = wsdl::cdiv(P, 32);
     const long long smax = std::max<long long>(1, std::min<long long>(256, chunks / 8));
     if (g_wgrad_force_s > 0) return (int)std::min<long long>(g_wgrad_force_s, smax);
     if (wgrad_chunk32(Cout, Cin, N)) {
+        tiles = (long long)wsdl::cdiv(Cout, BM) * wsdl::cdiv(std::max(n_live, BN), BN);
         // two workgroups per CU (one 53 KB LDS image each): fill whole rounds of 512 slots
         const long long slots = 2 * kNumCU;
         long long best_s = 1;
@@ -1597,7 +1614,8 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     const int N = kh * kw * Cin;
     Band bands[8];
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
-    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW) * Cout * N * sizeof(float);
+    const int n_live = __builtin_popcountll(live_taps(H, W, OH, OW, kh, kw, stride, pad, dil)) * Cin;
+    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live) * Cout * N * sizeof(float);
     return wsdl::align_up(slabs, 256) + wgrad_dys_bytes(Cout, Cin, N, B * OH * OW);
 }
 
@@ -1628,7 +1646,8 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     p.N = kh * kw * Cin; p.P = B * OH * OW;
     p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
-    const int S = wgrad_splits(Cout, Cin, p.N, p.P);
+    const unsigned long long live_all = live_taps(H, W, OH, OW, kh, kw, stride, pad, dil);
+    const int S = wgrad_splits(Cout, Cin, p.N, p.P, __builtin_popcountll(live_all) * Cin);
     Band bands[8];
     const int nb = (g_wgrad_bk == 32) ? 1 : wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
     if (nb == 1) bands[0] = Band{0, OW};
@@ -1663,6 +1682,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         }
         return WSDL_OK;
     }
+    unsigned long long live_mask = ~0ull;
     {
         const double flops = 2.0 * p.P * (double)Cout * p.N;
         double executed = flops;
@@ -1701,6 +1721,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             // 16-pixel chunks (35 KB of LDS, 4 workgroups per CU) beat 32-pixel chunks (68 KB, 2 per CU) on all but two
             // ASPP shapes (profiles/r01_notes.md)
             if (chunk32) {
+                live_mask = live_all;            // dead taps: no workgroup writes their slab columns, the reduce skips them
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
                 const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
                 hipLaunchKernelGGL(dy_split_kernel, dim3((int)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0,
@@ -1738,14 +1759,15 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     const int T = kh * kw;
     if (T >= 2 && T <= 16 && Cout <= 65535) {
         hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw,
-                           S_total, Cout, Cin, T, accumulate);
+                           S_total, Cout, Cin, T, accumulate, live_mask);
     } else if (T == 1 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
         const long long total4 = total / 4;
         hipLaunchKernelGGL(wgrad_reduce_vec4_kernel, dim3((int)std::min<long long>((total4 + 255) / 256, 8192)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(p.slab), reinterpret_cast<float4*>(dw), S_total, total4, accumulate);
     } else {
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate,
+                           live_mask);
     }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;

@@ -538,6 +538,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     const int l31 = lane & 31, lh = lane >> 5;
     const unsigned char* Ab = As + (wm * 64 + l31) * ROW + lh * 16;
     const unsigned char* Bb = Bs + (wn * 64 + l31) * ROW + lh * 16;
+    // a tap that reads padding for EVERY output pixel (dilation >= map size: ASPP d36 on 32x32 maps keeps only the
+    // centre tap) contributes exact zeros: its workgroups leave at once
+    // (the host leaves those slab columns out of the reduce: live_taps() in conv_igemm.hip applies the same test)
+    if (t_dh >= p.H || (p.OH - 1) * p.stride + t_dh < 0 || t_dw >= p.W || (p.OW - 1) * p.stride + t_dw < 0) return;
     int c0 = next_valid(chunk_begin);
     if (c0 < chunk_end) load_tiles(c0);
     while (c0 < chunk_end) {
