@@ -184,7 +184,10 @@ def test_conv_bad_geometry_raises(dev):
 
 
 @pytest.mark.parametrize("shape,relu,res", [((4, 24, 9, 7), True, True), ((3, 64, 16, 16), True, False),
-                                            ((8, 40, 1, 1), False, False), ((2, 16, 12, 20), False, True)])
+                                            ((8, 40, 1, 1), False, False), ((2, 16, 12, 20), False, True),
+                                            # channel-resident fused kernels (C >= 192, B*HW <= 32768, HW % 4 == 0)
+                                            ((4, 256, 8, 8), True, True), ((2, 192, 16, 16), False, False),
+                                            ((3, 200, 12, 4), True, False), ((24, 192, 32, 32), True, True)])
 def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     from weaklysuperviseddl_amd import ops
     g = torch.Generator().manual_seed(11)

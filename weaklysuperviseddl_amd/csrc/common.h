@@ -52,6 +52,9 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// A/B switch (wsdl_set_option "bn_resident"): channel-resident fused BatchNorm kernels (norm_pool.hip)
+extern int g_bn_resident;
+
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
 constexpr int kReduceSlots = 4096;
 

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 
+int wsdl::g_bn_resident = 1;
+
 namespace {
 
 constexpr int kStatSplit = 32;  // max partial sums per channel (workspace stride); the count used is a fixed
@@ -199,6 +201,146 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Channel-resident BatchNorm: when one channel's B*HW values fit in the registers of one workgroup (64 per thread,
+// 256 or 512 threads: layer2-4 and the heads at B=16, 256^2), the workgroup of channel c reads them ONCE, reduces
+// the statistics, and applies the normalisation (forward) / the input gradient (backward) from registers - the
+// second pass over x (forward) and over x, dy and the ReLU mask (backward) of the two-kernel form never happens.
+// Same arithmetic: double sums, fixed reduction tree (bitwise reproducible).  grid = C.
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
+    float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
+    long long y_bs, int relu) {
+    constexpr int V = 16;                         // float4 per thread
+    __shared__ double sm[16];
+    __shared__ float bc[2];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int HW4 = HW >> 2, n4 = B * HW4;
+    float4 v[V];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i4 = tid + k * NT;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < n4) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            v[k] = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
+            a0 += (double)((v[k].x + v[k].y) + (v[k].z + v[k].w));
+            a1 += (double)v[k].x * v[k].x + (double)v[k].y * v[k].y + (double)v[k].z * v[k].z + (double)v[k].w * v[k].w;
+        }
+    }
+    a0 = block_sum_d(a0, sm);
+    a1 = block_sum_d(a1, sm);
+    if (tid == 0) {
+        const long long n = (long long)B * HW;
+        const double mean = a0 / (double)n;
+        double var = a1 / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mu = (float)mean, istd = (float)(1.0 / sqrt(var + (double)eps));
+        save_mean[c] = mu;
+        save_invstd[c] = istd;
+        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        if (rvar) {
+            const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+        bc[0] = mu;
+        bc[1] = istd;
+    }
+    __syncthreads();
+    const float mu = bc[0], g = bc[1] * gamma[c], be = beta[c];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i4 = tid + k * NT;
+        if (i4 < n4) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            float4 o = v[k];
+            o.x = (o.x - mu) * g + be; o.y = (o.y - mu) * g + be;
+            o.z = (o.z - mu) * g + be; o.w = (o.w - mu) * g + be;
+            if (res) {
+                const float4 q = *reinterpret_cast<const float4*>(res + ((long long)b * C + c) * HW + r);
+                o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+            }
+            if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = o;
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
+    float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu) {
+    constexpr int V = 16;
+    __shared__ double sm[16];
+    __shared__ float bc[2];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int HW4 = HW >> 2, n4 = B * HW4;
+    const float mu = mean[c], is = invstd[c];
+    float4 g[V], xh[V];                            // dy' = dy*[y>0] and xhat, kept for the second phase
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i4 = tid + k * NT;
+        g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[k] = g[k];
+        if (i4 < n4) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
+            float4 gv = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
+            if (relu) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
+                if (!(yv.x > 0.f)) gv.x = 0.f;
+                if (!(yv.y > 0.f)) gv.y = 0.f;
+                if (!(yv.z > 0.f)) gv.z = 0.f;
+                if (!(yv.w > 0.f)) gv.w = 0.f;
+            }
+            g[k] = gv;
+            xh[k] = make_float4((xv.x - mu) * is, (xv.y - mu) * is, (xv.z - mu) * is, (xv.w - mu) * is);
+            a0 += (double)((gv.x + gv.y) + (gv.z + gv.w));
+            a1 += (double)gv.x * xh[k].x + (double)gv.y * xh[k].y + (double)gv.z * xh[k].z + (double)gv.w * xh[k].w;
+        }
+    }
+    a0 = block_sum_d(a0, sm);
+    a1 = block_sum_d(a1, sm);
+    if (tid == 0) {
+        const long long n = (long long)B * HW;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a1 : (float)a1;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a0 : (float)a0;
+        bc[0] = (float)(a0 / (double)n);
+        bc[1] = (float)(a1 / (double)n);
+    }
+    __syncthreads();
+    const float k0 = bc[0], k1 = bc[1], gi = gamma[c] * is;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i4 = tid + k * NT;
+        if (i4 < n4) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const long long o = ((long long)b * C + c) * HW + r;
+            float4 d;
+            d.x = gi * (g[k].x - k0 - xh[k].x * k1);
+            d.y = gi * (g[k].y - k0 - xh[k].y * k1);
+            d.z = gi * (g[k].z - k0 - xh[k].z * k1);
+            d.w = gi * (g[k].w - k0 - xh[k].w * k1);
+            *reinterpret_cast<float4*>(dx + o) = d;
+            if (dres) *reinterpret_cast<float4*>(dres + o) = g[k];
+        }
+    }
+}
+
+// threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
+static int resident_threads(int C, long long n, int HW) {
+    if (!wsdl::g_bn_resident || C < 192 || (HW & 3) != 0) return 0;
+    if (n <= 256 * 64) return 256;
+    if (n <= 512 * 64) return 512;
+    return 0;
+}
+
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                float* __restrict__ scale, float* __restrict__ shift, int C) {
@@ -383,6 +525,16 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     }
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
+    if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
+        if (nt == 256)
+            hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu);
+        else
+            hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
@@ -409,6 +561,16 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!dy_bs) dy_bs = (long long)C * HW;
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
+    if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
+        if (nt == 256)
+            hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu);
+        else
+            hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
