@@ -61,7 +61,8 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (fo
        WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16> (forward + dgrad launches) */
        WSDL_PROF_SPLIT_128x64 = 14, WSDL_PROF_SPLIT_64x256 = 15, WSDL_PROF_SPLIT_64x128 = 16,
        WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128> */
-       WSDL_PROF_NCLASSES = 18 };
+       WSDL_PROF_SPLIT_256x128 = 18,   /* conv_igemm_split_kernel<256,128,4,16,512> */
+       WSDL_PROF_NCLASSES = 19 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,

@@ -38,18 +38,20 @@ constexpr int kSplitK16Bytes = 96;   // one row's 16 k values: 3 pieces x 16 bf1
 
 // One chunk of global loads is in flight in registers while the previous one is computed; deeper register rings
 // (2, 3 chunks) measured no faster - the kernel is power-limited, not latency-limited (profiles/r01_notes.md).
-template <int BM, int BN, int WM, int BK>
-__global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) {
-    constexpr int WN = 4 / WM;
+// NT threads: 256 (4 waves, two workgroups per CU) or 512 (8 waves, one 256x128 workgroup per CU: every activation
+// element is split by half as many workgroups and the weight tile is shared by twice the pixels... per FLOP).
+template <int BM, int BN, int WM, int BK, int NT = kThreads>
+__global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
+    constexpr int WN = (NT / 64) / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
     static_assert(BK == 16 || BK == 32, "K chunk");
     constexpr int KS = BK / 16;                          // MFMA k-steps per chunk
     constexpr int ROW = KS * kSplitK16Bytes + 16;        // LDS row stride in bytes (odd multiple of 16)
     constexpr int A_UPS = BM * 6;                        // 16-byte units of one k16 slab of the row tile
-    constexpr int A_U = (KS * A_UPS + kThreads - 1) / kThreads;   // units per thread per chunk
-    constexpr bool A_EXACT = A_U * kThreads == KS * A_UPS;
-    constexpr int B_STEP = kThreads / BN;                // threads sharing one pixel
+    constexpr int A_U = (KS * A_UPS + NT - 1) / NT;   // units per thread per chunk
+    constexpr bool A_EXACT = A_U * NT == KS * A_UPS;
+    constexpr int B_STEP = NT / BN;                // threads sharing one pixel
     constexpr int B_PER = BK / B_STEP;                   // consecutive k (input channels) per thread
     static_assert(B_PER == 4 || B_PER == 8 || B_PER == 16 || B_PER == 32, "B tile");
     constexpr unsigned kOOB = 0x80000000u;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
     unsigned voff_a[A_U], lds_a[A_U];
 #pragma unroll
     for (int e = 0; e < A_U; ++e) {
-        const int u = tid + e * kThreads;
+        const int u = tid + e * NT;
         const int ks = u / A_UPS, v = u - ks * A_UPS;
         const int row = v / 6, part = v - row * 6;
         voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_igemm_split_kernel(ConvP p) 
     auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int e = 0; e < A_U; ++e)
-            if (A_EXACT || tid + e * kThreads < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
+            if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
         unsigned hp[B_PER / 2], mp[B_PER / 2], lp[B_PER / 2];
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e)

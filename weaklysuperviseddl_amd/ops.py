@@ -800,7 +800,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 18
+PROF_NCLASSES = 19
 
 
 def prof_class_name(cls):
