@@ -1208,6 +1208,7 @@ void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
 }
 
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
+                          // (128x256 measured 1 % behind it)
 void launch_split_256x128(const ConvP& p, hipStream_t s) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512>), grid, dim3(512), 0, s, p);
