@@ -58,7 +58,7 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (fo
        WSDL_PROF_WGRAD_FAST_128x128 = 10,  /* conv_wgrad_fast_kernel<128,128,2> */
        WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12,
        /* bf16x3-split kernels (six bf16 MFMAs per fp32 product; work counted in fp32-equivalent FLOPs) */
-       WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16> (forward + dgrad launches) */
+       WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16,256> (forward + dgrad launches) */
        WSDL_PROF_SPLIT_128x64 = 14, WSDL_PROF_SPLIT_64x256 = 15, WSDL_PROF_SPLIT_64x128 = 16,
        WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128> */
        WSDL_PROF_SPLIT_256x128 = 18,   /* conv_igemm_split_kernel<256,128,4,16,512> */

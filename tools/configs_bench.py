@@ -46,6 +46,7 @@ N = 64
 img, masks = bench.synthetic_batch(N, 256, 256, dev, 3)
 masks255 = masks * 255
 refine_pseudo_masks_batched(model, img[:8], masks255[:8], num_steps=2)
+refine_pseudo_masks_batched(model, img, masks255, threshold=0.3, lr=1e-4, num_steps=10)     # allocator warm-up at N
 torch.cuda.synchronize()
 t = time.perf_counter()
 out = refine_pseudo_masks_batched(model, img, masks255, threshold=0.3, lr=1e-4, num_steps=10)
