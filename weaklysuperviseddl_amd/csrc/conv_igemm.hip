@@ -1309,7 +1309,8 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         }
     }
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
-    const bool t256 = cfg == 0 && split && g_tile256 &&
+    // 256-row tiles only where the rows fill them (>= 90 %: not for 128-channel outputs)
+    const bool t256 = cfg == 0 && split && g_tile256 && p.Cout * 10 >= wsdl::cdiv(p.Cout, 256) * 256 * 9 &&
                       (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 256) * p.ksplit >= 256;
     wsdl::ProfScope prof(t256 ? WSDL_PROF_SPLIT_256x128
                               : split ? WSDL_PROF_SPLIT_128x128 + cfg : WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1),
