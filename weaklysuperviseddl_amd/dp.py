@@ -119,7 +119,11 @@ class GradBucketReducer:
         if self.world > 1:
             for b in range(len(self.bucket_size)):
                 self._launch(b)
-            for i in sorted(self._excluded & self._fired):
+            late = sorted(self._excluded & self._fired)
+            if late and opt.flat_grad.is_cuda:
+                from . import ops
+                ops.join_side_stream(opt.flat_grad.device)      # their weight gradients were written on the side stream
+            for i in late:
                 off, n = opt.offsets[i], opt.params[i].numel()
                 self._pending.append(dist.all_reduce(opt.flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
