@@ -3,22 +3,33 @@
 
 One "step" = one pass of the hot path over one synthetic batch: DeepLabV3-ResNet50 forward (aux head
 included, as the reference computes it), 2-class cross-entropy, backward, Adam - fp32, inputs resident
-in HBM before the timed region.  N > 1: one process per GPU (torchrun), the batch of 16 is PER GPU
-(weak scaling), gradients all-reduced over RCCL in 4 buckets overlapped with backward.
+in HBM before the timed region.  N > 1: one process per GPU, the batch of 16 is PER GPU (weak scaling),
+gradients all-reduced over RCCL in 4 buckets overlapped with backward.
+
+Launching: ``python bench.py --gpus N`` from a bare shell starts its own N ranks (child processes, before
+this process touches the GPU) and prints rank 0's JSON line; under ``torchrun`` (WORLD_SIZE set) it is one
+rank.  ``--config cfg2|cfg3|cfg4|cfg5`` selects the other BASELINE.json configurations (parity / rehearsal
+cases; the default cfg2 is the metric's):
+  cfg3  B=32/GPU 256x256, CE + 0.1 * LocalNormalizedCutLoss(sigma 0.1, w 5) on the logits
+  cfg4  two-stage: LayerCAM -> pseudo masks on 16 x 224x224 per GPU -> in-memory hand-off (NEAREST 224->256) ->
+        one training step on them; every step is the whole chain
+  cfg5  B=8/GPU 512x512, CE + 0.1 * NCut + 0.1 * ConstrainToBoundaryLoss(sigma_c 0.1, sigma_s 5)
 
 Prints ONE JSON line (rank 0).  Besides the contract keys:
   roofline     - the dominant kernel class (by summed device time): algorithmic FLOPs of its launches
-                 divided by their summed HIP-event durations, against the fp32 MFMA peak (157.3 TFLOP/s).
-                 Taken in a second, instrumented pass of the same K steps (event records around every
-                 launch would perturb `value`); `kernels` lists every instrumented class.
+                 divided by their summed HIP-event durations.  Taken in a second, instrumented pass of the same K
+                 steps (event records around every launch would perturb `value`); `kernels` lists every class.
   cpu_baseline - the CPU oracle (PyTorch CPU restatement, kind "port") timed on this box's host cores on a
-                 bounded sample (B=4 of the same workload), rank 0, N=1 only.
+                 bounded sample of the same workload (cfg2: the full B=16 step, 1 warm-up + 3 timed), rank 0, N=1.
   cam          - secondary metric of BASELINE.json ("CAM ms/img"): FrozenResNetCAM forward + class-logit
-                 backward + LayerCAM epilogue + threshold on 8 x 224x224, batched.
+                 backward + LayerCAM epilogue + threshold on 8 x 224x224, batched; with its own roofline and CPU
+                 baselines (the reference's per-image B=1 loop form, and batched).
+  ncut         - the pairwise-affinity loss kernel at cfg3 size beside the oracle's 24-slice formulation on the CPU.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,6 +44,18 @@ BF16_MFMA_PEAK_TFLOPS = 2516.6         # MI355X_MICROARCH.md: ~2.5 PF dense = 25
 HBM_PEAK_GBS = 8000.0
 # nominal dense FLOPs per image, DeepLabV3-R50 at 256x256, fwd (with aux) + bwd
 GFLOP_PER_IMG_256 = 250.2
+# FrozenResNetCAM at 224x224: forward 12.4 GFLOP + the part of the class-logit backward LayerCAM consumes
+# (fc, avgpool, layer4 down to layer3's output) ~5.9 GFLOP
+CAM_GFLOP_PER_IMG = 18.3
+
+CONFIGS = {
+    "cfg2": dict(batch=16, size=256, what="fwd + CrossEntropy + bwd + Adam (BASELINE configs[1])"),
+    "cfg3": dict(batch=32, size=256, what="fwd + CrossEntropy + 0.1*LocalNormalizedCutLoss(0.1, 5) + bwd + Adam (BASELINE configs[2])"),
+    "cfg4": dict(batch=16, size=256, what="LayerCAM -> pseudo masks (16 x 224x224, thresh 0.3, keep_largest) -> in-memory "
+                                          "hand-off -> fwd + CrossEntropy + bwd + Adam on them (BASELINE configs[3])"),
+    "cfg5": dict(batch=8, size=512, what="fwd + CrossEntropy + 0.1*NCut + 0.1*ConstrainToBoundaryLoss(0.1, 5) + bwd + Adam "
+                                         "(BASELINE configs[4])"),
+}
 
 
 def synthetic_batch(B, H, W, device, seed):
@@ -46,6 +69,17 @@ def synthetic_batch(B, H, W, device, seed):
     m = torch.nn.functional.avg_pool2d(m, 9, 1, 4)
     masks = (m[:, 0] > 0.5).long()
     return img.to(device), masks.to(device)
+
+
+def smooth_images(B, H, W, seed):
+    """Piece-wise smooth RGB in [0,1] (the pairwise losses carry no signal on iid-uniform pixels)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, H), torch.linspace(0, 1, W), indexing="ij")
+    f = torch.rand(B, 3, 4, 3, generator=g) * torch.tensor([3.0, 3.0, 6.28])
+    img = torch.zeros(B, 3, H, W)
+    for k in range(4):
+        img += 0.25 * torch.sin(6.28 * (f[:, :, k, 0, None, None] * yy + f[:, :, k, 1, None, None] * xx) + f[:, :, k, 2, None, None])
+    return (img * 0.5 + 0.5 + 0.01 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1)
 
 
 def sync_all(world):
@@ -71,6 +105,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch (fetch + write) of `kernel` from the committed rocprofv3 --pmc passes of this command
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x 2 - gfx950 counts half of a coalesced read, calibrated on a
@@ -83,7 +127,23 @@ def pmc_traffic(kernel):
     return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
 
 
-def cpu_baseline(B, H, W, steps=2):
+# ------------------------------------------------------------------------------------------ CPU baselines (oracle)
+def _timed(fn, warm, steps, what):
+    for _ in range(warm):
+        fn()
+    log(f"cpu_baseline: {what}: warm-up done")
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        log(f"cpu_baseline: {what}: timed iteration {len(ts)}/{steps} {ts[-1]:.2f} s")
+    ts.sort()
+    return ts[len(ts) // 2]                                   # median
+
+
+def cpu_baseline(B, H, W, extra=None, steps=3):
+    """BASELINE.md section 4 item 1 (item 4 at cfg5 size): the oracle's training step on the host cores."""
     import oracle
     torch.manual_seed(0)
     threads = host_cores()
@@ -95,24 +155,77 @@ def cpu_baseline(B, H, W, steps=2):
     def one():
         out = model(img)["out"]
         loss = torch.nn.functional.cross_entropy(out, torch.clamp(masks, max=1))
+        if extra is not None:
+            loss = loss + extra(out, img)
         opt.zero_grad()
         loss.backward()
         opt.step()
 
-    log(f"cpu_baseline: oracle on {threads} threads, B={B}")
-    one()                                  # warm-up
-    log("cpu_baseline: warm-up step done")
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-        log("cpu_baseline: timed step done")
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(B / dt, 4), "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": f"oracle SegmentationModel fwd+CE+bwd+Adam, B={B} {H}x{W}, 1 warm-up + {steps} timed steps, "
-                      f"torch CPU {torch.__version__} on {threads} threads"}
+    dt = _timed(one, 1, steps, f"oracle train step B={B} {H}x{W} on {threads} threads")
+    return {"value": round(B / dt, 4), "unit": "img/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "sample": f"oracle SegmentationModel fwd+loss+bwd+Adam, B={B} {H}x{W} (the full batch of the workload), 1 warm-up + "
+                      f"{steps} timed steps, median; torch CPU {torch.__version__} on {threads} threads"}
 
 
-def cam_bench(device, iters=5):
+def cam_cpu_baselines(n_img=8):
+    """oracle FrozenResNetCAM + LayerCAM + threshold + keep_largest on 8 x 224x224, in the
+    reference's per-image B=1 loop form (PsuedoMasks.py:47-65) and batched."""
+    import oracle
+    torch.manual_seed(0)
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    model = oracle.FrozenResNetCAM(37)
+    g = torch.Generator().manual_seed(3)
+    for m in model.modules():
+        if hasattr(m, "running_mean"):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    model.eval()
+    gen = oracle.LayerCAMGenerator(model, ["layer3", "layer4"])
+    imgs = torch.rand(n_img, 3, 224, 224, generator=g)
+    cls = torch.arange(n_img) % 37
+
+    def loop():
+        for i in range(n_img):
+            cam = gen.generate(imgs[i], alpha=1.0, class_idx=cls[i:i + 1])
+            oracle.keep_largest(oracle.cam_to_mask(cam[0], 0.3))
+
+    def batched():
+        cam = gen.generate(imgs, alpha=1.0, class_idx=cls)
+        for i in range(n_img):
+            oracle.keep_largest(oracle.cam_to_mask(cam[i], 0.3))
+
+    t_loop = _timed(loop, 1, 3, "oracle CAM per-image loop")
+    t_bat = _timed(batched, 1, 3, "oracle CAM batched")
+    base = {"unit": "ms/img", "cores": threads, "kind": "port", "cpu": cpu_model()}
+    return {"per_image_loop": dict(base, value=round(t_loop / n_img * 1e3, 3),
+                                   sample=f"oracle FrozenResNetCAM fwd + class-logit bwd (to the image, as the reference) + LayerCAM "
+                                          f"+ threshold + keep_largest, {n_img} x 224x224 one image per call, 1 warm-up + 3 timed, median"),
+            "batched": dict(base, value=round(t_bat / n_img * 1e3, 3),
+                            sample=f"same, one batch of {n_img}")}
+
+
+def ncut_cpu_baseline(B, H, W, steps=2):
+    """LocalNormalizedCutLoss fwd+bwd in the reference's 24-slice formulation."""
+    import oracle
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    img = smooth_images(B, H, W, 5)
+    preds = torch.randn(B, 2, H, W, generator=torch.Generator().manual_seed(6)).requires_grad_()
+    crit = oracle.LocalNormalizedCutLoss(0.1, 5)
+
+    def one():
+        preds.grad = None
+        crit(preds, img).backward()
+
+    dt = _timed(one, 1, steps, f"oracle NCut fwd+bwd ({B},2,{H},{W})")
+    return {"value": round(dt * 1e3, 2), "unit": "ms/step", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "sample": f"oracle LocalNormalizedCutLoss(0.1, 5) fwd+bwd, preds ({B},2,{H},{W}), 24-slice formulation "
+                      f"(AlternatingDirectionCutLoss.py:87-101), 1 warm-up + {steps} timed, median"}
+
+
+# ------------------------------------------------------------------------------------------ secondary GPU legs
+def cam_setup(device, n_img=8):
     from weaklysuperviseddl_amd.TraditionalModel import FrozenResNetCAM, LayerCAMGenerator
     torch.manual_seed(0)
     model = FrozenResNetCAM(37)
@@ -123,8 +236,28 @@ def cam_bench(device, iters=5):
             m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
     model = model.to(device).eval()
     gen = LayerCAMGenerator(model, ["layer3", "layer4"])
-    imgs = torch.rand(8, 3, 224, 224, generator=g).to(device)
-    cls = (torch.arange(8) % 37).to(device)
+    imgs = torch.rand(n_img, 3, 224, 224, generator=g).to(device)
+    cls = (torch.arange(n_img) % 37).to(device)
+    return gen, imgs, cls
+
+
+def conv_class_totals(ops):
+    """(ms, nominal flop, executed flop, split-kernel executed flop) summed over the instrumented conv classes."""
+    ms = work = exe = exe_split = 0.0
+    for c in range(ops.PROF_NCLASSES):
+        n, t, w, e, _ = ops.prof_collect(c)
+        name = ops.prof_class_name(c)
+        if n and "conv" in name:
+            ms, work, exe = ms + t, work + w, exe + e
+            if "split" in name:
+                exe_split += e
+    return ms, work, exe, exe_split
+
+
+def cam_bench(device, iters=5, roofline=True):
+    from weaklysuperviseddl_amd import ops
+    gen, imgs, cls = cam_setup(device)
+    n_img = imgs.shape[0]
     for _ in range(2):
         gen.generate_batch(imgs, 1.0, cls, thresh=0.3)
     torch.cuda.synchronize()
@@ -133,8 +266,138 @@ def cam_bench(device, iters=5):
         gen.generate_batch(imgs, 1.0, cls, thresh=0.3)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
-    return {"ms_per_img": round(ms / 8, 4), "batch": 8, "size": 224,
-            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
+    out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
+           "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
+    if roofline:
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for _ in range(iters):
+            gen.generate_batch(imgs, 1.0, cls, thresh=0.3)
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        kms, work, exe, exe_split = conv_class_totals(ops)
+        ops.prof_reset()
+        # whole-leg figure: needed-only FLOPs of the leg / its wall time; conv-kernel figure: executed FLOPs / event time
+        leg_tf = CAM_GFLOP_PER_IMG * n_img / ms                        # GFLOP / ms = TFLOP/s (fp32-equivalent)
+        conv_tf = exe / (kms * 1e-3) / 1e12 if kms else 0.0
+        out["roofline"] = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "achieved": round(6.0 * leg_tf, 3), "frac": round(6.0 * leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "achieved_fp32_equivalent": round(leg_tf, 3),
+                           "conv_kernels_fp32_equivalent": round(conv_tf, 3),
+                           "conv_kernels_frac": round(6.0 * conv_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "conv_kernel_ms_per_batch": round(kms / iters, 4),
+                           "gflop_per_img": CAM_GFLOP_PER_IMG, "traffic": None,
+                           "note": "needed-only FLOPs (forward 12.4 + backward to layer3's output 5.9 GFLOP/img) x 6 bf16 MFMA "
+                                   "products per fp32 product / wall time of the whole leg, against the dense bf16 MFMA peak; "
+                                   "conv_kernels_* = executed FLOPs of the instrumented conv launches / their HIP-event time"}
+    return out
+
+
+def ncut_bench(device, B=32, H=256, W=256, reps=20):
+    from weaklysuperviseddl_amd import ops
+    img = smooth_images(B, H, W, 5).to(device)
+    preds = torch.randn(B, 2, H, W, generator=torch.Generator().manual_seed(6)).to(device).requires_grad_()
+    for _ in range(3):
+        ops.pairwise_affinity_loss(preds, img, 5, 0.1, 0.0, True, 0)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        ops.pairwise_affinity_loss(preds, img, 5, 0.1, 0.0, True, 0)      # forward AND gradient: one fused launch
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) / reps * 1e3
+    px = B * H * W
+    return {"us_fwd_bwd": round(us, 2), "shape": [B, 2, H, W],
+            "roofline": {"bound": "hbm", "achieved": round(28 * px / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(28 * px / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "28 B/px algorithmic (20 read + 8 gradient write, C=2), fused forward + backward launch"}}
+
+
+# ------------------------------------------------------------------------------------------ launching
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` from a bare shell: start N ranks as child processes BEFORE anything here touches
+    the GPU (no re-exec of a process that has initialised HIP), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    n = args.gpus
+    ndev = torch.cuda.device_count()              # does not initialise the GPU on this image
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    if ndev < n:
+        # rehearsal: fewer GPUs than ranks - ranks share the devices, the collectives go over gloo
+        if n > 6 * max(ndev, 1):
+            raise SystemExit(f"--gpus {n}: only {ndev} GPU(s) here and at most 6 processes may share one")
+        env.setdefault("WSDL_DIST_BACKEND", "gloo")
+        log(f"{ndev} GPU(s) for {n} ranks: rehearsal over gloo, ranks share the device(s)")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = []
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=3000))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench ranks exited with {rcs}")
+
+
+def build_workload(cfg, B, S, device, rank):
+    """-> (step callable returning the loss tensor, description)."""
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import (build_segmentation_model, train_step, LocalNormalizedCutLoss,
+                                                         ConstrainToBoundaryLossSingle)
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    torch.manual_seed(0)                       # identical weights on every rank
+    model = build_segmentation_model().to(device).train()
+    opt = make_optimizer(model, lr=1e-4)
+    extra = None
+    if cfg in ("cfg3", "cfg5"):
+        ncut = LocalNormalizedCutLoss(0.1, 5)
+        if cfg == "cfg3":
+            extra = lambda o, i: 0.1 * ncut(o, i)                                                        # noqa: E731
+        else:
+            bnd = ConstrainToBoundaryLossSingle(0.1, 5, 5)
+            extra = lambda o, i: 0.1 * ncut(o, i) + 0.1 * bnd(ops.softmax_channels(o), i).mean()         # noqa: E731
+    if cfg == "cfg4":
+        from weaklysuperviseddl_amd.TraditionalModel import generate_pseudo_masks, stage_handoff
+        gen, _, _ = cam_setup(device, 1)
+        g = torch.Generator().manual_seed(100 + rank)
+        imgs224 = torch.rand(B, 3, 224, 224, generator=g)               # stage-1 inputs, un-normalised (SURVEY 8d)
+        labels = (torch.arange(B) + rank) % 37
+        loader = [(imgs224.to(device), (labels, None))]
+
+        def step():
+            generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=device)
+            masks = generate_pseudo_masks.last_masks
+            img, m = stage_handoff(loader[0][0], masks, (S, S), device)
+            return train_step(model, opt, img, m.long())
+    else:
+        if cfg == "cfg2":
+            img, masks = synthetic_batch(B, S, S, device, 1 + rank)
+        else:
+            # the pairwise losses need piece-wise smooth images (SURVEY.md 8d)
+            _, masks = synthetic_batch(B, S, S, device, 1 + rank)
+            mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+            std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+            img = ((smooth_images(B, S, S, 11 + rank) - mean) / std).to(device)
+
+        def step():
+            return train_step(model, opt, img, masks, extra)
+    return model, opt, step, extra
 
 
 def main():
@@ -142,8 +405,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the config's)")
+    ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cam", action="store_true")
@@ -152,15 +416,18 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="no side-stream overlap anywhere: every kernel has the chip to itself (profiling aid; the "
                          "roofline pass always runs like this)")
+    ap.add_argument("--graph", type=int, default=None, help="1/0: force hipGraph replay of the training step on/off")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args, sys.argv[1:])
+        return
 
     from weaklysuperviseddl_amd import ops
     for kv in [x for x in args.opt.split(",") if x]:
         k, v = kv.split("=")
         ops.set_option(k, int(v))
     from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
-    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
-    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
 
     if args.cam_only:
         print(json.dumps({"cam": cam_bench(torch.device("cuda", 0), iters=10)}), flush=True)
@@ -169,24 +436,20 @@ def main():
         ops.OVERLAP_WGRAD[0] = False
     rank, local, world = init_distributed()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev_index = local % torch.cuda.device_count()     # == local on a full node; rehearsal boxes have fewer GPUs
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
 
-    torch.manual_seed(0)                       # identical weights on every rank
-    model = build_segmentation_model().to(device).train()
-    opt = make_optimizer(model, lr=1e-4)
-    reducer = GradBucketReducer(opt) if world > 1 else None
-    B, S = args.batch, args.size
-    img, masks = synthetic_batch(B, S, S, device, 1 + rank)
-
-    def step():
-        return train_step(model, opt, img, masks)
+    cfg = args.config
+    B = args.batch or CONFIGS[cfg]["batch"]
+    S = args.size or CONFIGS[cfg]["size"]
+    model, opt, step, extra = build_workload(cfg, B, S, device, rank)
+    reducer = GradBucketReducer(opt, modules=[model]) if world > 1 else None   # noqa: F841  (hooks live on the optimizer)
 
     if rank == 0:
-        log(f"model on {device}, world={world}, B={B}, {S}x{S}; warm-up {args.warmup} steps")
+        log(f"{cfg} on {device}, world={world}, B={B}, {S}x{S}; warm-up {args.warmup} steps")
     for i in range(args.warmup):
         step()
         if rank == 0 and i == 0:
@@ -195,11 +458,14 @@ def main():
     sync_all(world)
     if rank == 0:
         log(f"timing {args.steps} steps")
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_issue_s = time.perf_counter() - t0           # the host has enqueued the K steps
     sync_all(world)
     dt = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,18 +476,25 @@ def main():
         log(f"{ms_per_step:.2f} ms/step, {value:.1f} img/s")
     loss_val = float(loss.item())
 
+    metric = ("SegmentationModel train img/s at B=16 256x256" if cfg == "cfg2"
+              else f"SegmentationModel train img/s, {cfg} (B={B} {S}x{S})")
     result = {
-        "metric": "SegmentationModel train img/s at B=16 256x256",
+        "metric": metric,
         "value": round(value, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"DeepLabV3-ResNet50 (SegmentationModel, aux head computed) fwd + CrossEntropy + bwd + Adam, "
-                               f"B={B}/GPU {S}x{S}x3, random-init weights, live dropout (BASELINE configs[1])",
+        "config": {"workload": f"{cfg}: DeepLabV3-ResNet50 (SegmentationModel, aux head computed) {CONFIGS[cfg]['what']}, "
+                               f"B={B}/GPU {S}x{S}x3, random-init weights, live dropout",
                    "arithmetic": "fp32 tensors; conv products as 6 bf16 MFMAs on exact 3-way bf16 splits of both operands, "
                                  "fp32 accumulate (fp32-level accuracy, tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
                    "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
+                   "backend": (dist.get_backend() if world > 1 else None),
                    "final_loss": round(loss_val, 5)},
+        "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5), "issue_ms_per_step": round(host_issue_s / args.steps * 1e3, 3),
+                 "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
     }
+    if world > 1:
+        result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches}
 
     if not args.no_roofline:
         # instrumented pass: same steps on every rank (the collectives must match), HIP events around every
@@ -283,11 +556,27 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        if world == 1 and not args.no_cam:
+        secondary = world == 1 and cfg == "cfg2"
+        if secondary and not args.no_cam:
             log("cam bench")
-            result["cam"] = cam_bench(device)
+            result["cam"] = cam_bench(device, roofline=not args.no_roofline)
+            result["ncut"] = ncut_bench(device)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(4, S, S)
+            # oracle twin of the extra loss terms of cfg3 / cfg5 (cfg4's CPU leg is the cfg2 step + the CAM legs)
+            cpu_extra = None
+            if cfg in ("cfg3", "cfg5"):
+                import oracle
+                o_ncut = oracle.LocalNormalizedCutLoss(0.1, 5)
+                o_bnd = oracle.ConstrainToBoundaryLossSingle(0.1, 5, 5)
+                if cfg == "cfg3":
+                    cpu_extra = lambda o, i: 0.1 * o_ncut(o, i)                                            # noqa: E731
+                else:
+                    cpu_extra = lambda o, i: 0.1 * o_ncut(o, i) + 0.1 * torch.stack(                       # noqa: E731
+                        [o_bnd(torch.softmax(o[b], 0), i[b]) for b in range(o.shape[0])]).mean()
+            result["cpu_baseline"] = cpu_baseline(B, S, S, cpu_extra, steps=3 if cfg == "cfg2" else 1)
+            if secondary and not args.no_cam:
+                result["cam"]["cpu_baseline"] = cam_cpu_baselines()
+                result["ncut"]["cpu_baseline"] = ncut_cpu_baseline(32, 256, 256)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,268 @@
+"""Data parallelism THROUGH THE HIP PATH: two ranks sharing one GPU over gloo
+(``WSDL_DIST_BACKEND=gloo``; on an 8-GPU node the same code runs over RCCL).  Checked:
+  * gradients written directly into the flat buffer by the HIP backward kernels (``grad_ready_hooks``), bucket
+    all-reduces enqueued from the side stream: reduced flat_grad == sum of the per-shard single-process gradients;
+  * buckets leave from backward hooks (before ``wait()``) from the second step on; replicas stay identical;
+  * stage 1 (CAM -> pseudo masks) sharded round-robin over the ranks: union == single-process masks, bit-exact;
+  * the alternating loop under DP with unequal shard sizes: same number of optimiser steps on every rank.
+Children are fresh processes (``mp.spawn``) that pick their device before any other GPU call."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), WSDL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.set_num_threads(2)
+    torch.cuda.set_device(0)
+
+
+def _seg_model(device, seed=0):
+    from weaklysuperviseddl_amd import nn as wnn
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model
+    torch.manual_seed(seed)
+    model = build_segmentation_model()
+    for m in model.modules():
+        if isinstance(m, wnn.Dropout):
+            m.p = 0.0
+    return model.to(device).train()
+
+
+def _shard(rank, B=2, S=64):
+    import bench
+    img, masks = bench.synthetic_batch(2 * B, S, S, "cpu", 7)
+    return img[rank * B:(rank + 1) * B], masks[rank * B:(rank + 1) * B]
+
+
+def _grads_only(model, opt, img, masks):
+    from weaklysuperviseddl_amd import ops
+    out = model(img)["out"]
+    loss = ops.cross_entropy(out, masks)
+    opt.zero_grad()
+    loss.backward()
+    return loss
+
+
+def _worker_train(rank, world, port, out):
+    _env(rank, world, port)
+    import torch.distributed as dist
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    dev = torch.device("cuda:0")
+    init_distributed()
+    assert dist.get_backend() == "gloo"
+    model = _seg_model(dev, seed=rank)                 # different seeds: the reducer must broadcast rank 0's weights
+    opt = make_optimizer(model, lr=1e-4)
+    red = GradBucketReducer(opt, modules=[model])
+    img, masks = (t.to(dev) for t in _shard(rank))
+    _grads_only(model, opt, img, masks)
+    early0 = sum(red._launched)
+    red.wait()
+    ops.join_side_stream(dev)
+    torch.cuda.synchronize()
+    reduced = opt.flat_grad.detach().cpu().clone()
+    excluded = len(red._excluded)
+    early = []
+    for _ in range(3):                                 # full steps: hooks, side-stream collectives, Adam, weight prefetch
+        train_step(model, opt, img, masks)
+        early.append(red.last_early_launches)
+    torch.cuda.synchronize()
+    params = opt.flat_param.detach().cpu()
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    if rank == 0:
+        torch.save({"reduced": reduced, "early0": early0, "early": early, "excluded": excluded, "params": gathered,
+                    "buckets": len(red.bucket_size)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hip_dp_reduced_gradients_equal_the_sum_of_the_shard_gradients(dev, tmp_path):
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_train, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    total = None
+    for r in range(2):
+        model = _seg_model(dev, seed=0)
+        opt = make_optimizer(model, lr=1e-4)
+        img, masks = (t.to(dev) for t in _shard(r))
+        _grads_only(model, opt, img, masks)
+        ops.join_side_stream(dev)
+        torch.cuda.synchronize()
+        g = opt.flat_grad.detach().cpu().clone()
+        total = g if total is None else total + g
+    scale = total.abs().max().item()
+    assert scale > 0
+    # the kernels are deterministic and the sum of two terms is order-free: equal to fp32 rounding
+    assert (got["reduced"] - total).abs().max().item() <= 1e-6 * scale
+    assert got["buckets"] == 4 and got["excluded"] > 0            # the aux head was learnt to be unused
+    # step 0 has to wait for the aux head (nothing is known yet); afterwards every bucket leaves from a hook
+    assert got["early"][0] >= 1 and got["early"][-1] == got["buckets"]
+    assert torch.equal(got["params"][0], got["params"][1])       # replicas stay bit-identical
+
+
+def _cam_loader(n_batches=4, B=2):
+    g = torch.Generator().manual_seed(41)
+    return [(torch.rand(B, 3, 224, 224, generator=g), ((torch.arange(B) + 5 * j) % 37, None)) for j in range(n_batches)]
+
+
+def _cam_generator(device):
+    from weaklysuperviseddl_amd.TraditionalModel import FrozenResNetCAM, LayerCAMGenerator
+    torch.manual_seed(0)
+    model = FrozenResNetCAM(37)
+    g = torch.Generator().manual_seed(3)
+    for m in model.modules():
+        if hasattr(m, "running_mean"):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    return LayerCAMGenerator(model.to(device).eval(), ["layer3", "layer4"])
+
+
+def _worker_stage1(rank, world, port, out):
+    _env(rank, world, port)
+    import torch.distributed as dist
+    from weaklysuperviseddl_amd.dp import init_distributed
+    from weaklysuperviseddl_amd.TraditionalModel import generate_pseudo_masks
+    init_distributed()
+    gen = _cam_generator(torch.device("cuda:0"))
+    generate_pseudo_masks(_cam_loader(), gen, cam_thresh=0.3, write_png=False, max_images=7, rank=rank, world=world)
+    mine = (generate_pseudo_masks.last_ids, generate_pseudo_masks.last_masks)
+    both = [None] * world
+    dist.all_gather_object(both, mine)
+    if rank == 0:
+        torch.save(both, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_sharded_over_ranks_equals_single_process(dev, tmp_path):
+    from weaklysuperviseddl_amd.TraditionalModel import generate_pseudo_masks
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_stage1, args=(2, _free_port(), out), nprocs=2, join=True)
+    both = torch.load(out, weights_only=False)
+    generate_pseudo_masks(_cam_loader(), _cam_generator(dev), cam_thresh=0.3, write_png=False, max_images=7)
+    ids, masks = generate_pseudo_masks.last_ids, generate_pseudo_masks.last_masks
+    assert ids == list(range(7))                                   # the cap cuts the last batch (PsuedoMasks.py:49)
+    assert sorted(both[0][0] + both[1][0]) == ids and not set(both[0][0]) & set(both[1][0])
+    assert both[0][0] == [0, 1, 4, 5] and both[1][0] == [2, 3, 6]  # batch j -> rank j % 2
+    union = {i: m for r in range(2) for i, m in zip(*both[r])}
+    for i, m in zip(ids, masks):
+        assert np.array_equal(union[i], m), i                      # bit-exact: same batches, deterministic kernels
+    assert sum(int(m.sum()) for m in masks) > 0
+
+
+def test_stage_handoff_equals_the_png_round_trip(dev, tmp_path):
+    """In-memory stage-1 -> stage-2 hand-off vs the reference's files (PsuedoMasks.py:68-74 -> SegmentationDataset.py)."""
+    from weaklysuperviseddl_amd.TraditionalModel import (generate_pseudo_masks, stage_handoff, PseudoSegmentationDataset)
+    gen = _cam_generator(dev)
+    loader = _cam_loader(2, 3)
+    img_dir, mask_dir = generate_pseudo_masks(loader, gen, cam_thresh=0.3, out_root=str(tmp_path), run_id="t",
+                                              write_png=True, keep_images=True)
+    masks, images = generate_pseudo_masks.last_masks, torch.stack(generate_pseudo_masks.last_images)
+    im256, m256 = stage_handoff(images, masks, (256, 256), dev)
+    ds = PseudoSegmentationDataset(img_dir, mask_dir, transform=True, return_name=True)
+    order = sorted(range(6), key=lambda i: f"{i}.png")             # sorted(listdir): "0.png", "1.png", ...
+    for k, i in enumerate(order):
+        img, mask, name = ds[k]
+        assert name == f"{i}.png"
+        assert torch.equal(m256[i].cpu().long(), mask)             # NEAREST 224 -> 256 of the {0,255} PNG
+        # PIL resamples 8-bit values in fixed point: one 8-bit level (1/255/std <= 0.0175) at most
+        assert (im256[i].cpu() - img).abs().max().item() <= 1.0 / 255 / 0.224 + 1e-5
+        assert ((im256[i].cpu() - img).abs() > 1e-5).float().mean().item() < 0.02
+    assert set(np.unique(m256.cpu().numpy())) <= {0, 255}
+
+
+def _toy_dataset(device, n, seed):
+    from conftest import smooth_image
+    from weaklysuperviseddl_amd.TraditionalModel import InMemoryPseudoDataset
+    img = smooth_image(n, 64, 64, seed)
+    masks = (img[:, 0] > 0.5).to(torch.uint8) * 255
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return InMemoryPseudoDataset(((img - mean) / std).to(device), masks.to(device))
+
+
+def test_alternating_loop_chains_refinement_in_memory(dev):
+    """Outer loop of reference AlternatingDirectionCutLoss.py:791-818 on a toy shard: train <-> chained refinement."""
+    from weaklysuperviseddl_amd.TraditionalModel import (run_alternating_training, refine_dataset,
+                                                         refine_pseudo_masks_batched)
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    model = _seg_model(dev)
+    opt = make_optimizer(model, lr=1e-4)
+    ds = _toy_dataset(dev, 6, 3)
+    m0 = ds.masks.clone()
+    logs = []
+    hist = run_alternating_training(model, opt, ds, num_alternations=2, epochs_per_round=2, refine_repeats=2,
+                                    first_batch_size=4, later_batch_size=6, refine_chunk=4, log=logs.append,
+                                    refine_kwargs=dict(lr=0.5, num_steps=5))
+    assert len(hist) == 2 and all(len(h["losses"]) == 2 for h in hist)
+    assert all(np.isfinite(t.item()) for h in hist for t in h["losses"])
+    assert opt.step_count == 2 * 2 + 2 * 1                          # 6 images: batches of 4+2, then one batch of 6
+    assert set(np.unique(ds.masks.cpu().numpy())) <= {0, 255} and not torch.equal(ds.masks, m0)
+    assert logs[-1] == "Alternating training and pseudo mask updates completed."
+    # refine_dataset == the reference's chain: pass r+1 starts from pass r's thresholded {0,255} masks
+    ds2 = _toy_dataset(dev, 6, 3)
+    want = ds2.masks.clone()
+    for _ in range(2):
+        r = refine_pseudo_masks_batched(model, ds2.images, want, threshold=0.3, lr=0.5, num_steps=5, lambda_boundary=0.1)
+        want = (r > 0).to(torch.uint8) * 255
+    refine_dataset(model, ds2, repeats=2, chunk=4, threshold=0.3, lr=0.5, num_steps=5, lambda_boundary=0.1)
+    assert torch.equal(ds2.masks, want)
+
+
+def _worker_alternating(rank, world, port, out):
+    _env(rank, world, port)
+    import torch.distributed as dist
+    from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
+    from weaklysuperviseddl_amd.TraditionalModel import run_alternating_training
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    dev = torch.device("cuda:0")
+    init_distributed()
+    model = _seg_model(dev)
+    opt = make_optimizer(model, lr=1e-4)
+    GradBucketReducer(opt, modules=[model])
+    ds = _toy_dataset(dev, 5 if rank == 0 else 3, 20 + rank)        # unequal shards: 3 vs 2 batches of 2
+    run_alternating_training(model, opt, ds, num_alternations=1, epochs_per_round=2, refine_repeats=1,
+                             first_batch_size=2, refine_chunk=4, log=None, refine_kwargs=dict(num_steps=2))
+    torch.cuda.synchronize()
+    params = opt.flat_param.detach().cpu()
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    dist.all_gather(gathered, params)
+    steps = [None] * world
+    dist.all_gather_object(steps, opt.step_count)
+    if rank == 0:
+        torch.save({"params": gathered, "steps": steps}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_alternating_loop_under_dp_takes_the_same_steps_on_every_rank(dev, tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_alternating, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    assert got["steps"] == [2, 2]                                  # min(2, 1) batches per epoch x 2 epochs
+    assert torch.equal(got["params"][0], got["params"][1])

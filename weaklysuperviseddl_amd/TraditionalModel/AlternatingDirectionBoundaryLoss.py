@@ -9,6 +9,8 @@ d loss / d preds (``wsdl_pairwise_affinity_loss_fwd_bwd`` with apply_softmax=0, 
 import torch.nn as nn
 
 from .. import ops
+from .AlternatingDirectionCutLoss import run_alternating_training  # noqa: F401  (reference :153-206 is the broken
+#   modular re-write of the same loop - SURVEY.md D6; the working behaviour is the script's, implemented there)
 
 
 class ConstrainToBoundaryLossSingle(nn.Module):

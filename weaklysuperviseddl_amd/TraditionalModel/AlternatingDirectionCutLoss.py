@@ -8,7 +8,8 @@ Mirrors reference TraditionalModel/AlternatingDirectionCutLoss.py:
   * ``refine_pseudo_mask``      :709-767 - Adam on a free tensor X: KL(softmax X || S) + lam_dyn*NCut
     with the dynamic weight kept ON DEVICE (the reference does two ``.item()`` syncs per step);
     softmax is applied twice to X on the NCut branch, as the reference does (SURVEY.md D8);
-  * ``train_model``             :684-707 - CE-only training epochs.
+  * ``train_model``             :684-707 - CE-only training epochs;
+  * ``run_alternating_training`` :791-818 - the outer loop: train <-> five chained refinement passes, in memory.
 """
 import torch
 import torch.nn as nn
@@ -62,20 +63,29 @@ def refine_pseudo_mask(model, image, mask, lambda_boundary=0.1, threshold=0.5, l
     return (Xf[0, 1] > threshold).float()
 
 
+def network_soft_prediction(model, images):
+    """S = softmax(model(images)['out']) in eval mode (AlternatingDirectionCutLoss.py:715-720): the constant target of
+    the KL term.  It does not depend on the mask, so the chained refinement repeats of one alternation share it."""
+    model.eval()
+    with torch.no_grad():
+        return ops.softmax_channels(model(images)["out"]).contiguous()
+
+
 def refine_pseudo_masks_batched(model, images, masks, lambda_boundary=0.1, threshold=0.5, lr=1e-2, num_steps=20,
-                                sigma_color=0.1, window_size=5):
+                                sigma_color=0.1, window_size=5, S=None):
     """``refine_pseudo_mask`` for N images at once: images (N,3,H,W), masks (N,H,W) with
     foreground = 255 -> (N,H,W) float masks.  Same arithmetic per image as the reference's per-image loop
     (AlternatingDirectionCutLoss.py:803-810); each step is six kernel launches for the whole batch and no host
-    synchronisation (the reference: ~2 x 24 x 14 tiny kernels and two ``.item()`` syncs per image and step)."""
+    synchronisation (the reference: ~2 x 24 x 14 tiny kernels and two ``.item()`` syncs per image and step).
+    ``S``: the network's soft prediction if the caller already has it (``network_soft_prediction``)."""
     import ctypes as C
     from .._lib import lib, check
     device = next(model.parameters()).device
     images = images.to(device).contiguous()
     N, _, H, W = images.shape
-    model.eval()
+    if S is None:
+        S = network_soft_prediction(model, images)
     with torch.no_grad():
-        S = ops.softmax_channels(model(images)["out"]).contiguous()
         fg = (masks.to(device) == 255)
         X = torch.stack([~fg, fg], dim=1).to(torch.float32).contiguous()
         Xn, dkl, dnc, dXn, dX = (torch.empty_like(X) for _ in range(5))
@@ -100,16 +110,83 @@ def refine_pseudo_masks_batched(model, images, masks, lambda_boundary=0.1, thres
         return (Xn[:, 1] > threshold).float()
 
 
-def train_model(model, optimizer, train_loader, num_epochs=3, device="cuda", log=print):
-    """CE-only epochs (the reference's ``train_model``; criterion is nn.CrossEntropyLoss())."""
+def train_model(model, optimizer, train_loader, num_epochs=3, device="cuda", log=print, max_steps_per_epoch=None):
+    """CE-only epochs (the reference's ``train_model``; criterion is nn.CrossEntropyLoss()).  ``train_loader``: a
+    DataLoader of (images, masks[, names]) or a callable returning a fresh iterator per epoch (the in-memory
+    dataset's ``batches``).  Returns the per-epoch summed losses (the number the reference prints)."""
     model.train()
+    totals = []
     for epoch in range(num_epochs):
         total = torch.zeros((), device=device)
-        for batch in train_loader:
+        it = train_loader() if callable(train_loader) else train_loader
+        for step, batch in enumerate(it):
+            if max_steps_per_epoch is not None and step >= max_steps_per_epoch:
+                break
             images, masks = batch[0].to(device), batch[1].to(device)
             if images.size(0) == 1:       # SegmentationModel.py:97-98: BN cannot normalise one pooled value
                 continue
             total += train_step(model, optimizer, images, masks)
+        totals.append(total)
         if log:
             log(f"Epoch {epoch + 1}/{num_epochs}, Loss: {total.item():.4f}")
-    return model
+    return totals
+
+
+def refine_dataset(model, dataset, repeats=5, chunk=64, threshold=0.3, lr=1e-4, num_steps=10, lambda_boundary=0.1,
+                   sigma_color=0.1, window_size=5):
+    """Step 2 of an alternation (AlternatingDirectionCutLoss.py:803-810): ``repeats`` passes over the data set, each
+    refining every pseudo mask and overwriting it - pass r+1 starts from pass r's thresholded masks, because the
+    reference's dataset re-reads the PNG it has just overwritten.  In memory: ``dataset.set_masks``.  The network is
+    frozen during the passes, so its soft prediction is computed once per chunk, not once per pass and image."""
+    n = len(dataset)
+    for s in range(0, n, chunk):
+        idx = torch.arange(s, min(s + chunk, n), device=dataset.images.device)
+        imgs = dataset.images[idx]
+        S = network_soft_prediction(model, imgs)
+        for _ in range(repeats):
+            refined = refine_pseudo_masks_batched(model, imgs, dataset.masks[idx], lambda_boundary=lambda_boundary,
+                                                  threshold=threshold, lr=lr, num_steps=num_steps,
+                                                  sigma_color=sigma_color, window_size=window_size, S=S)
+            dataset.set_masks(idx, refined)
+    return dataset
+
+
+def run_alternating_training(model, optimizer, dataset, num_alternations=10, epochs_per_round=10, refine_repeats=5,
+                             first_batch_size=4, later_batch_size=32, refine_chunk=64, refine_kwargs=None,
+                             evaluate=None, seed=0, device="cuda", log=print):
+    """The alternating-direction outer loop (reference AlternatingDirectionCutLoss.py:791-818; the modular re-write
+    AlternatingDirectionBoundaryLoss.py:153-206 is dead code): per alternation
+      1. ``train_model`` for ``epochs_per_round`` epochs on the current pseudo masks (batch 4 in the first
+         alternation, 32 afterwards - :781, :818),
+      2. optional ``evaluate(model)`` (:795),
+      3. ``refine_dataset``: five chained refinement passes over every pseudo mask (:803-810, threshold 0.3, lr 1e-4,
+         10 steps, lambda 0.1), masks overwritten in place, data set "re-opened" (:813-818).
+    ``dataset`` is THIS RANK's ``InMemoryPseudoDataset`` shard.  Under data parallelism (``torch.distributed``
+    initialised, a ``dp.GradBucketReducer`` on the optimizer) every rank must run the same number of optimiser steps:
+    the per-epoch step count is the minimum over the ranks; refinement is per-image independent and needs no
+    collective."""
+    import torch.distributed as dist
+    rk = dict(threshold=0.3, lr=1e-4, num_steps=10, lambda_boundary=0.1)
+    rk.update(refine_kwargs or {})
+    dp = dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if dp else 0
+    gen = torch.Generator().manual_seed(seed * 1000003 + rank)
+    history = []
+    for it in range(num_alternations):
+        bs = first_batch_size if it == 0 else later_batch_size
+        steps = dataset.num_batches(bs)
+        if dp:
+            from ..dp import control_group
+            t = torch.tensor([steps], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group())
+            steps = int(t.item())
+        losses = train_model(model, optimizer, lambda: dataset.batches(bs, shuffle=True, generator=gen, limit=steps),
+                             num_epochs=epochs_per_round, device=device, log=log if rank == 0 else None)
+        metrics = evaluate(model) if evaluate is not None else None
+        if log and rank == 0 and metrics is not None:
+            log(f"Iteration {it + 1}: Evaluation -> {metrics}")
+        refine_dataset(model, dataset, repeats=refine_repeats, chunk=refine_chunk, **rk)
+        history.append({"losses": losses, "metrics": metrics})
+    if log and rank == 0:
+        log("Alternating training and pseudo mask updates completed.")
+    return history

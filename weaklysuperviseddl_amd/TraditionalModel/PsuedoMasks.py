@@ -6,8 +6,12 @@ Mirrors reference TraditionalModel/PsuedoMasks.py: ``keep_largest`` (:15-21) and
     threshold fused into the epilogue kernel) - one device->host copy of uint8 masks per batch instead
     of a float map per image;
   * output directories are parameters (the reference hard-codes /content/...); ``write_png=False``
-    keeps the masks in memory (``generate_pseudo_masks.last_masks``) for the in-memory hand-off to
-    stage 2;
+    keeps the masks in memory for the in-memory hand-off to stage 2
+    (``generate_pseudo_masks.last_masks`` / ``.last_ids`` / ``.last_images``; ``stage_handoff`` turns them into
+    what ``PseudoSegmentationDataset`` would have read back from the PNGs);
+  * ``rank`` / ``world``: stage 1 is per-image independent (eval-mode BN), so under data parallelism the loader's
+    batches are dealt round-robin to the ranks - batch j belongs to rank j % world - with NO collective
+    (SURVEY.md 8e); image ids stay the global ones, so the union over the ranks is the single-process result;
   * ``keep_largest`` stays on the host as in the reference (skimage there; scipy.ndimage here -
     8-connectivity, raster label order, first label wins area ties, empty mask returned unchanged).
 """
@@ -16,6 +20,8 @@ import os
 import numpy as np
 import torch
 from scipy import ndimage
+
+from .. import ops
 
 _EIGHT = np.ones((3, 3), dtype=bool)
 
@@ -29,25 +35,34 @@ def keep_largest(mask):
 
 
 def _to_png_u8(t):
+    """torchvision.utils.save_image's quantisation: mul(255).add_(0.5).clamp_(0, 255) -> uint8, HWC."""
     return t.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
 
 
 def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_largest_masks=True,
                           run_id="default", out_root="/content", max_images=500, write_png=True,
-                          device="cuda"):
+                          device="cuda", rank=0, world=1, keep_images=False):
     mask_dir = os.path.join(out_root, f"pseudo_masks_{run_id}")
     image_dir = os.path.join(out_root, f"images_{run_id}")
     if write_png:
         from PIL import Image
         for d in (mask_dir, image_dir):
             os.makedirs(d, exist_ok=True)
-            for f in os.listdir(d):
-                os.remove(os.path.join(d, f))
-    masks, img_id = [], 0
-    for imgs, (labels, _) in loader:
+            if rank == 0:
+                for f in os.listdir(d):
+                    os.remove(os.path.join(d, f))
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()                  # nobody writes before rank 0 has emptied the directories
+    masks, ids, images, img_id = [], [], [], 0
+    for j, (imgs, (labels, _)) in enumerate(loader):
         if img_id >= max_images:
             break
-        take = min(imgs.size(0), max_images - img_id)
+        take = min(imgs.size(0), max_images - img_id)          # PsuedoMasks.py:49 - the 500-image cap
+        if j % world != rank:
+            img_id += take
+            continue
         imgs_d = imgs[:take].to(device, non_blocking=True)
         labels_d = torch.as_tensor(labels[:take]).to(device)
         _cam, m = layercam_gen.generate_batch(imgs_d, alpha=alpha, class_idx=labels_d, thresh=cam_thresh)
@@ -55,6 +70,9 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
         for i in range(take):
             mi = keep_largest(m_host[i]) if keep_largest_masks else m_host[i]
             masks.append(mi)
+            ids.append(img_id)
+            if keep_images:
+                images.append(imgs[i].detach())
             if write_png:
                 mt = torch.from_numpy(mi).float().unsqueeze(0).expand(3, -1, -1)
                 Image.fromarray(_to_png_u8(mt)).save(os.path.join(mask_dir, f"{img_id}.png"))
@@ -63,7 +81,49 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
                 Image.fromarray(_to_png_u8(im)).save(os.path.join(image_dir, f"{img_id}.png"))
             img_id += 1
     generate_pseudo_masks.last_masks = masks
+    generate_pseudo_masks.last_ids = ids
+    generate_pseudo_masks.last_images = images
     return image_dir, mask_dir
 
 
 generate = generate_pseudo_masks   # north-star alias "PsuedoMasks.generate"
+
+_MEAN = (0.485, 0.456, 0.406)
+_STD = (0.229, 0.224, 0.225)
+
+
+def nearest_resize_index(n_out, n_in, device):
+    """PIL NEAREST source index: floor((i + 0.5) * n_in / n_out)."""
+    return ((torch.arange(n_out, device=device, dtype=torch.float64) + 0.5) * (n_in / n_out)).floor().long().clamp_(max=n_in - 1)
+
+
+@torch.no_grad()
+def stage_handoff(images, masks, size=(256, 256), device="cuda"):
+    """In-memory stage-1 -> stage-2 hand-off: what ``PseudoSegmentationDataset`` (SegmentationDataset.py:19-38) would
+    read back from the PNGs ``generate_pseudo_masks`` writes (PsuedoMasks.py:68-74), without the file system.
+
+    images (N,3,h,w) float (stage-1 inputs), masks (N,h,w) uint8 {0,1} ->
+      images256 (N,3,H,W) float32 on ``device``: min-max rescale per image, 8-bit quantisation (save_image),
+                bilinear resize (PIL BILINEAR up-sampling == align_corners=False; HIP kernel), /255, ImageNet normalise;
+      masks256  (N,H,W) uint8 {0,255}: x255 (save_image of a 0/1 tensor), NEAREST resize.
+    """
+    x = torch.as_tensor(images).to(device=device, dtype=torch.float32)
+    lo = x.amin(dim=(1, 2, 3), keepdim=True)
+    hi = x.amax(dim=(1, 2, 3), keepdim=True)
+    q = ((x - lo) / (hi - lo)).mul(255).add(0.5).clamp(0, 255).floor()          # uint8 values, kept as float
+    H, W = size
+    # PIL resamples 8-bit images in two passes - columns first, then rows - and rounds to 8 bits after each
+    if q.shape[-1] != W:
+        q = ops.bilinear_resize(q.contiguous(), (q.shape[-2], W)).add(0.5).floor().clamp(0, 255)
+    if q.shape[-2] != H:
+        q = ops.bilinear_resize(q.contiguous(), (H, W)).add(0.5).floor().clamp(0, 255)
+    mean = torch.tensor(_MEAN, device=device).view(1, 3, 1, 1)
+    std = torch.tensor(_STD, device=device).view(1, 3, 1, 1)
+    img = (q / 255.0 - mean) / std
+    m = torch.as_tensor(np.asarray(masks)).to(device)
+    m = (m != 0).to(torch.uint8) * 255
+    if tuple(m.shape[-2:]) != (H, W):
+        ih = nearest_resize_index(H, m.shape[-2], device)
+        iw = nearest_resize_index(W, m.shape[-1], device)
+        m = m[:, ih][:, :, iw]
+    return img.contiguous(), m.contiguous()

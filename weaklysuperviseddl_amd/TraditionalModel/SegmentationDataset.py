@@ -42,3 +42,47 @@ class PseudoSegmentationDataset(Dataset):
         if self.transform:
             image, mask = self.joint_transform(image, mask)
         return (image, mask, self.mask_list[idx]) if self.return_name else (image, mask)
+
+
+class InMemoryPseudoDataset(Dataset):
+    """The same items ``PseudoSegmentationDataset(..., transform=True, return_name=True)`` yields, held as device
+    tensors: ``images`` (N,3,H,W) float32 normalised, ``masks`` (N,H,W) uint8 {0,255}, ``names`` (e.g. "17.png").
+    Built by ``PsuedoMasks.stage_handoff`` from stage 1's in-memory output; ``set_masks`` is the in-memory twin of
+    overwriting the mask PNGs (reference AlternatingDirectionCutLoss.py:806-809).  ``batches`` iterates like
+    ``DataLoader(dataset, batch_size, shuffle)`` without leaving the device."""
+
+    def __init__(self, images, masks, names=None):
+        assert images.shape[0] == masks.shape[0] and images.shape[-2:] == masks.shape[-2:]
+        self.images, self.masks = images, masks.to(torch.uint8)
+        self.names = list(names) if names is not None else [f"{i}.png" for i in range(images.shape[0])]
+
+    def __len__(self):
+        return self.images.shape[0]
+
+    def __getitem__(self, idx):
+        return self.images[idx], self.masks[idx].long(), self.names[idx]
+
+    def set_masks(self, idx, refined):
+        """refined: (n,H,W) float/bool masks in {0,1} (refine_pseudo_mask's output) -> stored as {0,255}, what
+        ``save_image`` + ``Image.open(...).convert('L')`` turn them into."""
+        self.masks[idx] = (refined > 0).to(torch.uint8) * 255
+
+    def num_batches(self, batch_size, drop_single=True):
+        n, r = divmod(len(self), batch_size)
+        return n + (1 if r > (1 if drop_single else 0) else 0)
+
+    def batches(self, batch_size, shuffle=True, generator=None, limit=None):
+        """Yields (images, masks int64, index tensor).  A trailing batch of ONE image is skipped like the reference's
+        trainer does (SegmentationModel.py:97-98: train-mode BN cannot normalise one pooled value)."""
+        n = len(self)
+        order = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
+        order = order.to(self.images.device)
+        done = 0
+        for s in range(0, n, batch_size):
+            idx = order[s:s + batch_size]
+            if idx.numel() == 1 and batch_size > 1:
+                continue
+            if limit is not None and done >= limit:
+                return
+            done += 1
+            yield self.images[idx], self.masks[idx].long(), idx

@@ -10,9 +10,24 @@ Design for 8 x MI355X (xGMI is point-to-point, 7 links/GPU): the flat gradient b
 cut into a few large contiguous buckets (default 4 x ~40 MB - large enough that each collective is
 bandwidth- not latency-bound per link).  Parameters are laid out in forward order, so backward fills the
 buffer from its END: a bucket's all-reduce is launched (async, RCCL's own stream) from the
-post-accumulate-grad hook of the last parameter it is waiting for and overlaps the remaining backward;
+gradient-ready hook of the last parameter it is waiting for and overlaps the remaining backward;
 ``wait()`` (called from ``FlatAdam.step``) only makes the compute stream wait on those collectives.
+
+What keeps the replicas identical (none of it is in the reference, all of it is needed once there is more
+than one process):
+  * ``sync_initial_state``: parameters and module buffers (BatchNorm running statistics) are broadcast from
+    rank 0 when the reducer is built - a checkpoint loaded on one rank or a different seed cannot leave the
+    replicas apart;
+  * every rank issues the SAME collectives: which parameters fired is agreed with a MAX all-reduce of a small
+    bitmap over a host-side (gloo) control group in every ``wait()``; bucket ranges, the set of parameters cut
+    out of their bucket and the "late" list are all derived from the agreed bitmap, never from local firing;
+  * a parameter counts once per step (a second firing - a weight used twice - does not launch its bucket early);
+    a gradient that arrives after its bucket has left raises unless it is inside ``no_sync()``;
+  * per-replica BatchNorm statistics are the design: ``average_bn_buffers`` averages the running
+    statistics over the ranks, for the moment a state_dict is saved; dropout seeds differ per rank
+    (``ops.DROPOUT_SEED_OFFSET``).
 """
+import contextlib
 import os
 
 import torch
@@ -33,22 +48,74 @@ def init_distributed(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:
+        from . import ops
+        ops.DROPOUT_SEED_OFFSET[0] = rank * 0x9E3779B97F4A7C15 % (1 << 62)      # different masks on every replica
     return rank, local, world
 
 
+_control_groups = {}
+
+
+def control_group(group=None):
+    """Host-side (gloo) twin of ``group`` for tiny control-plane exchanges that must not touch the GPU streams.  Always a
+    communicator of its own: ranks reach the control exchange at different points of their collective sequence (one has
+    launched a bucket from a hook, another has not yet), and collectives of ONE communicator must be issued in one order."""
+    if not dist.is_initialized():
+        return None
+    key = id(group)
+    if key not in _control_groups:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _control_groups[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _control_groups[key]
+
+
+def sync_initial_state(optimizer, modules=(), group=None, src=0):
+    """Broadcast the flat parameter buffer, the Adam moments / step count and every buffer of ``modules`` from ``src``."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in (optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq):
+        dist.broadcast(t, src=src, group=group)
+    step = torch.tensor([optimizer.step_count], dtype=torch.int64)
+    dist.broadcast(step, src=src, group=control_group(group))
+    optimizer.step_count = int(step.item())
+    for m in modules:
+        for b in m.buffers():
+            dist.broadcast(b, src=src, group=group)
+    from . import ops
+    ops.bump_param_epoch()
+    ops.bump_stats_epoch()
+
+
+def average_bn_buffers(modules, group=None):
+    """Replace every floating-point buffer (BatchNorm running_mean / running_var) by its mean over the ranks; call
+    it before saving a state_dict, which would otherwise hold the saving rank's statistics only."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    for m in modules:
+        for b in m.buffers():
+            if b.is_floating_point():
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
+                b.div_(world)
+    from . import ops
+    ops.bump_stats_epoch()
+
+
 class GradBucketReducer:
-    def __init__(self, optimizer, process_group=None, num_buckets=4):
+    def __init__(self, optimizer, process_group=None, num_buckets=4, modules=(), sync_state=True):
         self.opt = optimizer
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step_hook = self.wait
         n = optimizer.numel
-        num_buckets = max(1, min(num_buckets, len(optimizer.params)))
+        nparams = len(optimizer.params)
+        num_buckets = max(1, min(num_buckets, nparams))
         # bucket boundaries on parameter boundaries, roughly equal sizes
         target = n / num_buckets
-        bounds, acc = [0], 0
-        for p, off in zip(optimizer.params, optimizer.offsets):
+        bounds = [0]
+        for off in optimizer.offsets:
             if off - bounds[-1] >= target and len(bounds) < num_buckets:
                 bounds.append(off)
         bounds.append(n)
@@ -62,44 +129,82 @@ class GradBucketReducer:
             self.bucket_size[b] += 1
         self._pending = []
         self._launched = [False] * len(self.bucket_size)
+        self.early_launches = 0            # buckets of the last step that left before wait()
         # Parameters that receive no gradient (the aux head: no loss of the reference uses it) would hold their
-        # bucket's collective back until the end of backward.  They are learnt from the previous step: unused
-        # parameters at either END of a bucket's range are cut out of its collective (so a gradient that does turn up
-        # for one of them later cannot race with it; it is reduced on its own at the join) and no longer waited for.
+        # bucket's collective back until the end of backward.  They are learnt from the previous step's AGREED
+        # firing bitmap: unused parameters at either END of a bucket's range are cut out of its collective and no
+        # longer waited for; a gradient that does turn up for one of them later is seen by every rank in the
+        # agreed bitmap and reduced on its own at the join.
         self._fired = set()
         self._excluded = set()
         self._range = [(self.bounds[b], self.bounds[b + 1]) for b in range(len(self.bucket_size))]
         self._remaining = list(self.bucket_size)
+        self._accumulating = False
+        self._hooks = {}
         if self.world > 1:
+            self._control = control_group(process_group)
+            self._bitmap = torch.zeros(nparams, dtype=torch.uint8)
+            if sync_state:
+                sync_initial_state(optimizer, modules, process_group)
             self._index = {id(p): i for i, p in enumerate(optimizer.params)}
             for i, p in enumerate(optimizer.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))     # gradients arriving through autograd
             # gradients written directly by the HIP backward kernels (no AccumulateGrad node runs for them)
             optimizer.grad_ready_hooks.append(lambda p: self._hooks[self._index[id(p)]](p))
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside the context only accumulate into the flat buffer; the
+        collectives of the step go out from the last backward (outside the context) or at ``wait()``."""
+        self._accumulating = True
+        try:
+            yield
+        finally:
+            self._accumulating = False
+
     def _make_hook(self, i):
         b = self.bucket_of[i]
 
         def hook(_p):
+            if self._accumulating:
+                return
+            if i in self._fired:               # a weight used twice in the graph: counted once per step
+                if self._launched[b] and i not in self._excluded:
+                    raise RuntimeError(
+                        "GradBucketReducer: a gradient arrived after its bucket's all-reduce had been launched "
+                        "(a second backward before step()?).  Wrap all but the last backward in reducer.no_sync().")
+                return
             self._fired.add(i)
             if i in self._excluded:            # reduced on its own at the join (not part of the bucket's collective)
                 return
+            if self._launched[b]:
+                raise RuntimeError("GradBucketReducer: gradient for an already reduced bucket (see no_sync())")
             self._remaining[b] -= 1
-            if self._remaining[b] == 0:
-                self._launch(b)
-        if not hasattr(self, "_hooks"):
-            self._hooks = {}
+            self._launch_ready(early=True)
         self._hooks[i] = hook
         return hook
 
-    def _launch(self, b):
-        if self._launched[b]:
-            return
+    def _launch_ready(self, early):
+        """Buckets leave in ONE order on every rank - last bucket first, the order backward fills them - and a bucket
+        only once every bucket behind it has left: ranks whose hooks fire in a different pattern (a data-dependent
+        branch) still issue the same sequence of collectives, the stragglers from ``wait()``."""
+        for b in range(len(self.bucket_size) - 1, -1, -1):
+            if self._launched[b]:
+                continue
+            if early and self._remaining[b] > 0:
+                return
+            self._launch(b, early)
+
+    def _launch(self, b, early=False):
         self._launched[b] = True
         lo, hi = self._range[b]
         if hi <= lo:
             return
-        view = self.opt.flat_grad[lo:hi]
+        if early:
+            self.early_launches += 1
+        self._all_reduce(self.opt.flat_grad[lo:hi])
+
+    def _all_reduce(self, view):
         if view.is_cuda:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
@@ -112,28 +217,39 @@ class GradBucketReducer:
             return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def _agree(self):
+        """MAX over the ranks of the local firing bitmap (host-side control group): the one source of truth for what
+        this step reduces beyond the buckets and for next step's ranges."""
+        self._bitmap.zero_()
+        if self._fired:
+            self._bitmap[list(self._fired)] = 1
+        dist.all_reduce(self._bitmap, op=dist.ReduceOp.MAX, group=self._control)
+        return set(torch.nonzero(self._bitmap).flatten().tolist())
+
     def wait(self):
         """Launch any bucket whose hooks did not all fire, reduce late gradients of excluded parameters, join, and
-        learn which parameters to leave out next step."""
+        learn which parameters to leave out next step - all from the bitmap every rank agrees on."""
         opt = self.opt
         if self.world > 1:
-            for b in range(len(self.bucket_size)):
-                self._launch(b)
-            late = sorted(self._excluded & self._fired)
+            fired = self._agree()
+            self._launch_ready(early=False)
+            late = sorted(self._excluded & fired)
             if late and opt.flat_grad.is_cuda:
                 from . import ops
                 ops.join_side_stream(opt.flat_grad.device)      # their weight gradients were written on the side stream
             for i in late:
                 off, n = opt.offsets[i], opt.params[i].numel()
-                self._pending.append(dist.all_reduce(opt.flat_grad[off:off + n], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+                self._all_reduce(opt.flat_grad[off:off + n])
             for w in self._pending:
                 w.wait()
+            if opt.flat_grad.is_cuda:
+                from . import ops
+                ops.join_side_stream(opt.flat_grad.device)      # the collectives were enqueued from the side stream
             # next step: per bucket, drop the unused parameters before the first / after the last used one
             self._excluded = set()
             for b in range(len(self.bucket_size)):
                 idx = [i for i, bb in enumerate(self.bucket_of) if bb == b]
-                used = [i for i in idx if i in self._fired]
+                used = [i for i in idx if i in fired]
                 if not used:
                     self._excluded.update(idx)
                     self._range[b] = (self.bounds[b], self.bounds[b])
@@ -146,3 +262,4 @@ class GradBucketReducer:
         self._pending = []
         self._fired = set()
         self._launched = [False] * len(self.bucket_size)
+        self.last_early_launches, self.early_launches = self.early_launches, 0

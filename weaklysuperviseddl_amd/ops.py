@@ -662,11 +662,14 @@ def bilinear_resize(x, size):
     return _Bilinear.apply(x, int(size[0]), int(size[1]))
 
 
+DROPOUT_SEED_OFFSET = [0]      # dp.init_distributed: a different offset on every rank, so replicas draw different masks
+
+
 def dropout(x, p, training=True, seed=None, mask=None):
     if not training or p == 0.0:
         return x
     if seed is None:
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) + DROPOUT_SEED_OFFSET[0]) % (1 << 62)
     return _Dropout.apply(x, p, seed, mask)
 
 
