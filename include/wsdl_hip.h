@@ -151,6 +151,10 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
 int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift, int C,
                  wsdl_stream_t stream);
+/* y = act(scale[c]*x + shift[c]) - a stand-alone eval-mode BatchNorm2d (scale / shift from wsdl_bn_fold) or a
+ * stand-alone ReLU (scale = shift = NULL); the models run both fused behind the convolution instead. */
+int wsdl_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                        int relu, wsdl_stream_t stream);
 /* backward of y = act(scale*conv + shift + res) wrt conv: dconv = dy*[y>0]*scale ; dres = dy*[y>0] */
 int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, float* dconv, float* dres,
                         int B, int C, int HW, int relu, wsdl_stream_t stream);
@@ -185,12 +189,16 @@ int wsdl_copy_planes(const float* src, float* dst, int B, int C, int HW, long lo
 
 /* ---- losses --------------------------------------------------------------------------------- */
 size_t wsdl_reduce_workspace(void);
-/* nn.CrossEntropyLoss() on (B,C,H,W) logits and int64 (B,H,W) labels, mean over B*H*W
- * (TraditionalModel/SegmentationModel.py:90,107; AlternatingDirectionCutLoss.py:789,699).
- * dlogits (optional) = grad_scale * (softmax - onehot)/(B*H*W). */
+/* nn.CrossEntropyLoss() on (B,C,H,W) logits and int64 (B,H,W) labels
+ * (TraditionalModel/SegmentationModel.py:90,107; AlternatingDirectionCutLoss.py:789,699): mean over the pixels whose
+ * label != ignore_index (PyTorch's default is -100; such pixels get zero loss and zero gradient).  Any other label
+ * outside [0,C) - PyTorch raises - makes the loss NaN: a kernel cannot raise, and it must not train the pixel as a
+ * real class.  dlogits (optional) = grad_scale * (softmax - onehot), NOT yet divided by the valid-pixel count:
+ * *inv_count (device scalar, required with dlogits) receives 1/count and is applied together with the upstream
+ * gradient (wsdl_scale_by_device_scalar). */
 int wsdl_softmax_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
-                            int B, int C, int H, int W, float grad_scale,
-                            void* ws, size_t ws_bytes, wsdl_stream_t stream);
+                            float* inv_count, int B, int C, int H, int W, float grad_scale,
+                            long long ignore_index, void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* Pairwise-affinity loss over a reflect-padded window x window neighbourhood:
  *   apply_softmax=1, normalise=0, sigma_space<=0 : LocalNormalizedCutLoss.forward
  *                                  (TraditionalModel/AlternatingDirectionCutLoss.py:65-105)

@@ -4,7 +4,7 @@
 layer1: ReLU-mask flips average out, unlike the 64x64 case), dropout off, train-mode BatchNorm.
 
 Stored (tests/golden/network_grads_256.npz):
-  loss64 / loss32, logits checksums, per-parameter gradient norms of the fp64 run, the fp32 oracle's relative L2
+  loss64 / loss32, logits checksums and a 16-strided sample of the logits of both runs, per-parameter gradient norms of the fp64 run, the fp32 oracle's relative L2
   distance to fp64 for every parameter (the yardstick two correct fp32 implementations differ by), and the FULL fp64
   gradients (as float32) of backbone.conv1, layer1.0.conv1, layer4.2.conv3, classifier.4 and every BatchNorm
   weight / bias.  Weights are the seeded initialisation (torch.manual_seed(0)); `weights_checksum` guards that.
@@ -59,9 +59,9 @@ def main():
         out["logits_abs_sum" + name] = np.float64(logits.detach().double().abs().sum().item())
         out["logits_sum" + name] = np.float64(logits.detach().double().sum().item())
         grads[name] = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+        out["logits_sample" + name] = logits.detach()[:, :, ::16, ::16].double().numpy()
         if name == "64":
             out["weights_checksum"] = np.float64(weights_checksum(m))
-            out["logits_sample64"] = logits.detach()[:, :, ::16, ::16].numpy().astype(np.float32)
     names = sorted(grads["64"])
     out["names"] = np.array(names)
     out["norm64"] = np.array([grads["64"][k].norm().item() for k in names])

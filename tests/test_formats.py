@@ -63,3 +63,15 @@ def test_state_dict_files_round_trip(tmp_path):
     keys = list(seg.state_dict())
     assert keys == list(ref.state_dict())                 # same ORDER too (torchvision registration order)
     assert keys[0] == "backbone.conv1.weight" and "classifier.0.convs.4.1.weight" in keys and "aux_classifier.4.bias" in keys
+
+
+def test_product_compute_iou_and_acc_matches_the_reference_vectors(golden):
+    """The product's metric (TraditionalModel/ExtraUtilities.py) against the golden vector of the reference body
+    (ExtraUtilities.py:4-21) - host code, no kernel involved."""
+    import torch
+    from weaklysuperviseddl_amd.TraditionalModel import compute_iou_and_acc
+    g = golden("refine_metrics")
+    iou, acc = compute_iou_and_acc(torch.from_numpy(g["metric_pred"]), torch.from_numpy(g["metric_true"]))
+    assert abs(iou - g["metric_iou_acc"][0]) < 1e-12 and abs(acc - g["metric_iou_acc"][1]) < 1e-12
+    z = torch.zeros(4, 4, dtype=torch.long)
+    assert compute_iou_and_acc(z, z) == (0.0, 1.0)                 # empty union: 0 / (0 + 1e-8)

@@ -34,12 +34,22 @@ FULL_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", FULL_SHAPES)
+# BASELINE configs[2] (B=32 at 256x256: 32x32 maps, twice the pixel tiles of cfg2) and configs[4] (B=8 at 512x512:
+# 64x64 maps - other tile / split-K / column-band / batch-slice choices than B=16 at 32x32): (B, Cin, Cout, k, s, d, H)
+OTHER_CONFIG_SHAPES = [
+    (32, 256, 256, 3, 1, 2, 32), (32, 512, 512, 3, 1, 4, 32), (32, 2048, 256, 3, 1, 24, 32), (32, 1024, 256, 1, 1, 1, 32),
+    (32, 64, 64, 3, 1, 1, 64),
+    (8, 64, 64, 3, 1, 1, 128), (8, 128, 128, 3, 2, 1, 128), (8, 256, 256, 3, 1, 2, 64), (8, 512, 512, 3, 1, 4, 64),
+    (8, 2048, 256, 3, 1, 12, 64), (8, 2048, 256, 3, 1, 36, 64), (8, 1024, 256, 1, 1, 1, 64), (8, 512, 2048, 1, 1, 1, 64),
+    (8, 3, 64, 7, 2, 1, 512),
+]
+
+
+@pytest.mark.parametrize("shape", [(16,) + s for s in FULL_SHAPES] + OTHER_CONFIG_SHAPES)
 def test_conv_adjointness_full_size(dev, shape):
     """<conv(x,w), dy> == <x, dgrad(dy,w)> == <w, wgrad(x,dy)> : one identity ties the three kernels together."""
     from weaklysuperviseddl_amd import ops
-    Cin, Cout, k, s, d, H = shape
-    B = 16
+    B, Cin, Cout, k, s, d, H = shape
     pad = (k // 2) * d if k > 1 else 0
     g = torch.Generator(device=dev).manual_seed(Cin + Cout)
     x = torch.randn(B, Cin, H, H, device=dev, generator=g)
@@ -162,6 +172,78 @@ def test_full_size_training_steps(dev):
     assert torch.isfinite(g1).all() and torch.isfinite(p1).all()
     l2, g2, p2 = run()
     assert l1 == l2 and torch.equal(g1, g2) and torch.equal(p1, p2)     # no atomics anywhere: bitwise reproducible
+
+
+def _run_config(dev, B, S, extra_of, steps=3):
+    import bench
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    from weaklysuperviseddl_amd import nn as wnn
+    torch.manual_seed(0)
+    model = build_segmentation_model().to(dev).train()
+    for m in model.modules():
+        if isinstance(m, wnn.Dropout):
+            m.p = 0.0
+    opt = make_optimizer(model, lr=1e-4)
+    _, masks = bench.synthetic_batch(B, S, S, dev, 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img = ((bench.smooth_images(B, S, S, 11) - mean) / std).to(dev)
+    extra = extra_of()
+    losses = [train_step(model, opt, img, masks, extra).item() for _ in range(steps)]
+    torch.cuda.synchronize()
+    return losses, opt.flat_grad.clone(), opt.flat_param.clone()
+
+
+def _check_config(dev, B, S, extra_of):
+    l1, g1, p1 = _run_config(dev, B, S, extra_of)
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0], l1
+    assert torch.isfinite(g1).all() and torch.isfinite(p1).all() and g1.abs().max().item() > 0
+    l2, g2, p2 = _run_config(dev, B, S, extra_of)
+    assert l1 == l2 and torch.equal(g1, g2) and torch.equal(p1, p2)     # bitwise reproducible
+
+
+def test_cfg3_training_steps_b32_with_ncut(dev):
+    """BASELINE configs[2]: B=32, 256x256, CE + 0.1 * LocalNormalizedCutLoss(0.1, 5) on the logits, Adam."""
+    from weaklysuperviseddl_amd.TraditionalModel import LocalNormalizedCutLoss
+
+    def extra_of():
+        ncut = LocalNormalizedCutLoss(0.1, 5)
+        return lambda o, i: 0.1 * ncut(o, i)
+    _check_config(dev, 32, 256, extra_of)
+
+
+def test_cfg5_training_steps_512_with_ncut_and_boundary(dev):
+    """BASELINE configs[4], one GPU's share: B=8, 512x512, CE + 0.1 * NCut + 0.1 * ConstrainToBoundaryLoss, Adam."""
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import LocalNormalizedCutLoss, ConstrainToBoundaryLossSingle
+
+    def extra_of():
+        ncut, bnd = LocalNormalizedCutLoss(0.1, 5), ConstrainToBoundaryLossSingle(0.1, 5, 5)
+        return lambda o, i: 0.1 * ncut(o, i) + 0.1 * bnd(ops.softmax_channels(o), i).mean()
+    _check_config(dev, 8, 512, extra_of)
+
+
+def test_cross_entropy_ignore_index_and_bad_labels(dev):
+    """nn.CrossEntropyLoss semantics at full size: -100 pixels are left out of the mean with zero gradient; a label
+    outside [0, C) that is not the ignore index poisons the loss (PyTorch raises) instead of training as a class."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(4, 2, 256, 256, generator=g)
+    labels = (torch.rand(4, 256, 256, generator=g) > 0.5).long()
+    labels[torch.rand(4, 256, 256, generator=g) < 0.25] = -100
+    lr = logits.clone().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(lr, labels)
+    (ref * 3.0).backward()
+    ld = logits.to(dev).requires_grad_()
+    out = ops.cross_entropy(ld, labels.to(dev))
+    (out * 3.0).backward()
+    assert abs(out.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert ((ld.grad.cpu() - lr.grad).abs().max() / lr.grad.abs().max()).item() < 1e-5
+    assert ld.grad.cpu()[:, 0][labels == -100].abs().max().item() == 0.0
+    bad = labels.clone()
+    bad[0, 0, 0] = 255                       # an un-clamped mask value
+    assert torch.isnan(ops.cross_entropy(logits.to(dev), bad.to(dev))).item()
 
 
 def test_keep_largest_idempotent_full_size():

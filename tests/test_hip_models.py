@@ -409,3 +409,68 @@ def test_train_fc_only(dev, cam_models):
     frozen = [k for k, p in mine.named_parameters() if not k.startswith("fc.")]
     for k in frozen[:5] + frozen[-5:]:
         assert torch.equal(dict(mine.named_parameters())[k].cpu(), dict(cam_models[1].named_parameters())[k].cpu()), k
+
+
+def test_evaluate_model_matches_the_reference_procedure(dev, seg_models):
+    """evaluate_model (SegmentationModel.py:126-159 / AlternatingDirectionCutLoss.py:639-682): eval-mode forward, argmax,
+    F.interpolate(nearest) to the trimap's size, compute_iou_and_acc - against the same steps on the oracle."""
+    import oracle
+    from weaklysuperviseddl_amd.TraditionalModel import evaluate_model
+    ref, mine = seg_models
+    ref.eval()
+    g = torch.Generator().manual_seed(9)
+    loader = []
+    for hw in ((64, 64), (96, 80), (48, 56)):
+        img = torch.randn(2, 3, 64, 64, generator=g)
+        trimap = torch.randint(1, 4, (2,) + hw, generator=g)            # Oxford-IIIT Pet trimaps: 1 pet, 2 background, 3 border
+        loader.append((img, (torch.zeros(2, dtype=torch.long), trimap)))
+    for mode in ("notebook", "modular"):
+        ious, accs = [], []
+        with torch.no_grad():
+            for img, (_, tm) in loader:
+                t = tm[0].clone()
+                if mode == "notebook":
+                    t[t == 2] = 1
+                    t = 1 - t
+                else:
+                    t = (t == 1).long()
+                pred = ref(img[0:1])["out"].argmax(dim=1).squeeze(0)
+                if pred.shape != t.shape:
+                    pred = F.interpolate(pred[None, None].float(), size=t.shape[-2:], mode="nearest").squeeze().long()
+                iou, acc = oracle.compute_iou_and_acc(pred, t)
+                ious.append(iou)
+                accs.append(acc)
+        want = (sum(ious) / len(ious), sum(accs) / len(accs))
+        got = evaluate_model(mine, loader, device=dev, binarize=mode)
+        # argmax of two logits can flip where they are within fp32 noise of each other: a few pixels of 64 x 64
+        assert abs(got[0] - want[0]) < 5e-3 and abs(got[1] - want[1]) < 5e-3, (mode, got, want)
+    assert not mine.training
+
+
+def test_standalone_batchnorm_and_relu_modules(dev):
+    """model.backbone.bn1(x) / a hooked ReLU: the stand-alone forms of modules the models only run fused."""
+    from weaklysuperviseddl_amd import nn as wnn
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(4, 8, 12, 10, generator=g)
+    dy = torch.randn(4, 8, 12, 10, generator=g)
+    ref = nn.BatchNorm2d(8)
+    ref.weight.data.copy_(torch.rand(8, generator=g) + 0.5)
+    ref.bias.data.copy_(torch.randn(8, generator=g) * 0.1)
+    mine = wnn.BatchNorm2d(8)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(dev)
+    for training in (True, False):
+        ref.train(training), mine.train(training)
+        xr, xm = x.clone().requires_grad_(), x.to(dev).requires_grad_()
+        yr, ym = F.relu(ref(xr)), wnn.ReLU()(mine(xm))
+        yr.backward(dy), ym.backward(dy.to(dev))
+        assert rel_err(ym, yr) < 1e-5 and rel_err(xm.grad, xr.grad) < 1e-4, training
+        if training:
+            assert rel_err(mine.weight.grad, ref.weight.grad) < 1e-4 and rel_err(mine.bias.grad, ref.bias.grad) < 1e-4
+            assert rel_err(mine.running_mean, ref.running_mean) < 1e-5 and rel_err(mine.running_var, ref.running_var) < 1e-5
+    assert int(mine.state_dict()["num_batches_tracked"]) == 1
+    h = []
+    relu = wnn.ReLU()
+    relu.register_forward_hook(lambda m, i, o: h.append(o))
+    out = relu(torch.tensor([[-1.0, 2.0]], device=dev))
+    assert out.tolist() == [[0.0, 2.0]] and len(h) == 1

@@ -75,7 +75,10 @@ def test_network_gradients_vs_fp64_fixture_256(dev):
     o = out.detach().cpu().double()
     assert abs(o.abs().sum().item() - float(gold["logits_abs_sum64"])) <= 1e-5 * float(gold["logits_abs_sum64"])
     samp = torch.from_numpy(gold["logits_sample64"]).double()
-    assert ((o[:, :, ::16, ::16] - samp).abs().max() / samp.abs().max()).item() < 1e-4
+    e32 = (np.abs(gold["logits_sample32"] - gold["logits_sample64"]).max() / np.abs(gold["logits_sample64"]).max()).item()
+    e_hip_logits = ((o[:, :, ::16, ::16] - samp).abs().max() / samp.abs().max()).item()
+    print("logits max-norm distance to fp64: HIP %.3e, fp32 oracle %.3e" % (e_hip_logits, e32))
+    assert e_hip_logits <= 2.0 * e32 and e_hip_logits < 1e-3                                   # fp32 oracle: 1.3e-4
     names = [str(n) for n in gold["names"]]
     assert sorted(grads) == names                                   # the aux head receives no gradient on either side
     norm64, err32 = gold["norm64"], gold["err32_l2"]

@@ -127,19 +127,28 @@ def make_optimizer(model, lr=1e-4):
 
 
 @torch.no_grad()
-def evaluate_model(model, loader, device="cuda"):
-    """Reference SegmentationModel.py:126-159 / AlternatingDirectionCutLoss.py:639-682: argmax -> IoU/acc
-    against the trimap-derived ground truth (2 -> 1, then inverted)."""
+def evaluate_model(model, loader, device="cuda", binarize="notebook"):
+    """argmax -> nearest resize to the ground truth's size -> IoU / pixel accuracy, averaged over the loader's images
+    (one image - the first of each batch - per batch, as the reference).  Ground truth from the Oxford-IIIT Pet trimap:
+      binarize="notebook": ``tm[tm == 2] = 1; tm = 1 - tm``      (AlternatingDirectionCutLoss.py:639-682, the script
+                           that actually runs - SURVEY.md section 0);
+      binarize="modular" : ``tm = (tm == 1)``                    (SegmentationModel.py:126-159)."""
     model.eval()
     ious, accs = [], []
     for img, (_label, true_mask) in loader:
         x = img[0].to(device).unsqueeze(0)
         tm = true_mask[0].to(device).clone()
-        tm[tm == 2] = 1
-        tm = 1 - tm
+        if binarize == "notebook":
+            tm[tm == 2] = 1
+            tm = 1 - tm
+        elif binarize == "modular":
+            tm = (tm == 1).long()
+        else:
+            raise ValueError(binarize)
         out = model(x)["out"]
         pred = out.squeeze(0).argmax(dim=0)
         if pred.shape != tm.shape:
+            # F.interpolate(mode='nearest'): source index = floor(dst * in / out)
             idx_h = (torch.arange(tm.shape[-2], device=device) * pred.shape[0] // tm.shape[-2])
             idx_w = (torch.arange(tm.shape[-1], device=device) * pred.shape[1] // tm.shape[-1])
             pred = pred[idx_h][:, idx_w]

@@ -36,6 +36,7 @@ SIGNATURES = {
     "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _sz, _vp]),
     "wsdl_bn_train_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _sz, _vp]),
     "wsdl_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "wsdl_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp]),
     "wsdl_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsdl_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -49,7 +50,7 @@ SIGNATURES = {
     "wsdl_scale_by_device_scalar": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "wsdl_copy_planes": (_i, [_vp, _vp, _i, _i, _i, _ll, _ll, _vp]),
     "wsdl_reduce_workspace": (_sz, []),
-    "wsdl_softmax_ce_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "wsdl_softmax_ce_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _ll, _vp, _sz, _vp]),
     "wsdl_pairwise_affinity_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _sz, _vp]),
     "wsdl_pairwise_workspace": (_sz, [_i, _i, _i]),
     "wsdl_compute_affinities": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp]),

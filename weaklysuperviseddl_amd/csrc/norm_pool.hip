@@ -367,6 +367,24 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ dy, const float*
   }
 }
 
+// y = act(scale[c]*x + shift[c]): a stand-alone eval-mode BatchNorm2d (folded running statistics) or a stand-alone ReLU
+// (scale = shift = null).  The models never run these - their BatchNorm / ReLU are fused behind the convolution -
+// but a drop-in user may call model.backbone.bn1(x) or hook a ReLU module.
+__global__ void affine_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, float* __restrict__ y, int C, int HW, int relu,
+                                      int planes) {
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    const int c = plane % C;
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const long long base = (long long)plane * HW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        float v = x[base + i] * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        y[base + i] = v;
+    }
+  }
+}
+
 // ---- MaxPool2d(3, 2, 1)
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                    uint8_t* __restrict__ am, int H, int W, int OH, int OW, int planes) {
@@ -598,6 +616,15 @@ int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, flo
     WSDL_REQUIRE(!relu || y, "affine_act_bwd: relu mask needs y");
     hipLaunchKernelGGL(affine_act_bwd_kernel, plane_grid(B * C, HW), dim3(256), 0, wsdl::as_stream(stream), dy, y,
                        scale, dconv, dres, C, HW, relu, B * C);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_affine_act_fwd(const float* x, const float* scale, const float* shift, float* y, int B, int C, int HW,
+                        int relu, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && y && B > 0 && C > 0 && HW > 0, "affine_act_fwd: bad arguments");
+    hipLaunchKernelGGL(affine_act_fwd_kernel, plane_grid(B * C, HW), dim3(256), 0, wsdl::as_stream(stream), x, scale,
+                       shift, y, C, HW, relu, B * C);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -131,35 +131,67 @@ __global__ void finalize_sum_kernel(const float* __restrict__ part, int n, int g
 }
 
 // ------------------------------------------------------------------------------- cross entropy
+// nn.CrossEntropyLoss() semantics: mean over the pixels whose label is not `ignore_index` (default -100); such
+// pixels get zero loss and zero gradient.  Any other label outside [0, C) is an error in PyTorch (IndexError on the
+// CPU, a device assert on a GPU); a kernel cannot raise, so it POISONS the loss with NaN - loud, instead of silently
+// training the pixel as a real class (e.g. an un-clamped 255 of a mask PNG; the reference clamps before the loss:
+// AlternatingDirectionCutLoss.py:695).  part[0..blocks) = loss partials, part[blocks..2*blocks) = valid-pixel counts.
 __global__ void softmax_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                   float* __restrict__ part, float* __restrict__ dlogits, int C, int HW,
-                                  long long npix, float gscale) {
+                                  long long npix, float gscale, long long ignore_index) {
     __shared__ float sm[16];
-    float acc = 0.f;
+    float acc = 0.f, cnt = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix;
          i += (long long)gridDim.x * blockDim.x) {
         const long long b = i / HW;
         const int r = (int)(i - b * HW);
         const float* lp = logits + b * C * HW + r;
-        long long lab = labels[i];
-        lab = lab < 0 ? 0 : (lab >= C ? C - 1 : lab);
+        const long long lab = labels[i];
+        const bool ignored = lab == ignore_index;
+        const bool bad = !ignored && (lab < 0 || lab >= C);
         float m = -INFINITY;
         for (int c = 0; c < C; ++c) m = fmaxf(m, lp[(long long)c * HW]);
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(lp[(long long)c * HW] - m);
         const float lse = m + logf(se);
-        acc += lse - lp[lab * HW];
+        if (bad)
+            acc += NAN;
+        else if (!ignored) {
+            acc += lse - lp[lab * HW];
+            cnt += 1.f;
+        }
         if (dlogits) {
             float* dp = dlogits + b * C * HW + r;
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) {
                 const float pr = expf(lp[(long long)c * HW] - m) * inv;
-                dp[(long long)c * HW] = (pr - (c == lab ? 1.f : 0.f)) * gscale;
+                dp[(long long)c * HW] = ignored ? 0.f : (pr - (c == lab ? 1.f : 0.f)) * gscale;
             }
         }
     }
     acc = block_sum(acc, sm);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    cnt = block_sum(cnt, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = acc;
+        part[gridDim.x + blockIdx.x] = cnt;
+    }
+}
+
+// loss = sum / count, inv_count = 1 / count (the factor the gradient still lacks); count == 0 -> NaN like PyTorch
+__global__ void ce_finalize_kernel(const float* __restrict__ part, int blocks, float* __restrict__ loss,
+                                   float* __restrict__ inv_count) {
+    __shared__ double sm[16];
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) {
+        s += part[i];
+        c += part[blocks + i];
+    }
+    s = block_sum_d(s, sm);
+    c = block_sum_d(c, sm);
+    if (threadIdx.x == 0) {
+        *loss = (float)(s / c);
+        if (inv_count) *inv_count = (float)(1.0 / c);
+    }
 }
 
 // ------------------------------------------------------------------------------- pairwise loss
@@ -446,21 +478,23 @@ int wsdl_bilinear_bwd(const float* dy, float* dx, int B, int C, int h, int w, in
     return WSDL_OK;
 }
 
-int wsdl_softmax_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits, int B,
-                            int C, int H, int W, float grad_scale, void* ws, size_t ws_bytes,
-                            wsdl_stream_t stream) {
+int wsdl_softmax_ce_fwd_bwd(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                            float* inv_count, int B, int C, int H, int W, float grad_scale, long long ignore_index,
+                            void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(logits && labels && loss && ws && B > 0 && C > 0 && H > 0 && W > 0, "softmax_ce: bad arguments");
+    WSDL_REQUIRE(!dlogits || inv_count, "softmax_ce: the gradient needs inv_count (it is left unnormalised)");
     if (ws_bytes < wsdl_reduce_workspace()) {
         wsdl::set_error("softmax_ce: workspace too small");
         return WSDL_EWORKSPACE;
     }
     const long long npix = (long long)B * H * W;
-    const int blocks = flat_blocks(npix);
+    const int blocks = std::min(flat_blocks(npix), wsdl::kReduceSlots / 2);
     hipStream_t s = wsdl::as_stream(stream);
     float* part = static_cast<float*>(ws);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(blocks), dim3(256), 0, s, logits, labels, part, dlogits, C, H * W,
-                       npix, grad_scale / (float)npix);
-    hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, s, part, blocks, 1, 1.f / (float)npix, loss);
+                       npix, grad_scale, ignore_index);
+    WSDL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks, loss, inv_count);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -135,7 +135,7 @@ class GradBucketReducer:
         # firing bitmap: unused parameters at either END of a bucket's range are cut out of its collective and no
         # longer waited for; a gradient that does turn up for one of them later is seen by every rank in the
         # agreed bitmap and reduced on its own at the join.
-        self._fired = set()
+        self._fired = {}                   # parameter index -> source of its first announcement this step
         self._excluded = set()
         self._range = [(self.bounds[b], self.bounds[b + 1]) for b in range(len(self.bucket_size))]
         self._remaining = list(self.bucket_size)
@@ -148,9 +148,10 @@ class GradBucketReducer:
                 sync_initial_state(optimizer, modules, process_group)
             self._index = {id(p): i for i, p in enumerate(optimizer.params)}
             for i, p in enumerate(optimizer.params):
-                p.register_post_accumulate_grad_hook(self._make_hook(i))     # gradients arriving through autograd
-            # gradients written directly by the HIP backward kernels (no AccumulateGrad node runs for them)
-            optimizer.grad_ready_hooks.append(lambda p: self._hooks[self._index[id(p)]](p))
+                h = self._make_hook(i)
+                p.register_post_accumulate_grad_hook(lambda q, h=h: h(q, "autograd"))   # gradients arriving through autograd
+            # gradients written directly by the HIP backward kernels into the flat buffer
+            optimizer.grad_ready_hooks.append(lambda p: self._hooks[self._index[id(p)]](p, "direct"))
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -165,16 +166,23 @@ class GradBucketReducer:
     def _make_hook(self, i):
         b = self.bucket_of[i]
 
-        def hook(_p):
+        def hook(_p, src):
+            # Two sources can announce one gradient: "direct" (a HIP backward kernel has been enqueued that writes the
+            # parameter's flat_grad slice) and "autograd" (the parameter's post-accumulate hook).  The engine runs the
+            # post-accumulate hook of a parameter of a node in the graph even when that node's backward returned
+            # None for it - which is what the direct path returns - so a direct firing is followed by a spurious
+            # autograd one (measured: every one of the 182 trained parameters, every step).  The first announcement
+            # of a step counts; the other source's echo is dropped.
             if self._accumulating:
                 return
-            if i in self._fired:               # a weight used twice in the graph: counted once per step
-                if self._launched[b] and i not in self._excluded:
+            if i in self._fired:
+                if self._fired[i] == src and self._launched[b] and i not in self._excluded:
                     raise RuntimeError(
-                        "GradBucketReducer: a gradient arrived after its bucket's all-reduce had been launched "
-                        "(a second backward before step()?).  Wrap all but the last backward in reducer.no_sync().")
+                        f"GradBucketReducer: a second gradient for parameter {i} {tuple(_p.shape)} arrived after its "
+                        "bucket's all-reduce had been launched (a second backward before step()?).  Wrap all but the "
+                        "last backward in reducer.no_sync().")
                 return
-            self._fired.add(i)
+            self._fired[i] = src
             if i in self._excluded:            # reduced on its own at the join (not part of the bucket's collective)
                 return
             if self._launched[b]:
@@ -260,6 +268,6 @@ class GradBucketReducer:
                 self._range[b] = (opt.offsets[first], opt.offsets[last] + opt.params[last].numel())
                 self._remaining[b] = last - first + 1       # unused parameters INSIDE the range are still waited for
         self._pending = []
-        self._fired = set()
+        self._fired = {}
         self._launched = [False] * len(self.bucket_size)
         self.last_early_launches, self.early_launches = self.early_launches, 0

@@ -60,13 +60,18 @@ class BatchNorm2d(nn.Module):
         super()._load_from_state_dict(*args, **kwargs)
 
     def forward(self, x):
-        # stand-alone BN = identity 1x1 "conv" is wasteful; only the fused path is used by the models
-        raise RuntimeError("BatchNorm2d is only run fused behind a Conv2d (see FusedSequential / conv_bn)")
+        # the models run BatchNorm fused behind the convolution (FusedSequential / conv_bn); a stand-alone call - a
+        # drop-in user doing model.backbone.bn1(x) - takes the same kernels without the convolution
+        if self.training:
+            self._pending_steps += 1
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.momentum, self.eps,
+                              self.training)
 
 
 class ReLU(nn.Module):
     def forward(self, x):
-        raise RuntimeError("ReLU is only run fused (see FusedSequential / conv_bn)")
+        # fused into the producing kernel inside the models; stand-alone (hooked / called directly) it is one launch
+        return ops.relu(x)
 
 
 class MaxPool3x3s2(nn.Module):

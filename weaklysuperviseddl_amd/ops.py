@@ -184,6 +184,7 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
                                   int(accumulate_into is not None), dy_bs, _p(ws), ws.numel() if ws is not None else 0,
                                   _stream()))
+    dx._wsdl_fresh = True        # a buffer this library has just produced and nobody else holds (see _owned)
     return dx
 
 
@@ -259,7 +260,21 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if relu else None), _p(gamma), _p(mean), _p(invstd), _p(dx),
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, int(relu), int(acc), dy_bs, y_bs,
                                   _p(ws), ws.numel(), _stream()))
+    dx._wsdl_fresh = True
+    if dres is not None:
+        dres._wsdl_fresh = True
     return dx, dgamma, dbeta, dres
+
+
+def _owned(t):
+    """May this incoming gradient buffer be accumulated into IN PLACE?  Only buffers the library itself produced for
+    exactly this purpose (a BatchNorm-backward ``dres`` / ``dx`` or a dgrad output - marked ``_wsdl_fresh``; the mark
+    survives the autograd engine, which either hands the tensor on untouched or sums a fan-out into the first
+    arrival, still exclusively its own) and that are not views of something else.  Aliased gradients - the same tensor
+    returned twice by an add node, channel slices of a concat's gradient, anything a user hook produced - fall back to
+    an out-of-place add."""
+    return (t is not None and getattr(t, "_wsdl_fresh", False) and t._base is None and t.is_contiguous()
+            and t.dtype == torch.float32 and not t.requires_grad)
 
 
 def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
@@ -365,8 +380,7 @@ class _ConvBNAct(torch.autograd.Function):
             if wd is None:
                 raise WsdlError("conv backward: dgrad weights were not prepared")
             into = None
-            if (dxres is not None and tuple(dxres.shape) == tuple(xshape) and dxres.is_contiguous()
-                    and dxres.dtype == torch.float32):
+            if _owned(dxres) and tuple(dxres.shape) == tuple(xshape):
                 into = dxres        # the identity branch's gradient (a fresh BN-backward output): dx = dgrad(...) + it
             dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into)
             if into is None and dxres is not None:
@@ -424,6 +438,64 @@ class _ConvAffineAct(torch.autograd.Function):
         return dx, dw, None, dshift, dres, None, None, None, None, None, None
 
 
+class _BNTrain(torch.autograd.Function):
+    """Stand-alone train-mode BatchNorm2d (batch statistics, running-statistics update): the same two kernels the
+    fused conv -> BN node runs, without the convolution."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps):
+        x = _dense(x, "x")
+        y, mean, invstd = bn_train_fwd(x, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps)
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta, _ = bn_train_bwd(x, dy, None, _dense(gamma), mean, invstd, False, False)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+class _AffineAct(torch.autograd.Function):
+    """y = act(scale[c]*x + shift[c]) on (B,C,H,W) [or (B,C)]: stand-alone eval-mode BatchNorm2d / ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, relu):
+        x = _dense(x, "x")
+        B, Cc = (x.shape[0], x.shape[1]) if x.dim() >= 2 else (1, 1)
+        HW = x.numel() // max(B * Cc, 1)
+        y = torch.empty_like(x)
+        check(lib().wsdl_affine_act_fwd(_p(x), _p(scale), _p(shift), _p(y), B, Cc, HW, int(relu), _stream()))
+        ctx.relu, ctx.geom = relu, (B, Cc, HW)
+        ctx.save_for_backward(y if relu else None, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        B, Cc, HW = ctx.geom
+        dy = _dense(dy, "dy")
+        if not ctx.relu and scale is None:
+            return dy, None, None, None
+        dx = torch.empty_like(dy)
+        check(lib().wsdl_affine_act_bwd(_p(dy), _p(y), _p(scale), _p(dx), _vp(0), B, Cc, HW, int(ctx.relu), _stream()))
+        return dx, None, None, None
+
+
+def batch_norm(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, training=True):
+    """Stand-alone nn.BatchNorm2d.forward.  Eval mode folds the running statistics; like the fused eval path it
+    treats gamma / beta as constants (the frozen classifier is the only eval-mode user of the reference)."""
+    if training:
+        bump_stats_epoch()
+        return _BNTrain.apply(x, gamma, beta, running_mean, running_var, momentum, eps)
+    scale, shift = bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+    return _AffineAct.apply(x, scale, shift, False)
+
+
+def relu(x):
+    return _AffineAct.apply(x, None, None, True)
+
+
 class _MaxPool3x3s2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -461,6 +533,7 @@ class _GlobalAvgPool(torch.autograd.Function):
         B, Cc, H, W = ctx.xshape
         dx = torch.empty(ctx.xshape, device=dy.device, dtype=torch.float32)
         check(lib().wsdl_global_avgpool_bwd(_p(_dense(dy)), _p(dx), B * Cc, H * W, 0, _stream()))
+        dx._wsdl_fresh = True       # ASPP: the pooling branch's input gradient is summed into by the conv branches' dgrads
         return dx
 
 
@@ -557,10 +630,12 @@ class _AddAct(torch.autograd.Function):
 
 
 class _SoftmaxCE(torch.autograd.Function):
-    """nn.CrossEntropyLoss() on (B,C,H,W) logits, int64 labels; forward and gradient in one kernel."""
+    """nn.CrossEntropyLoss() on (B,C,H,W) logits, int64 labels; forward and gradient in one kernel.  Labels equal to
+    ``ignore_index`` are left out of the mean (zero gradient); any other label outside [0, C) turns the loss into NaN
+    (PyTorch raises there; see the kernel)."""
 
     @staticmethod
-    def forward(ctx, logits, labels):
+    def forward(ctx, logits, labels, ignore_index):
         logits = _dense(logits, "logits")
         labels = _req(labels, "labels", torch.int64).contiguous()
         B, Cc, H, W = logits.shape
@@ -569,18 +644,19 @@ class _SoftmaxCE(torch.autograd.Function):
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         need = logits.requires_grad
         dl = torch.empty_like(logits) if need else None
+        inv = torch.empty(1, device=logits.device, dtype=torch.float32)
         ws = workspace(lib().wsdl_reduce_workspace(), logits.device)
-        check(lib().wsdl_softmax_ce_fwd_bwd(_p(logits), _p(labels), _p(loss), _p(dl), B, Cc, H, W, 1.0, _p(ws),
-                                            ws.numel(), _stream()))
-        ctx.save_for_backward(dl)
+        check(lib().wsdl_softmax_ce_fwd_bwd(_p(logits), _p(labels), _p(loss), _p(dl), _p(inv), B, Cc, H, W, 1.0,
+                                            int(ignore_index), _p(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(dl, inv)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dl,) = ctx.saved_tensors
+        dl, inv = ctx.saved_tensors
         out = torch.empty_like(dl)
-        check(lib().wsdl_scale_by_device_scalar(_p(dl), _p(_dense(g.reshape(1))), _p(out), dl.numel(), _stream()))
-        return out, None
+        check(lib().wsdl_scale_by_device_scalar(_p(dl), _p(_dense(g.reshape(1)) * inv), _p(out), dl.numel(), _stream()))
+        return out, None, None
 
 
 class _PairwiseAffinityLoss(torch.autograd.Function):
@@ -681,8 +757,8 @@ def add_act(a, b, relu=False):
     return _AddAct.apply(a, b, bool(relu))
 
 
-def cross_entropy(logits, labels):
-    return _SoftmaxCE.apply(logits, labels)
+def cross_entropy(logits, labels, ignore_index=-100):
+    return _SoftmaxCE.apply(logits, labels, ignore_index)
 
 
 def pairwise_affinity_loss(preds, image, window=5, sigma_color=0.1, sigma_space=0.0, apply_softmax=True,
