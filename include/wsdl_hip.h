@@ -39,8 +39,25 @@ const char* wsdl_last_error(void);
 int wsdl_version(void);               /* 10000*major + 100*minor + patch */
 const char* wsdl_target_arch(void);   /* "gfx950" */
 
-/* tuning knobs (A/B experiments): "occupancy_cap" 0/1 - pad the LDS request of the conv kernels so that a
- * CU holds at most ceil(blocks/256) workgroups (even placement).  Default 1. */
+/* Process-wide options (plain globals: set them before launching work, not while another thread is inside the
+ * library - calls are re-entrant across streams only for a fixed option set).  Changing "conv_split" /
+ * "conv_arith" changes what the weight layout buffers hold: re-run wsdl_conv2d_prep_weights afterwards.
+ *   conv_arith     1*  arithmetic of the split kernels: 1 = fp16x2 (three 16-bit MFMAs per fp32 product, per-tensor
+ *                      power-of-two scales from the amax arguments), 0 = bf16x3 (six MFMAs, no scales)
+ *   conv_split     1*  0 = forward / input-gradient convolutions on the exact-fp32 MFMA kernels everywhere
+ *   wgrad_split    1*  0 = weight gradients on the exact-fp32 MFMA kernels everywhere
+ *   tile256        1*  256x128 workgroup tiles (512 threads) where they still give >= 256 workgroups
+ *   t256_bk32      1*  K chunks of 32 in the 256x128 form
+ *   split_bk32     1*  K chunks of 32 in the small-tile split forms;   bk32  1*  same for the fp32 kernels
+ *   ksplit_big     1*  128x128 tiles + 2 K slices for grids of 200..399 tiles with K >= 2048
+ *   tile_threshold 400* workgroups below which the half-size pixel tile is used
+ *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
+ *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
+ *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers
+ *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
+ *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
+ *   occupancy_cap  0*  pad the conv kernels' LDS request so that a CU holds at most ceil(blocks/256) workgroups
+ * (* = default). */
 int wsdl_set_option(const char* name, int value);
 
 /* ---- per-kernel-class timing (bench.py roofline leg) --------------------------------------
@@ -48,20 +65,21 @@ int wsdl_set_option(const char* name, int value);
  * launch stream.  wsdl_prof_collect synchronises the events and returns, per class, the number of
  * launches, summed milliseconds and summed algorithmic work (flops for conv classes, bytes else).
  * Classes are kernel instantiations, so a class lines up with one row of `rocprofv3 --stats`. */
-enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_kernel<128,128,2,true>  (forward + dgrad launches) */
+enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_fast_kernel<128,128,2,16> (forward + dgrad launches) */
        WSDL_PROF_IGEMM_128x128_U = 1,  /* conv_igemm_kernel<128,128,2,false> (K not a multiple of 16)     */
        WSDL_PROF_IGEMM_128x64_A = 2, WSDL_PROF_IGEMM_128x64_U = 3,
        WSDL_PROF_IGEMM_64x256_A = 4, WSDL_PROF_IGEMM_64x256_U = 5,
        WSDL_PROF_IGEMM_64x128_A = 6, WSDL_PROF_IGEMM_64x128_U = 7,
        WSDL_PROF_WGRAD_128x128 = 8,    /* conv_wgrad_kernel<128,128,2> */
        WSDL_PROF_WGRAD_64x128 = 9,     /* conv_wgrad_kernel<64,128,1>  */
-       WSDL_PROF_WGRAD_FAST_128x128 = 10,  /* conv_wgrad_fast_kernel<128,128,2> */
+       WSDL_PROF_WGRAD_FAST_128x128 = 10,  /* conv_wgrad_fast_kernel<128,128,2,16> (and its 128x64 / 64x128 / 64x64 forms) */
        WSDL_PROF_PAIRWISE = 11, WSDL_PROF_LAYERCAM = 12,
-       /* bf16x3-split kernels (six bf16 MFMAs per fp32 product; work counted in fp32-equivalent FLOPs) */
-       WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16,256> (forward + dgrad launches) */
+       /* split kernels (three fp16 / six bf16 MFMAs per fp32 product; work counted in fp32-equivalent FLOPs);
+        * the last template argument is the arithmetic (1 = fp16x2, 0 = bf16x3) */
+       WSDL_PROF_SPLIT_128x128 = 13,   /* conv_igemm_split_kernel<128,128,2,16,256,AR> (forward + dgrad launches) */
        WSDL_PROF_SPLIT_128x64 = 14, WSDL_PROF_SPLIT_64x256 = 15, WSDL_PROF_SPLIT_64x128 = 16,
-       WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128> */
-       WSDL_PROF_SPLIT_256x128 = 18,   /* conv_igemm_split_kernel<256,128,4,16,512> */
+       WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128,AR> */
+       WSDL_PROF_SPLIT_256x128 = 18,   /* conv_igemm_split_kernel<256,128,4,32|16,512,AR> */
        WSDL_PROF_NCLASSES = 19 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
@@ -71,12 +89,15 @@ int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* to
 int wsdl_prof_reset(void);
 
 /* ---- convolution: implicit GEMM on the matrix cores -------------------------------------------
- * Two arithmetic paths with the same fp32-level accuracy (tools/conv_accuracy.py, tests/test_hip_ops.py):
+ * Arithmetic paths, all at fp32-level accuracy (tools/conv_accuracy.py, tests/test_hip_ops.py measure them against fp64):
  *   fp32 : v_mfma_f32_32x32x2_f32, exact fp32 fma chains;
- *   split: every fp32 operand is split exactly into three bf16 pieces and a product is six
- *          v_mfma_f32_32x32x16_bf16 partial products accumulated in fp32 (dropped terms <= 2^-23 |a*b|);
- *          used whenever the contracted channel count is a multiple of 16 and kh*kw <= 9
- *          (wsdl_set_option("conv_split", 0) / ("wgrad_split", 0) select the fp32 kernels everywhere).
+ *   split: every fp32 operand is split exactly into 16-bit pieces and a product is a few 16-bit MFMA partial products
+ *          accumulated in fp32 - used whenever the contracted channel count is a multiple of 16 and kh*kw <= 9
+ *          (wsdl_set_option("conv_split", 0) / ("wgrad_split", 0) select the fp32 kernels everywhere):
+ *            fp16x2 (default): x*s = h + l in fp16 (22 bits), three v_mfma_f32_32x32x16_f16 per product; s is a power of
+ *                    two per tensor, derived in the kernel from the `*_amax` device scalars (>= max|tensor|, e.g. from
+ *                    wsdl_bn_train_fwd / wsdl_amax), which are therefore REQUIRED (non-NULL) for these launches;
+ *            bf16x3 ("conv_arith" 0): x = h + m + l in bf16 (24 bits), six v_mfma_f32_32x32x16_bf16, amax unused.
  * Replaces the ATen conv2d forward / input-gradient / weight-gradient reached from
  *   torchvision ResNet-50 and DeepLabV3 convs called at TraditionalModel/ClassificationModel.py:29-33,
  *   TraditionalModel/SegmentationModel.py:102,110, TraditionalModel/AlternatingDirectionCutLoss.py:697-703,
@@ -87,8 +108,9 @@ int wsdl_prof_reset(void);
 /* Re-layout w[Cout][Cin][kh][kw] for the kernels.  The layout buffers are opaque to the caller; their size
  * comes from wsdl_conv2d_weight_layout_bytes (dgrad = 0: forward layout, 1: input-gradient layout):
  *   plain  (fp32 MFMA kernels)      : wt_fwd[(tap*Cin+ci)][Cout], wt_dgrad[(tap*Cout+co)][Cin]  fp32;
- *   split  (bf16x3 kernels, used when the contracted channel count % 16 == 0 and kh*kw <= 9):
- *            [(k/16)][row][h|m|l][k%16] bf16, every weight split exactly into three bf16 pieces.
+ *   split  (used when the contracted channel count % 16 == 0 and kh*kw <= 9):
+ *            [(k/16)][row][piece][k%16] 16-bit pieces (fp16x2: w * 2^e = h + l, 4 bytes per weight; bf16x3: h + m + l,
+ *            6 bytes per weight) + a 16-byte trailer holding max|w| (the scale the kernels derive 2^e from).
  * *is_plain (optional) tells which one the current options select; for a plain 1x1 kernel the dgrad layout
  * equals w itself.  Either destination of prep_weights may be NULL. */
 size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dgrad, int* is_plain);
@@ -104,6 +126,8 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y,
                     int stride, int pad, int dil,
                     const float* scale, const float* shift, const float* residual, int relu,
                     long long x_bs, long long y_bs, long long res_bs,
+                    const float* x_amax /* device scalar >= max|x| (fp16x2 split launches; else may be NULL) */,
+                    float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
                     void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* Optional scratch for forward / dgrad: grids too small to fill 256 CUs (small batches of small maps) are split
  * along K into slabs summed in fixed order.  Returns 0 when the geometry does not benefit; ws may be NULL. */
@@ -114,7 +138,7 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
 int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate,
-                      long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream);
+                      long long dy_bs, const float* dy_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
 /* dw[Cout][Cin][kh][kw] = sum_{b,oh,ow} dy * x_shifted  (+ dw if accumulate).  Split over pixel
  * ranges into fp32 slabs in `ws`, summed in fixed order by a second kernel (bitwise reproducible). */
@@ -123,8 +147,11 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate,
-                      long long x_bs, long long dy_bs,
+                      long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* out = max|x| over B images of per_image contiguous floats (batch stride x_bs elements, 0 = dense); zeroes `out`
+ * first.  For tensors whose producer did not publish an amax (network input, concatenations, dropout outputs). */
+int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, wsdl_stream_t stream);
 
 /* dbias[co] = sum_{b,hw} dy  (classifier[4] / fc bias gradient). */
 int wsdl_bias_grad(const float* dy, float* dbias, int B, int C, int HW, long long dy_bs,
@@ -138,6 +165,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float* save_mean, float* save_invstd, float* running_mean, float* running_var,
                       float momentum, float eps, int B, int C, int HW,
                       const float* residual, int relu, long long y_bs,
+                      float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* Backward of the above.  y (the forward output) is needed only when relu != 0 (mask = y > 0).
  * dres (optional) receives the masked upstream gradient (the residual branch's gradient). */
@@ -146,6 +174,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       float* dx, float* dgamma, float* dbeta, float* dres,
                       int B, int C, int HW, int relu, int accumulate_param_grads,
                       long long dy_bs, long long y_bs,
+                      float* dx_amax /* optional: atomicMax of max|dx| into a ZEROED device scalar */,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (fed to wsdl_conv2d_fwd). */
 int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,

@@ -126,13 +126,17 @@ def test_split_arithmetic_is_fp32_accurate(dev):
 
 
 def test_weight_layout_sizes(dev):
-    """The opaque layout buffers: 4 bytes per weight (fp32 k-major) or 6 (three bf16 pieces), by shape and option."""
+    """The opaque layout buffers: 4 bytes per weight (fp32 k-major; two fp16 pieces + a 16-byte amax trailer) or 6 (three
+    bf16 pieces + trailer), by shape and option."""
     import ctypes
     from weaklysuperviseddl_amd import ops
     from weaklysuperviseddl_amd._lib import lib
     plain = ctypes.c_int(-1)
     n = 64 * 32 * 9
-    assert lib().wsdl_conv2d_weight_layout_bytes(64, 32, 3, 3, 0, ctypes.byref(plain)) == n * 6 and plain.value == 0
+    assert lib().wsdl_conv2d_weight_layout_bytes(64, 32, 3, 3, 0, ctypes.byref(plain)) == n * 4 + 16 and plain.value == 0
+    ops.set_option("conv_arith", 0)
+    assert lib().wsdl_conv2d_weight_layout_bytes(64, 32, 3, 3, 0, ctypes.byref(plain)) == n * 6 + 16 and plain.value == 0
+    ops.set_option("conv_arith", 1)
     assert lib().wsdl_conv2d_weight_layout_bytes(64, 3, 7, 7, 0, ctypes.byref(plain)) == 64 * 3 * 49 * 4 and plain.value == 1
     assert lib().wsdl_conv2d_weight_layout_bytes(2, 256, 1, 1, 1, ctypes.byref(plain)) == 2 * 256 * 4 and plain.value == 1
     ops.set_option("conv_split", 0)

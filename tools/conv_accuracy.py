@@ -1,10 +1,14 @@
-"""Accuracy of the two convolution arithmetic paths against an fp64 reference (GPU, through the C ABI).
+"""Accuracy of the convolution arithmetic paths against an fp64 reference (GPU, through the C ABI).
 
 For a handful of DeepLabV3-R50 shapes: forward, input-gradient and weight-gradient results of
-  * the fp32-MFMA kernels            (wsdl_set_option("conv_split", 0)), and
-  * the bf16x3-split kernels         (conv_split = 1: six bf16 MFMAs per product, conv_split.h)
-are compared with torch's fp64 convolution on the same device.  Reported: max |err| / max |ref| and
-rms err / rms ref.  The split path must not be worse than the fp32 path by more than a small factor.
+  * the fp32-MFMA kernels            (wsdl_set_option("conv_split", 0): exact fp32 fma chains),
+  * the bf16x3-split kernels         (conv_arith = 0: six bf16 MFMAs per product), and
+  * the fp16x2-split kernels         (conv_arith = 1, the default: three fp16 MFMAs per product, per-tensor
+                                      power-of-two scales - conv_split.h)
+are compared with torch's fp64 convolution on the same device.  Reported: rms err / rms ref (and max |err| / max |ref|
+for the default path).  Inputs: unit-variance noise, and a "wide" variant whose channels / pixels span seven decades
+and whose gradients are tiny (1e-6) - what the scales have to cope with.  A split path must not be worse than the
+fp32 path by more than a small factor.
 
     python tools/conv_accuracy.py
 """
@@ -38,34 +42,46 @@ def errs(a, ref):
     return (d.abs().max() / ref.abs().max()).item(), (d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
 
 
+MODES = (("fp32", dict(conv_split=0, wgrad_split=0, conv_arith=1)),
+         ("bf16x3", dict(conv_split=1, wgrad_split=1, conv_arith=0)),
+         ("fp16x2", dict(conv_split=1, wgrad_split=1, conv_arith=1)))
+
+
 def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    print(f"{'shape':34s} {'pass':6s} {'fp32 max':>10s} {'fp32 rms':>10s} {'split max':>10s} {'split rms':>10s}")
-    worst = 0.0
+    print(f"{'shape':34s} {'data':5s} {'pass':6s} {'fp32 rms':>10s} {'bf16x3 rms':>11s} {'fp16x2 rms':>11s} {'fp16x2 max':>11s}")
+    worst = {"bf16x3": 0.0, "fp16x2": 0.0}
     for Cin, Cout, k, s, d, H, B in SHAPES:
         pad = (k // 2) * d if k > 1 else 0
-        x = torch.randn(B, Cin, H, H, device=dev)
-        w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
-        ref = F.conv2d(x.double(), w.double(), None, s, pad, d)
-        dy = torch.randn_like(ref, dtype=torch.float32)
-        ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad, d)
-        ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, pad, d)
-        res = {}
-        for mode in (0, 1):
-            ops.set_option("conv_split", mode)
-            ops.set_option("wgrad_split", mode)
-            wf, wd = ops.prep_weights(w)
-            y = ops.conv2d_fwd(x, wf, w.shape, s, pad, d)
-            dx = ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d)
-            dw = ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)
-            res[mode] = (errs(y, ref), errs(dx, ref_dx), errs(dw, ref_dw))
-        name = f"{Cin}->{Cout} k{k} s{s} d{d} {H}x{H} B{B}"
-        for i, ps in enumerate(("fwd", "dgrad", "wgrad")):
-            f32, sp = res[0][i], res[1][i]
-            print(f"{name:34s} {ps:6s} {f32[0]:10.2e} {f32[1]:10.2e} {sp[0]:10.2e} {sp[1]:10.2e}")
-            worst = max(worst, sp[1] / f32[1])
-    print(f"worst split/fp32 rms-error ratio: {worst:.2f}")
+        for data in ("unit", "wide"):
+            x = torch.randn(B, Cin, H, H, device=dev)
+            w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
+            if data == "wide":
+                x = torch.relu(x) * torch.logspace(-4, 3, Cin, device=dev).view(1, Cin, 1, 1)
+                w = w * torch.logspace(-2, 2, Cout, device=dev).view(Cout, 1, 1, 1)
+            ref = F.conv2d(x.double(), w.double(), None, s, pad, d)
+            dy = torch.randn_like(ref, dtype=torch.float32)
+            if data == "wide":
+                dy = dy * 1e-6 * torch.logspace(-3, 3, dy.shape[-1], device=dev)
+            ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad, d)
+            ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, pad, d)
+            res = {}
+            for mode, opts in MODES:
+                for o, v in opts.items():
+                    ops.set_option(o, v)
+                wf, wd = ops.prep_weights(w)
+                y = ops.conv2d_fwd(x, wf, w.shape, s, pad, d)
+                dx = ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d)
+                dw = ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)
+                res[mode] = (errs(y, ref), errs(dx, ref_dx), errs(dw, ref_dw))
+            name = f"{Cin}->{Cout} k{k} s{s} d{d} {H}x{H} B{B}"
+            for i, ps in enumerate(("fwd", "dgrad", "wgrad")):
+                f32, b3, h2 = res["fp32"][i], res["bf16x3"][i], res["fp16x2"][i]
+                print(f"{name:34s} {data:5s} {ps:6s} {f32[1]:10.2e} {b3[1]:11.2e} {h2[1]:11.2e} {h2[0]:11.2e}")
+                worst["bf16x3"] = max(worst["bf16x3"], b3[1] / f32[1])
+                worst["fp16x2"] = max(worst["fp16x2"], h2[1] / f32[1])
+    print("worst split/fp32 rms-error ratio: bf16x3 %.2f, fp16x2 %.2f" % (worst["bf16x3"], worst["fp16x2"]))
 
 
 if __name__ == "__main__":

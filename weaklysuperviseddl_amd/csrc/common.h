@@ -86,6 +86,30 @@ __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// max|v| of what a kernel stored, into a zero-initialised device scalar (the fp16x2 convolutions scale their operands by
+// a power of two derived from it).  One atomic per WORKGROUP at most, and only when the workgroup's maximum beats the
+// value already there (a relaxed device-scope read; a stale - smaller - value only costs an atomic): thousands of
+// atomics on one address serialise (a per-wave version made the two-pass BatchNorm kernels 2x slower).  The bit patterns
+// of non-negative floats order like the floats.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void publish_amax(float m, float* __restrict__ amax) {
+    __shared__ float s_amax[16];
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, s_amax[i]);
+        if (m > 0.f) {
+            unsigned* a = reinterpret_cast<unsigned*>(amax);
+            const unsigned bits = __builtin_bit_cast(unsigned, m);
+            if (bits > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, bits);
+        }
+    }
+}
+__device__ __forceinline__ float amax4(float m, const float4& v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in thread 0.
 __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats */) {
     v = wave_sum(v);

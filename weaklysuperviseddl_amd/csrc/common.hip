@@ -70,9 +70,9 @@ const char* wsdl_prof_class_name(int cls) {
         "conv_igemm_fast_kernel<64, 128, 1, 32>", "conv_igemm_kernel<64, 128, 1, false>",
         "conv_wgrad_kernel<128, 128, 2>", "conv_wgrad_kernel<64, 128, 1>", "conv_wgrad_fast_kernel<128, 128, 2, 16>",
         "pairwise_kernel", "layercam_partial_kernel",
-        "conv_igemm_split_kernel<128, 128, 2, 16, 256>", "conv_igemm_split_kernel<128, 64, 2, 32, 256>",
-        "conv_igemm_split_kernel<64, 256, 1, 16, 256>", "conv_igemm_split_kernel<64, 128, 1, 32, 256>",
-        "conv_wgrad_split32_kernel<128, 128>", "conv_igemm_split_kernel<256, 128, 4, 16, 512>"};
+        "conv_igemm_split_kernel<128, 128, 2, 16, 256, AR>", "conv_igemm_split_kernel<128, 64, 2, 32, 256, AR>",
+        "conv_igemm_split_kernel<64, 256, 1, 16, 256, AR>", "conv_igemm_split_kernel<64, 128, 1, 32, 256, AR>",
+        "conv_wgrad_split32_kernel<128, 128, AR>", "conv_igemm_split_kernel<256, 128, 4, 32, 512, AR>"};
     return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
 }
 

@@ -48,6 +48,9 @@ struct ConvP {
     int nb;
     int b_ow0[4], b_own[4], b_tile0[5];
     int grid_x;         // host only: pixel tiles of the launch when banded (0 = cdiv(P, BN))
+    int xcd_py;         // split kernels: > 0 = XCD-aware tile order with this many row groups (1, 2, 4 or 8); 0 = launch order
+    const float* x_amax;   // split kernels, fp16x2 arithmetic: device scalar >= max|x| (the scale of the activation operand)
+    float* y_amax;         // optional: receives max|y| of what the epilogue stores (atomicMax into a zeroed device scalar)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -593,6 +596,7 @@ struct WgradP {
     int slab0;                    // first slab index of this launch
     int nb, splits;               // column bands inside one launch: blockIdx.z = band * splits + split
     int b_ow0[4], b_own[4], b_cps[4];   // per band: window and 32-pixel chunks per split
+    const float* x_amax;                // split kernel, fp16x2 arithmetic: device scalar >= max|x|
 };
 
 #include "conv_split.h"
@@ -1196,22 +1200,58 @@ void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
 // bf16x3-split kernels (conv_split.h): which (rows, K-channels, taps) shapes use them.  A function of the
 // weight shape alone, so the layout kernel and the convolution agree on what the layout buffer holds.
 int g_conv_split = 1;
+int g_conv_arith = 1;    // arithmetic of the split kernels: 1 = fp16x2 (three MFMAs per product, per-tensor power-of-two
+                         // scales), 0 = bf16x3 (six MFMAs, no scales) - see conv_split.h
 int g_split_bk32 = 1;    // K chunk 32 on the small-tile split configurations
 bool split_eligible(int rows, int kc, int T) {
-    return g_conv_split && kc % 16 == 0 && T <= 9 && (long long)T * kc * rows * 6 < (1ll << 31);
+    return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
+}
+
+int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
+// row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
+// worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
+int choose_xcd_py(const ConvP& p, int gx, int gy) {
+    if (!g_xcd_map || p.ksplit > 1 || ((long long)gx * gy) % 8 != 0) return 0;
+    const double wb = (g_conv_arith ? 4.0 : 6.0) * (double)p.K * p.Cout, xb = 4.0 * (double)p.B * p.Cin * p.H * p.W;
+    int best = 0;
+    double best_cost = 0.0;
+    for (int py = 1; py <= 8; py *= 2) {
+        const int px = 8 / py;
+        if (gy % py || gx % px) continue;
+        if (g_xcd_map > 10 && py != g_xcd_map - 10) continue;     // 11 / 12 / 14 / 18: force py = 1 / 2 / 4 / 8
+        const double cost = wb * px + xb * py;
+        if (!best || cost < best_cost) { best = py; best_cost = cost; }
+    }
+    if (g_xcd_map == 1 && (best <= 1 || best_cost > 0.9 * (wb * 8 + xb))) return 0;
+    return best;
 }
 
 template <int BM, int BN, int WM, int BK>
-void launch_split(const ConvP& p, hipStream_t s, dim3 grid) {
+void launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
+    ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
-    hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
+    p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
+    if (g_conv_arith)
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 0>), grid, dim3(kThreads), 0, s, p);
 }
 
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
-void launch_split_256x128(const ConvP& p, hipStream_t s) {
+int g_t256_bk32 = 1;      // K chunks of 32 in the 256x128 form (half the barriers; +3.5 % measured on the bf16x3 kernel)
+void launch_split_256x128(const ConvP& p_in, hipStream_t s) {
+    ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
-    hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512>), grid, dim3(512), 0, s, p);
+    p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
+    const bool bk32 = g_t256_bk32 && p.Cin % 32 == 0;
+    if (g_conv_arith) {
+        if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
+    } else {
+        if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 0>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
+    }
 }
 
 template <int BM, int BN, int WM>
@@ -1270,6 +1310,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     p.own = p.OW;
     p.nb = 1;
     p.grid_x = 0;
+    p.xcd_py = 0;
     {
         const int ks = igemm_ksplit(p.P, p.Cout, p.Cin, p.KH * p.KW, p.bh < 0 ? -p.bh : p.bh);
         if (ks > 1 && ws && ws_bytes >= (size_t)ks * p.Cout * p.P * sizeof(float) && p.x_bytes != 0 &&
@@ -1284,6 +1325,15 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         wsdl::set_error("conv: activation extent >= 2 GiB is not supported by the split-bf16 kernels "
                         "(wsdl_set_option(\"conv_split\", 0) selects the fp32 kernels)");
         return WSDL_EINVAL;
+    }
+    if (split && g_conv_arith && !p.x_amax) {
+        wsdl::set_error("conv: the fp16x2 split kernels need the activation tensor's amax (x_amax / dy_amax is null)");
+        return WSDL_EINVAL;
+    }
+    float* amax_after = nullptr;
+    if (p.y_amax && !(split && p.ksplit == 1)) {
+        amax_after = p.y_amax;
+        p.y_amax = nullptr;
     }
     const bool aligned = split || ((p.Cin % 16) == 0 && (p.Cout % 4) == 0 && p.x_bytes != 0 &&
                                    (long long)p.K * p.Cout * 4 < (1ll << 31));
@@ -1349,6 +1399,13 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
                                dim3(256), 0, s, p);
     }
     WSDL_LAUNCH_CHECK();
+    if (amax_after) {
+        // the kernel that ran has no amax epilogue (fp32 kernels, split-K reduce): one read pass over the output
+        const long long per = (long long)p.Cout * p.OH * p.OW, total = (long long)p.B * per;
+        hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 2048)), dim3(256), 0, s, p.y, per,
+                           p.y_bs, total, amax_after);
+        WSDL_LAUNCH_CHECK();
+    }
     return WSDL_OK;
 }
 
@@ -1498,6 +1555,9 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
+    if (!strcmp(name, "t256_bk32")) { g_t256_bk32 = value; return WSDL_OK; }
+    if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
+    if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
@@ -1512,7 +1572,7 @@ size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dg
     const bool split = dgrad ? split_eligible(Cin, Cout, T) : split_eligible(Cout, Cin, T);
     if (is_plain) *is_plain = split ? 0 : 1;
     const size_t n = (size_t)Cout * Cin * T;
-    return split ? n * 6 : n * 4;
+    return split ? (size_t)split_layout_bytes(g_conv_arith, (long long)T * (dgrad ? Cout : Cin), dgrad ? Cin : Cout) : n * 4;
 }
 
 int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int Cout, int Cin,
@@ -1527,9 +1587,23 @@ int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int C
     float* pd = dg_split ? nullptr : static_cast<float*>(wt_dgrad);
     if (fwd_split || dg_split) {
         dim3 grid(wsdl::cdiv(Cin, 32), wsdl::cdiv(Cout, 32));
-        hipLaunchKernelGGL(prep_weights_split_kernel, grid, dim3(256), 0, wsdl::as_stream(stream), w,
-                           fwd_split ? static_cast<unsigned char*>(wt_fwd) : nullptr,
-                           dg_split ? static_cast<unsigned char*>(wt_dgrad) : nullptr, Cout, Cin, T);
+        unsigned char* f8 = fwd_split ? static_cast<unsigned char*>(wt_fwd) : nullptr;
+        unsigned char* d8 = dg_split ? static_cast<unsigned char*>(wt_dgrad) : nullptr;
+        if (g_conv_arith) {
+            // the tensor's max|w| is reduced into the trailer of one layout; the layout kernel scales by it and copies it
+            // into the other layout's trailer
+            const long long body = split_layout_bytes(1, (long long)T * Cin, Cout) - 16;
+            float* amax = reinterpret_cast<float*>((f8 ? f8 : d8) + body);
+            WSDL_HIP_CHECK(hipMemsetAsync(amax, 0, 16, wsdl::as_stream(stream)));
+            hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 1024)), dim3(256), 0,
+                               wsdl::as_stream(stream), w, total, total, total, amax);
+            hipLaunchKernelGGL(prep_weights_split_kernel<1>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
+                               T, amax);
+        } else {
+            hipLaunchKernelGGL(prep_weights_split_kernel<0>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
+                               T, static_cast<const float*>(nullptr));
+        }
+        WSDL_LAUNCH_CHECK();
     }
     if (pf || pd) {
         if (T <= 9 && Cout <= 65535 * 32) {
@@ -1553,7 +1627,8 @@ int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int C
 int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin, int H, int W,
                     int Cout, int kh, int kw, int stride, int pad, int dil, const float* scale,
                     const float* shift, const float* residual, int relu, long long x_bs,
-                    long long y_bs, long long res_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                    long long y_bs, long long res_bs, const float* x_amax, float* y_amax, void* ws, size_t ws_bytes,
+                    wsdl_stream_t stream) {
     WSDL_REQUIRE(x && wt_fwd && y, "conv2d_fwd: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
@@ -1567,13 +1642,14 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin
     p.res_bs = res_bs ? res_bs : (long long)Cout * OH * OW;
     WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
     p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
+    p.x_amax = x_amax; p.y_amax = y_amax;
     return launch_igemm_sliced(p, OH * OW, (long long)Cin * H * W, wsdl::as_stream(stream),
                                2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
 }
 
 int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                      long long dy_bs, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                      long long dy_bs, const float* dy_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && wt_dgrad && dx, "conv2d_dgrad: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
@@ -1588,6 +1664,7 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
     p.res_bs = p.y_bs;
     WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
     p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
+    p.x_amax = dy_amax; p.y_amax = nullptr;
     return launch_igemm_sliced(p, H * W, (long long)Cout * OH * OW, wsdl::as_stream(stream),
                                2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
 }
@@ -1605,7 +1682,7 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
 // bytes of the pre-split dY image of the 32-pixel-chunk weight-gradient kernel (0: kernel not used)
 static size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
     if (!wgrad_chunk32(Cout, Cin, N)) return 0;
-    const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * kW2Row;
+    const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * w2row_bytes(g_conv_arith);
     return n < (1ull << 31) ? n : 0;
 }
 
@@ -1637,8 +1714,8 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
 
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
-                      long long x_bs, long long dy_bs, void* ws, size_t ws_bytes,
-                      wsdl_stream_t stream) {
+                      long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
+                      size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
@@ -1648,7 +1725,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         float* dwt = static_cast<float*>(ws);
         if (int rc = wsdl_conv2d_wgrad(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
                                        dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
-                                       static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream))
+                                       dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream))
             return rc;
         hipLaunchKernelGGL(transpose_add_kernel, dim3(wsdl::cdiv(Cout, 32), wsdl::cdiv(Cin, 32)), dim3(32, 8), 0,
                            wsdl::as_stream(stream), dwt, dw, Cout, Cin, accumulate);
@@ -1662,6 +1739,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     p.N = kh * kw * Cin; p.P = B * OH * OW;
     p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
+    p.x_amax = x_amax;
     const unsigned long long live_all = live_taps(H, W, OH, OW, kh, kw, stride, pad, dil);
     const int S = wgrad_splits(Cout, Cin, p.N, p.P, __builtin_popcountll(live_all) * Cin);
     Band bands[8];
@@ -1693,7 +1771,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
             const int nb_img = (int)std::min<long long>(per, B - b0);
             if (int rc = wsdl_conv2d_wgrad(x + (long long)b0 * p.x_bs, dy + (long long)b0 * p.dy_bs, dw, nb_img, Cin, H, W,
                                            Cout, kh, kw, stride, pad, dil, (accumulate || b0 > 0) ? 1 : 0, p.x_bs, p.dy_bs,
-                                           ws, ws_bytes, stream))
+                                           x_amax, dy_amax, ws, ws_bytes, stream))
                 return rc;
         }
         return WSDL_OK;
@@ -1740,11 +1818,19 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 live_mask = live_all;            // dead taps: no workgroup writes their slab columns, the reduce skips them
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
                 const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
-                hipLaunchKernelGGL(dy_split_kernel, dim3((int)std::min<long long>((total + 255) / 256, 16384)), dim3(256), 0,
-                                   s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P);
                 dim3 grid(p.N / 128, Cout / 128, S);
-                hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
-                                   (unsigned)dys_bytes);
+                const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
+                if (g_conv_arith) {
+                    WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
+                    hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                    hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
+                                       (unsigned)dys_bytes, dy_amax);
+                } else {
+                    hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,
+                                       static_cast<const float*>(nullptr));
+                    hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 0>), grid, dim3(kThreads), 0, s, p, dys,
+                                       (unsigned)dys_bytes, static_cast<const float*>(nullptr));
+                }
             } else if (tBM == 128 && tBN == 128 && g_wgrad_bk == 32) {
                 dim3 grid(p.N / 128, Cout / 128, S);
                 hipLaunchKernelGGL((conv_wgrad_fast_kernel<128, 128, 2, 32>), grid, dim3(kThreads), lds128, s, p);
@@ -1785,6 +1871,17 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate,
                            live_mask);
     }
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && out && B > 0 && per_image > 0, "amax: bad arguments");
+    if (!x_bs) x_bs = per_image;
+    const long long total = (long long)B * per_image;
+    WSDL_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), wsdl::as_stream(stream)));
+    hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 2048)), dim3(256), 0,
+                       wsdl::as_stream(stream), x, per_image, x_bs, total, out);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

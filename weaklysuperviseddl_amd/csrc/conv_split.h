@@ -1,25 +1,40 @@
-// conv_split.h - the implicit-GEMM convolution on the bf16 matrix core with fp32-equivalent accuracy
+// conv_split.h - the implicit-GEMM convolution on the 16-bit matrix core with fp32-equivalent accuracy
 // (included by conv_igemm.hip inside its anonymous namespace; shares ConvP and the host-side tile logic).
 //
-// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand is split exactly into
-// three bf16 pieces  x = h + m + l  (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); 3 x 8 significant bits
-// cover fp32's 24), and a product a*b is evaluated as the six partial products whose weight is >= 2^-16:
-//     a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)
-// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms
-// (am*bl, al*bm, al*bl) are <= 2^-23 |a*b| together: the size of ONE fp32 rounding, while an fp32 fma chain of
-// length K makes K of them.  Six bf16 MFMAs replace sixteen fp32-MFMA-equivalents of issue time: 2.67x the
-// arithmetic peak at unchanged accuracy (tests/test_hip_ops.py measures both kernels against fp64).
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate.  Every fp32 operand is split EXACTLY into a few
+// 16-bit pieces and a product a*b is evaluated as the partial products that matter, each an exact 16-bit x 16-bit
+// product accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}.  Two arithmetics (template parameter AR):
 //
-// Data path: weights are split once per optimiser step by the layout kernel ([k/16][row][piece][16] bf16, so a
-// K-chunk of a row tile is one contiguous run copied to LDS with 16-byte loads); activations are split by the
-// loading thread between the global load and the LDS store (11 VALU ops per pair, hidden under the MFMAs of
-// the other resident wave).  LDS rows are  (BK/16) x [h|m|l] x 16 bf16  + 16 bytes of padding: a row stride that
-// is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots
-// of the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
+//   AR = 1, "fp16x2" (default): x*s = h + l, h = fp16(x*s), l = fp16(x*s - h) - 2 x 11 significant bits, residual
+//       <= 2^-22 |x| - and  a*b ~= ah*bh + (ah*bl + al*bh): THREE MFMAs per fp32 product.  fp16 has a 5-bit exponent, so
+//       each operand tensor is scaled by a power of two s (exact) that puts its largest magnitude in [2^14, 2^15): the
+//       host passes a device scalar amax >= max|x| per tensor (produced by the kernel that wrote the tensor), the
+//       kernel derives s from its exponent and the epilogue multiplies the accumulator by 1/(s_a*s_b).  Elements
+//       within 2^17 of the tensor's maximum keep the full 22 bits; smaller ones are represented to an ABSOLUTE
+//       2^-39 of the maximum (l drops into fp16's subnormal range) - far below an fp32 rounding of the dot product
+//       they enter.  Measured against float64 (tools/conv_accuracy.py, tests/test_hip_ops.py): rms error at or below that
+//       of the exact-fp32 MFMA chain for K >= 64 - the representation error (2^-22 per product, random sign) is smaller
+//       than what K fp32 accumulator roundings contribute, and three accumulations per k-step round less than six.
+//   AR = 0, "bf16x3": x = h + m + l (3 x 8 bits cover fp32's 24; no scaling: bf16 has fp32's exponent range) and the SIX
+//       products of weight >= 2^-16: ah*bh, ah*bm, am*bh, ah*bl, al*bh, am*bm (dropped terms <= 2^-23 |a*b|).  Round 1's
+//       kernel; kept as wsdl_set_option("conv_arith", 0) and as the A/B partner.
+//
+// The kernels are power-limited (same binary 30 % faster on all-zero operands; halving the MFMAs of the bf16x3
+// kernel at unchanged staging removed 26 % of its time; deeper pipelines, staggered wave roles and a three-image LDS
+// ring with fragments read one chunk ahead all measured SLOWER or equal - profiles/r02_notes.md): what pays is energy per
+// fp32-equivalent FLOP, which is what AR = 1 halves (MFMAs) and cuts by a third (LDS bytes, weight bytes).
+//
+// Data path: weights are split once per optimiser step by the layout kernel ([k/16][row][piece][16], so a K-chunk of
+// a row tile is one contiguous run copied to LDS with 16-byte loads); activations are split by the loading thread
+// between the global load and the LDS store.  LDS rows are (BK/16) x NP x 32 bytes + 16 bytes of padding: a row stride
+// that is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots of
+// the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -33,25 +48,93 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2));
 }
 
-constexpr int kSplitK16Bytes = 96;   // one row's 16 k values: 3 pieces x 16 bf16
+// (x0, x1), already scaled -> packed fp16 pairs of the two pieces (round to nearest even; x - h is exact in fp32)
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
+    f32x2 v = {x0, x1};
+    const half2v hv = __builtin_convertvector(v, half2v);
+    h = __builtin_bit_cast(unsigned, hv);
+    f32x2 r = {x0 - (float)hv[0], x1 - (float)hv[1]};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
+}
 
+// power-of-two scale that puts amax in [2^14, 2^15); 1 for amax = 0 / inf / NaN.  `e` returns its exponent.
+__device__ __forceinline__ float pow2_scale(float amax, int& e) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax) & 0x7fffffffu;
+    const int be = (int)(bits >> 23);                   // biased exponent
+    e = (bits == 0u || be == 255) ? 0 : 14 - (be - 127);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ float pow2(int e) {          // |e| <= 200: two exact factors
+    const int e1 = e / 2, e2 = e - e1;
+    return __builtin_bit_cast(float, (unsigned)(e1 + 127) << 23) * __builtin_bit_cast(float, (unsigned)(e2 + 127) << 23);
+}
 
-// One chunk of global loads is in flight in registers while the previous one is computed; deeper register rings
-// (2, 3 chunks) measured no faster - the kernel is power-limited, not latency-limited (profiles/r01_notes.md).
+template <int AR> struct SplitArith;
+template <> struct SplitArith<0> {
+    static constexpr int NP = 3;
+    using frag = bf16x8;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct SplitArith<1> {
+    static constexpr int NP = 2;
+    using frag = half8;
+    static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+// the partial products of one k-step, smallest terms first
+template <int AR, typename F>
+__device__ __forceinline__ f32x16 split_products(const F (&a)[SplitArith<AR>::NP], const F (&b)[SplitArith<AR>::NP], f32x16 c) {
+    using A = SplitArith<AR>;
+    if constexpr (AR == 0) {
+        c = A::mma(a[2], b[0], c);
+        c = A::mma(a[0], b[2], c);
+        c = A::mma(a[1], b[1], c);
+        c = A::mma(a[1], b[0], c);
+        c = A::mma(a[0], b[1], c);
+        c = A::mma(a[0], b[0], c);
+    } else {
+        c = A::mma(a[1], b[0], c);
+        c = A::mma(a[0], b[1], c);
+        c = A::mma(a[0], b[0], c);
+    }
+    return c;
+}
+
+constexpr int split_k16_bytes(int AR) { return AR ? 64 : 96; }     // one row's 16 k values: NP pieces x 16 x 2 bytes
+// the layout buffers end in a 16-byte trailer holding the tensor's amax (AR = 1)
+__host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_total, long long rows) {
+    return (k_total / 16) * rows * split_k16_bytes(AR) + 16;
+}
+
+// One chunk of global loads is in flight in registers while the previous one is computed.
 // NT threads: 256 (4 waves, two workgroups per CU) or 512 (8 waves, one 256x128 workgroup per CU: every activation
 // element is split by half as many workgroups and the weight tile is shared by twice the pixels... per FLOP).
-template <int BM, int BN, int WM, int BK, int NT = kThreads>
+//
+// XCD-aware tile order (p.xcd_py > 0): workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.
+// The kernel re-labels its workgroup so that XCD c owns a (pixel-group, row-group) rectangle of the tile grid:
+// py row groups x 8/py pixel groups.  Each XCD then streams 1/py of the weights and py/8 of the activations instead of
+// all the weights and 1/8 of the activations; the host picks py per launch from the two operands' byte counts.
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
+    using Ar = SplitArith<AR>;
+    using frag = typename Ar::frag;
+    constexpr int NP = Ar::NP;
+    constexpr int K16B = split_k16_bytes(AR);
     constexpr int WN = (NT / 64) / WM;
     constexpr int MI = BM / WM / 32, NI = BN / WN / 32;
     static_assert(MI >= 1 && NI >= 1 && MI * 32 * WM == BM && NI * 32 * WN == BN, "bad tile");
     static_assert(BK == 16 || BK == 32, "K chunk");
     constexpr int KS = BK / 16;                          // MFMA k-steps per chunk
-    constexpr int ROW = KS * kSplitK16Bytes + 16;        // LDS row stride in bytes (odd multiple of 16)
-    constexpr int A_UPS = BM * 6;                        // 16-byte units of one k16 slab of the row tile
-    constexpr int A_U = (KS * A_UPS + NT - 1) / NT;   // units per thread per chunk
+    constexpr int ROW = KS * K16B + 16;                  // LDS row stride in bytes (odd multiple of 16)
+    constexpr int UPR = K16B / 16;                       // 16-byte units per row of one k16 slab
+    constexpr int A_UPS = BM * UPR;                      // 16-byte units of one k16 slab of the row tile
+    constexpr int A_U = (KS * A_UPS + NT - 1) / NT;      // units per thread per chunk
     constexpr bool A_EXACT = A_U * NT == KS * A_UPS;
-    constexpr int B_STEP = NT / BN;                // threads sharing one pixel
+    constexpr int B_STEP = NT / BN;                      // threads sharing one pixel
     constexpr int B_PER = BK / B_STEP;                   // consecutive k (input channels) per thread
     static_assert(B_PER == 4 || B_PER == 8 || B_PER == 16 || B_PER == 32, "B tile");
     constexpr unsigned kOOB = 0x80000000u;
@@ -63,27 +146,45 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int m0 = blockIdx.y * BM;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_py > 0) {
+        // host guarantees: gridDim.x * gridDim.y % 8 == 0, gridDim.y % py == 0, gridDim.x % (8 / py) == 0
+        const int gx = gridDim.x;
+        const int L = by * gx + bx;
+        const int xcd = L & 7, idx = L >> 3;
+        const int py = p.xcd_py, px = 8 / py;
+        const int lx = gx / px, ly = (int)gridDim.y / py;
+        bx = (xcd / py) * lx + idx % lx;
+        by = (xcd % py) * ly + idx / lx;
+    }
+    const int m0 = by * BM;
     int w_ow0 = p.ow0, w_own = p.own, w_tile0 = 0;
     if (p.nb > 1) {
         w_ow0 = p.b_ow0[0];
         w_own = p.b_own[0];
 #pragma unroll
         for (int i = 1; i < 4; ++i)
-            if (i < p.nb && (int)blockIdx.x >= p.b_tile0[i]) {
+            if (i < p.nb && bx >= p.b_tile0[i]) {
                 w_ow0 = p.b_ow0[i];
                 w_own = p.b_own[i];
                 w_tile0 = p.b_tile0[i];
             }
     }
     const int W_P = p.nb > 1 ? p.B * p.OH * w_own : p.P;
-    const int n0 = ((int)blockIdx.x - w_tile0) * BN;
+    const int n0 = (bx - w_tile0) * BN;
     const int OHOW = p.OH * p.OW;
     const int HW = p.H * p.W;
 
+    const int wbytes = (p.K / 16) * p.Cout * K16B;       // the layout without its trailer
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, (p.K / 16) * p.Cout * kSplitK16Bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, wbytes, 0x00020000);
+    float xs = 1.f, out_scale = 1.f;
+    if constexpr (AR == 1) {
+        int ex, ew;
+        xs = pow2_scale(*p.x_amax, ex);
+        (void)pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) + wbytes), ew);
+        out_scale = pow2(-(ex + ew));
+    }
 
     const int pl = tid % BN, kr = tid / BN;
     const int pix = n0 + pl;
@@ -137,10 +238,10 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     for (int e = 0; e < A_U; ++e) {
         const int u = tid + e * NT;
         const int ks = u / A_UPS, v = u - ks * A_UPS;
-        const int row = v / 6, part = v - row * 6;
+        const int row = v / UPR, part = v - row * UPR;
         voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
-                        ? (unsigned)(ks * p.Cout * kSplitK16Bytes + (m0 * 6 + v) * 16) : kOOB;
-        lds_a[e] = (unsigned)(row * ROW + ks * kSplitK16Bytes + part * 16);
+                        ? (unsigned)(ks * p.Cout * K16B + (m0 * UPR + v) * 16) : kOOB;
+        lds_a[e] = (unsigned)(row * ROW + ks * K16B + part * 16);
     }
 
     f32x16 acc[MI][NI];
@@ -170,7 +271,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             set_tap(ld_vi);
         }
         const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
-        const unsigned soff_a = (unsigned)(c16 * p.Cout * kSplitK16Bytes);
+        const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
         const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
@@ -184,23 +285,28 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
         for (int e = 0; e < A_U; ++e)
             if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
-        unsigned hp[B_PER / 2], mp[B_PER / 2], lp[B_PER / 2];
+        unsigned pc[NP][B_PER / 2];
 #pragma unroll
-        for (int e = 0; e < B_PER / 2; ++e)
-            split3(__builtin_bit_cast(float, rb[2 * e]), __builtin_bit_cast(float, rb[2 * e + 1]), hp[e], mp[e], lp[e]);
+        for (int e = 0; e < B_PER / 2; ++e) {
+            const float x0 = __builtin_bit_cast(float, rb[2 * e]), x1 = __builtin_bit_cast(float, rb[2 * e + 1]);
+            if constexpr (AR == 0)
+                split3(x0, x1, pc[0][e], pc[1][e], pc[2][e]);
+            else
+                split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
+        }
         unsigned char* rowp = &Bs[buf][pl * ROW];
         if constexpr (B_PER == 4) {
-            const int k = kr * 4, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
-            *reinterpret_cast<u32x2*>(rowp + off) = u32x2{hp[0], hp[1]};
-            *reinterpret_cast<u32x2*>(rowp + off + 32) = u32x2{mp[0], mp[1]};
-            *reinterpret_cast<u32x2*>(rowp + off + 64) = u32x2{lp[0], lp[1]};
+            const int k = kr * 4, off = (k / 16) * K16B + (k % 16) * 2;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x2*>(rowp + off + c * 32) = u32x2{pc[c][0], pc[c][1]};
         } else {
 #pragma unroll
             for (int g = 0; g < B_PER / 8; ++g) {
-                const int k = kr * B_PER + g * 8, off = (k / 16) * kSplitK16Bytes + (k % 16) * 2;
-                *reinterpret_cast<u32x4*>(rowp + off) = u32x4{hp[4 * g], hp[4 * g + 1], hp[4 * g + 2], hp[4 * g + 3]};
-                *reinterpret_cast<u32x4*>(rowp + off + 32) = u32x4{mp[4 * g], mp[4 * g + 1], mp[4 * g + 2], mp[4 * g + 3]};
-                *reinterpret_cast<u32x4*>(rowp + off + 64) = u32x4{lp[4 * g], lp[4 * g + 1], lp[4 * g + 2], lp[4 * g + 3]};
+                const int k = kr * B_PER + g * 8, off = (k / 16) * K16B + (k % 16) * 2;
+#pragma unroll
+                for (int c = 0; c < NP; ++c)
+                    *reinterpret_cast<u32x4*>(rowp + off + c * 32) =
+                        u32x4{pc[c][4 * g], pc[c][4 * g + 1], pc[c][4 * g + 2], pc[c][4 * g + 3]};
             }
         }
     };
@@ -217,29 +323,21 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
         const unsigned char* Bb = Bs[cur] + (wn * (NI * 32) + l31) * ROW + lh * 16;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 a[MI][3], b[NI][3];
+            frag a[MI][NP], b[NI][NP];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    a[i][c] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+                for (int c = 0; c < NP; ++c)
+                    a[i][c] = *reinterpret_cast<const frag*>(Ab + i * 32 * ROW + ks * K16B + c * 32);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    b[j][c] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+                for (int c = 0; c < NP; ++c)
+                    b[j][c] = *reinterpret_cast<const frag*>(Bb + j * 32 * ROW + ks * K16B + c * 32);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NI; ++j) acc[i][j] = split_products<AR>(a[i], b[j], acc[i][j]);
         }
     };
     for (int q = 0; q < nq; ++q) {
@@ -265,11 +363,12 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = acc[i][j][r];
+                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = AR == 1 ? acc[i][j][r] * out_scale : acc[i][j][r];
                 }
         }
         return;
     }
+    float vmax = 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int opix = n0 + wn * (NI * 32) + j * 32 + l31;
@@ -286,6 +385,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 const int co = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (co >= p.Cout) continue;
                 float v = acc[i][j][r];
+                if constexpr (AR == 1) v *= out_scale;
                 if (p.scale) v *= p.scale[co];
                 if (p.shift) v += p.shift[co];
                 const long long off = (long long)co * OHOW;
@@ -293,18 +393,45 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 if (p.accumulate) v += yb[off];
                 if (p.relu) v = fmaxf(v, 0.f);
                 yb[off] = v;
+                vmax = fmaxf(vmax, fabsf(v));
             }
         }
     }
+    if (p.y_amax) publish_amax(vmax, p.y_amax);
+}
+
+// ---------------------------------------------------------------------------------------------
+// max|x| of a tensor of B images of `per` contiguous floats (batch stride x_bs), into a zero-initialised device scalar
+__global__ void amax_kernel(const float* __restrict__ x, long long per, long long x_bs, long long total,
+                            float* __restrict__ out) {
+    float m = 0.f;
+    if (x_bs == per && (per & 3) == 0 && (reinterpret_cast<unsigned long long>(x) & 15) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total / 4; i += (long long)gridDim.x * blockDim.x) {
+            const float4 v = x4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            const long long b = i / per;
+            m = fmaxf(m, fabsf(x[b * x_bs + (i - b * per)]));
+        }
+    }
+    publish_amax(m, out);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Weight layout for the split kernels: w[co][ci][tap] ->
 //   fwd  : [ (tap*Cin + ci) / 16 ][ co ][ piece ][ ci % 16 ]      (rows = co,  Cin  % 16 == 0)
 //   dgrad: [ (tap*Cout + co) / 16 ][ ci ][ piece ][ co % 16 ]     (rows = ci,  Cout % 16 == 0)
-// One thread converts 8 consecutive k of one row and writes three 16-byte runs.
+// One thread converts 8 consecutive k of one row and writes NP 16-byte runs.  AR = 1: `amax` (device scalar, the
+// tensor's max|w|, already reduced) gives the scale; it is also copied into both layouts' trailers.
+template <int AR>
 __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ fwd,
-                                          unsigned char* __restrict__ dg, int Cout, int Cin, int T) {
+                                          unsigned char* __restrict__ dg, int Cout, int Cin, int T,
+                                          const float* __restrict__ amax) {
+    constexpr int NP = SplitArith<AR>::NP;
+    constexpr int K16B = split_k16_bytes(AR);
     // a block stages w[co0..co0+31][ci0..ci0+31][all taps] like prep_weights_tiled_kernel (T <= 9)
     constexpr int LDT = 32 * 9 + 1;
     __shared__ float tile[32 * LDT];
@@ -312,48 +439,60 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
     const int tid = threadIdx.x;
     const int nci = min(32, Cin - ci0), nco = min(32, Cout - co0);
     const int run = nci * T;
+    float ws = 1.f;
+    if constexpr (AR == 1) {
+        int e;
+        ws = pow2_scale(*amax, e);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            const long long body = split_layout_bytes(AR, (long long)T * Cin, Cout) - 16;     // same for both layouts
+            if (fwd) *reinterpret_cast<float*>(fwd + body) = *amax;
+            if (dg) *reinterpret_cast<float*>(dg + body) = *amax;
+        }
+    }
     for (int r = tid >> 5; r < nco; r += 8) {
         const float* src = w + ((long long)(co0 + r) * Cin + ci0) * T;
-        for (int j = tid & 31; j < run; j += 32) tile[r * LDT + j] = src[j];
+        for (int j = tid & 31; j < run; j += 32) tile[r * LDT + j] = src[j] * ws;
     }
     __syncthreads();
+    auto emit = [&](unsigned char* dst, const float (&v)[8]) {
+        unsigned pc[NP][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (AR == 0)
+                split3(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e], pc[2][e]);
+            else
+                split2h(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e]);
+        }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(dst + c * 32) = u32x4{pc[c][0], pc[c][1], pc[c][2], pc[c][3]};
+    };
     if (fwd) {
         // items: (tap, g = 8-run of ci, co) with co fastest
         const int ng = nci / 8, items = T * ng * nco;
         for (int it = tid; it < items; it += blockDim.x) {
             const int col = it % nco, rest = it / nco, g = rest % ng, tap = rest / ng;
-            unsigned h[4], m[4], l[4];
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                split3(tile[col * LDT + (g * 8 + 2 * e) * T + tap], tile[col * LDT + (g * 8 + 2 * e + 1) * T + tap],
-                       h[e], m[e], l[e]);
+            for (int e = 0; e < 8; ++e) v[e] = tile[col * LDT + (g * 8 + e) * T + tap];
             const int k = tap * Cin + ci0 + g * 8;
-            unsigned char* dst = fwd + ((long long)(k / 16) * Cout + co0 + col) * kSplitK16Bytes + (k % 16) * 2;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4*>(dst + 32) = u32x4{m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+            emit(fwd + ((long long)(k / 16) * Cout + co0 + col) * K16B + (k % 16) * 2, v);
         }
     }
     if (dg) {
         const int ng = nco / 8, items = T * ng * nci;
         for (int it = tid; it < items; it += blockDim.x) {
             const int cil = it % nci, rest = it / nci, g = rest % ng, tap = rest / ng;
-            unsigned h[4], m[4], l[4];
+            float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                split3(tile[(g * 8 + 2 * e) * LDT + cil * T + tap], tile[(g * 8 + 2 * e + 1) * LDT + cil * T + tap],
-                       h[e], m[e], l[e]);
+            for (int e = 0; e < 8; ++e) v[e] = tile[(g * 8 + e) * LDT + cil * T + tap];
             const int k = tap * Cout + co0 + g * 8;
-            unsigned char* dst = dg + ((long long)(k / 16) * Cin + ci0 + cil) * kSplitK16Bytes + (k % 16) * 2;
-            *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
-            *reinterpret_cast<u32x4*>(dst + 32) = u32x4{m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<u32x4*>(dst + 64) = u32x4{l[0], l[1], l[2], l[3]};
+            emit(dg + ((long long)(k / 16) * Cin + ci0 + cil) * K16B + (k % 16) * 2, v);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Weight gradient on the bf16 matrix core: D[cout][n] = sum_pixel dY[cout][pixel] * Xg[n][pixel], 32-pixel chunks
+// Weight gradient on the 16-bit matrix core: D[cout][n] = sum_pixel dY[cout][pixel] * Xg[n][pixel], 32-pixel chunks
 // (Cout % 128 == 0, Cin % 128 == 0, at least 6 N tiles; everything else stays on the fp32 kernels of conv_igemm.hip).
 //
 // A first version kept conv_wgrad_fast_kernel's 16-pixel chunks and split both operands in the kernel: no faster than
@@ -362,18 +501,25 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
 // VALU split.  Here
 //   * a chunk is 32 consecutive pixels = one full 128-byte line per row, read by 32 adjacent lanes;
 //   * dY is split ONCE per launch by dy_split_kernel into the kernel's own LDS row format
-//     ([pixel/32][cout][2 x [h|m|l] x 16 bf16 + 16 B pad] = 208 B rows): a row tile of a chunk is one contiguous
-//     26 KB run that every N tile of the launch (36 for a 3x3 on 512 channels) copies with 16-byte units - no
-//     arithmetic, no bank conflicts (the unpadded form cost 33 % of the LDS cycles in conflicts);
+//     ([pixel/32][cout][2 x NP pieces x 16 + 16 B pad]): a row tile of a chunk is one contiguous run that every N tile
+//     of the launch (36 for a 3x3 on 512 channels) copies with 16-byte units - no arithmetic, no bank conflicts;
 //   * x is split in the kernel.  A lane holds ONE pixel of a row, the packed converts want a pixel PAIR per
 //     lane: lanes swap one value with their neighbour (DPP quad_perm) so that even lanes own the pair of one
 //     row and odd lanes the pair of the row below - 4 VALU ops per pair instead of a second, half-used load.
-constexpr int kW2Row = 2 * kSplitK16Bytes + 16;     // 208-byte LDS rows: 32 pixels x 3 pieces + padding
+constexpr int w2row_bytes(int AR) { return 2 * split_k16_bytes(AR) + 16; }     // 32 pixels x NP pieces + padding
 
+template <int AR>
 __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __restrict__ out, int B, int Cout,
-                                int OHOW, long long dy_bs, int P) {
+                                int OHOW, long long dy_bs, int P, const float* __restrict__ amax) {
+    constexpr int NP = SplitArith<AR>::NP;
+    constexpr int K16B = split_k16_bytes(AR), ROW = w2row_bytes(AR);
+    float sc = 1.f;
+    if constexpr (AR == 1) {
+        int e;
+        sc = pow2_scale(*amax, e);
+    }
     // one thread: 16 consecutive pixels (linear index over b, oh, ow) of one channel; an even number of groups so that
-    // every 208-byte row is written in full (zeros past the last pixel)
+    // every row is written in full (zeros past the last pixel)
     const int groups = 2 * ((P + 31) / 32);
     const long long total = (long long)groups * Cout;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
@@ -404,33 +550,42 @@ __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __r
                 v[e] = t;
             }
         }
-        unsigned h[8], m[8], l[8];
+        unsigned pc[NP][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split3(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
-        u32x4* dst = reinterpret_cast<u32x4*>(out + ((long long)(g >> 1) * Cout + c) * kW2Row + (g & 1) * kSplitK16Bytes);
-        dst[0] = u32x4{h[0], h[1], h[2], h[3]};
-        dst[1] = u32x4{h[4], h[5], h[6], h[7]};
-        dst[2] = u32x4{m[0], m[1], m[2], m[3]};
-        dst[3] = u32x4{m[4], m[5], m[6], m[7]};
-        dst[4] = u32x4{l[0], l[1], l[2], l[3]};
-        dst[5] = u32x4{l[4], l[5], l[6], l[7]};
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (AR == 0)
+                split3(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e], pc[2][e]);
+            else
+                split2h(v[2 * e] * sc, v[2 * e + 1] * sc, pc[0][e], pc[1][e]);
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(out + ((long long)(g >> 1) * Cout + c) * ROW + (g & 1) * K16B);
+#pragma unroll
+        for (int c2 = 0; c2 < NP; ++c2) {
+            dst[2 * c2] = u32x4{pc[c2][0], pc[c2][1], pc[c2][2], pc[c2][3]};
+            dst[2 * c2 + 1] = u32x4{pc[c2][4], pc[c2][5], pc[c2][6], pc[c2][7]};
+        }
     }
 }
 
-// 256 threads, 64x64 wave tiles (12 operand reads per 24 MFMAs), ONE LDS image per workgroup (53 KB) and two
-// barriers per chunk, so two workgroups share a CU: while one converts / stores its next chunk, the other one's MFMAs
-// use the matrix cores.  The two rows of a lane pair are neighbours (208-byte stride: disjoint banks).
+// 256 threads, 64x64 wave tiles, ONE LDS image per workgroup and two barriers per chunk, so two workgroups share a CU:
+// while one converts / stores its next chunk, the other one's MFMAs use the matrix cores.  The two rows of a lane pair
+// are neighbours (row stride an odd multiple of 16 bytes: disjoint banks).
 // Variants measured and dropped (profiles/r01_notes.md): 512 threads with a double-buffered image (both waves of a
 // SIMD sit in the same phase), producer / consumer waves with a 3-deep register ring (the pure consumer loop - one
 // wave per SIMD, operand reads exposed after every barrier - already runs at half the MFMA rate).
-template <int BM, int BN>
+// `dy_amax` / p.x_amax: the scales of the two operands (AR = 1); the slab receives acc / (s_dy * s_x).
+template <int BM, int BN, int AR>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP p, const unsigned char* __restrict__ dys,
-                                                                        unsigned dys_bytes) {
+                                                                        unsigned dys_bytes, const float* __restrict__ dy_amax) {
     static_assert(BM == 128 && BN == 128, "tile");
-    constexpr int BK = 32, ROW = kW2Row;
+    using Ar = SplitArith<AR>;
+    using frag = typename Ar::frag;
+    constexpr int NP = Ar::NP;
+    constexpr int K16B = split_k16_bytes(AR);
+    constexpr int BK = 32, ROW = w2row_bytes(AR);
     constexpr int WN = 2, MI = 2, NI = 2;
-    constexpr int A_UNITS = BM * ROW / 16;                 // the dY image of a chunk is one contiguous run: 1664 units
-    constexpr int A_U = (A_UNITS + kThreads - 1) / kThreads;   // 7 per thread, the last one partial (LDS padded)
+    constexpr int A_UNITS = BM * ROW / 16;                 // the dY image of a chunk is one contiguous run
+    constexpr int A_U = (A_UNITS + kThreads - 1) / kThreads;   // per thread, the last one partial (LDS padded)
     constexpr int B_PER = BN / 8;                          // 16 rows per thread: 8 half-waves x 32 pixels per pass
     constexpr unsigned kOOB = 0x80000000u;
 
@@ -450,14 +605,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(dys), 0, (int)dys_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    float xs = 1.f, out_scale = 1.f;
+    if constexpr (AR == 1) {
+        int ex, ed;
+        xs = pow2_scale(*p.x_amax, ex);
+        (void)pow2_scale(*dy_amax, ed);
+        out_scale = pow2(-(ex + ed));
+    }
 
     const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
     const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
     // this thread's x rows: 2*hw + (e & 1) + 16*(e >> 1): the two rows of a pair are neighbours
     const unsigned b_row = (unsigned)((ci0 + 2 * hw) * HW);
 
-    // dY arrives in the LDS row format itself ([pixel/32][cout][208 B]): unit u of the row tile goes to byte 16 u of
-    // the image - consecutive lanes, consecutive 16 bytes on both sides, no bank conflicts
+    // dY arrives in the LDS row format itself: unit u of the row tile goes to byte 16 u of the image - consecutive
+    // lanes, consecutive 16 bytes on both sides, no bank conflicts
     unsigned voff_a[A_U];
 #pragma unroll
     for (int e = 0; e < A_U; ++e) {
@@ -518,7 +680,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     };
     const bool even = (px & 1) == 0;
     const int pair = px >> 1;
-    const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * kSplitK16Bytes + (pair & 7) * 4);
+    const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * K16B + (pair & 7) * 4);
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
@@ -528,12 +690,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
             const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);
             const unsigned x0 = even ? rb[2 * i] : recv;
             const unsigned x1 = even ? recv : rb[2 * i + 1];
-            unsigned h, m, l;
-            split3(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), h, m, l);
+            unsigned pc[NP];
+            if constexpr (AR == 0)
+                split3(__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), pc[0], pc[1], pc[2]);
+            else
+                split2h(__builtin_bit_cast(float, x0) * xs, __builtin_bit_cast(float, x1) * xs, pc[0], pc[1]);
             unsigned char* d = Bs + st_b + i * 16 * ROW;
-            *reinterpret_cast<unsigned*>(d) = h;
-            *reinterpret_cast<unsigned*>(d + 32) = m;
-            *reinterpret_cast<unsigned*>(d + 64) = l;
+#pragma unroll
+            for (int c = 0; c < NP; ++c) *reinterpret_cast<unsigned*>(d + c * 32) = pc[c];
         }
     };
 
@@ -547,34 +711,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     int c0 = next_valid(chunk_begin);
     if (c0 < chunk_end) load_tiles(c0);
     while (c0 < chunk_end) {
-        store_tiles();                                   // chunk c0: registers -> bf16 pieces -> LDS
+        store_tiles();                                   // chunk c0: registers -> 16-bit pieces -> LDS
         const int c1 = next_valid(c0 + 1);
         if (c1 < chunk_end) load_tiles(c1);              // in flight during this chunk's MFMAs
         lds_barrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[MI][3], b[NI][3];
+            frag a[MI][NP], b[NI][NP];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    a[i][c] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+                for (int c = 0; c < NP; ++c)
+                    a[i][c] = *reinterpret_cast<const frag*>(Ab + i * 32 * ROW + ks * K16B + c * 32);
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    b[j][c] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * ROW + ks * kSplitK16Bytes + c * 32);
+                for (int c = 0; c < NP; ++c)
+                    b[j][c] = *reinterpret_cast<const frag*>(Bb + j * 32 * ROW + ks * K16B + c * 32);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NI; ++j) acc[i][j] = split_products<AR>(a[i], b[j], acc[i][j]);
         }
         lds_barrier();
         c0 = c1;
@@ -589,7 +746,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                slab[(long long)co * p.N + n] = acc[i][j][r];
+                slab[(long long)co * p.N + n] = AR == 1 ? acc[i][j][r] * out_scale : acc[i][j][r];
             }
     }
 }

@@ -94,7 +94,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                 long long n, int nsplit, const float* __restrict__ res,
-                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes) {
+                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes,
+                                float* __restrict__ amax) {
+  float vmax = 0.f;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
     const int b = plane / C, c = plane - b * C;
     double s0 = 0.0, s1 = 0.0;
@@ -130,6 +132,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(yp + i) = v;
+            vmax = amax4(vmax, v);
         }
     } else {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
@@ -137,9 +140,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             if (rp) v += rp[i];
             if (relu) v = fmaxf(v, 0.f);
             yp[i] = v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
     }
   }
+  if (amax) publish_amax(vmax, amax);
 }
 
 // dx = gamma*invstd*(dy' - k0 - xhat*k1) ; dres = dy'
@@ -150,7 +155,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ dbeta, int accumulate, long long n, int nsplit,
                                     float* __restrict__ dx,
                                     float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
-                                    int relu, int planes) {
+                                    int relu, int planes, float* __restrict__ amax) {
+  float vmax = 0.f;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
     const int b = plane / C, c = plane - b * C;
     // finish the channel's two sums (sum dy', sum dy'*xhat) from the partials; one block publishes the parameter
@@ -188,6 +194,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
             o.z = gi * (g.z - k0 - (xv.z - mu) * is * k1);
             o.w = gi * (g.w - k0 - (xv.w - mu) * is * k1);
             *reinterpret_cast<float4*>(dxp + i) = o;
+            vmax = amax4(vmax, o);
             if (drp) *reinterpret_cast<float4*>(drp + i) = g;
         }
     } else
@@ -195,10 +202,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
         float g = gp[i];
         if (yp && !(yp[i] > 0.f)) g = 0.f;
         const float xh = (xp[i] - mu) * is;
-        dxp[i] = gi * (g - k0 - xh * k1);
+        const float o = gi * (g - k0 - xh * k1);
+        dxp[i] = o;
+        vmax = fmaxf(vmax, fabsf(o));
         if (drp) drp[i] = g;
     }
   }
+  if (amax) publish_amax(vmax, amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
-    long long y_bs, int relu) {
+    long long y_bs, int relu, float* __restrict__ amax) {
     constexpr int V = 16;                         // float4 per thread
     __shared__ double sm[16];
     __shared__ float bc[2];
@@ -251,6 +261,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     }
     __syncthreads();
     const float mu = bc[0], g = bc[1] * gamma[c], be = beta[c];
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
@@ -265,8 +276,10 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = o;
+            vmax = amax4(vmax, o);
         }
     }
+    if (amax) publish_amax(vmax, amax);
 }
 
 template <int NT>
@@ -274,7 +287,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
-    float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu) {
+    float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
+    float* __restrict__ amax) {
     constexpr int V = 16;
     __shared__ double sm[16];
     __shared__ float bc[2];
@@ -316,6 +330,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     }
     __syncthreads();
     const float k0 = bc[0], k1 = bc[1], gi = gamma[c] * is;
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
@@ -328,9 +343,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             d.z = gi * (g[k].z - k0 - xh[k].z * k1);
             d.w = gi * (g[k].w - k0 - xh[k].w * k1);
             *reinterpret_cast<float4*>(dx + o) = d;
+            vmax = amax4(vmax, d);
             if (dres) *reinterpret_cast<float4*>(dres + o) = g[k];
         }
     }
+    if (amax) publish_amax(vmax, amax);
 }
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
@@ -533,7 +550,7 @@ size_t wsdl_bn_workspace(int C) {
 int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                       float* save_invstd, float* running_mean, float* running_var, float momentum,
                       float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
-                      void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                      float* y_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     WSDL_REQUIRE(B > 0 && C > 0 && HW > 0 , "bn_train_fwd: bad shape");
     WSDL_REQUIRE((long long)B * HW > 1, "bn_train_fwd: needs more than one value per channel (as torch)");
@@ -546,10 +563,12 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
         if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
-                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu);
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
+                               y_amax);
         else
             hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
-                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu);
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
+                               y_amax);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -559,7 +578,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                        nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns);
     hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, part, save_mean,
                        save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, ns, residual, y, C,
-                       HW, y_bs, relu, B * C);
+                       HW, y_bs, relu, B * C, y_amax);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -567,7 +586,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
 int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, float* dres, int B, int C, int HW, int relu,
-                      int accumulate_param_grads, long long dy_bs, long long y_bs, void* ws,
+                      int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax, void* ws,
                       size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
     WSDL_REQUIRE(!relu || y, "bn_train_bwd: relu mask needs the forward output y");
@@ -582,10 +601,12 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
         if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
-                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu);
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                               dx_amax);
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
-                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu);
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                               dx_amax);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -595,7 +616,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                        part, B, C, HW, dy_bs, y_bs, relu, 1, ns);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, part, dgamma, dbeta, accumulate_param_grads, (long long)B * HW, ns, dx, dres, C, HW,
-                       dy_bs, y_bs, relu, B * C);
+                       dy_bs, y_bs, relu, B * C, dx_amax);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

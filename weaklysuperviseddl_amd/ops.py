@@ -117,11 +117,62 @@ def conv_out_hw(H, W, k, stride, pad, dil):
 
 
 # ------------------------------------------------------------------------------------------ raw ops
+CONV_ARITH = [1]       # mirrors the library's "conv_arith": 1 = fp16x2 split kernels (need per-tensor amax scalars)
+
+
 def set_option(name, value):
     """wsdl_set_option + invalidation of every cached weight layout (options such as "conv_split" change what the
     layout buffers hold)."""
     check(lib().wsdl_set_option(name.encode(), int(value)))
+    if name == "conv_arith":
+        CONV_ARITH[0] = int(value != 0)
     bump_param_epoch()
+
+
+# ---- per-tensor amax scalars ------------------------------------------------------------------------------------
+# The fp16x2 convolution kernels scale each operand tensor by a power of two derived from a device scalar
+# amax >= max|tensor| (conv_split.h).  The kernel that WRITES a tensor publishes it for free (BatchNorm forward /
+# backward, the eval-mode conv epilogue: an atomicMax into a zeroed slot); the tensor carries it as ``_wsdl_amax``.
+# Tensors that arrive without one (the network input, concatenations, dropout outputs, views) get a read pass
+# (``wsdl_amax``) the first time a split convolution consumes them.
+_amax_pools = {}
+
+
+def amax_slot(device):
+    """A zero-initialised one-element fp32 view (slots are handed out once; a pool of 4096 is one memset)."""
+    pool = _amax_pools.get(device)
+    if pool is None or pool[1] >= pool[0].numel():
+        buf = torch.zeros(4096, device=device, dtype=torch.float32)
+        buf.record_stream(side_stream(device))        # read by weight-gradient kernels on the side stream
+        pool = [buf, 0]
+        _amax_pools[device] = pool
+    i = pool[1]
+    pool[1] += 1
+    return pool[0][i:i + 1]
+
+
+def _split_kc(kc, taps):
+    """Could a convolution contracting ``kc`` channels over ``taps`` taps run on the split kernels? (split_eligible in
+    conv_igemm.hip; an over-approximation only costs an unused amax)."""
+    return CONV_ARITH[0] == 1 and kc % 16 == 0 and taps <= 9
+
+
+def amax_of(t, needed=True):
+    """The tensor's amax scalar: the one its producer published, else one read pass (cached on the tensor)."""
+    if not needed:
+        return None
+    a = getattr(t, "_wsdl_amax", None)
+    if a is None:
+        tt, bs = _planes(t, "amax input") if t.dim() == 4 else (_dense(t, "amax input"), 0)
+        a = amax_slot(t.device)
+        B = tt.shape[0] if tt.dim() == 4 else 1
+        per = tt.numel() // B
+        check(lib().wsdl_amax(_p(tt), B, per, bs if tt.dim() == 4 else per, _p(a), _stream()))
+        try:
+            t._wsdl_amax = a
+        except AttributeError:
+            pass
+    return a
 
 
 def _layout_buffer(w, dgrad):
@@ -145,7 +196,12 @@ def prep_weights(w, want_fwd=True, want_dgrad=True):
     return wf, wd
 
 
-def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, residual=None, relu=False, out=None):
+def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, residual=None, relu=False, out=None,
+               x_amax=None, want_amax=False):
+    """``x_amax``: the input's amax scalar (looked up / computed when None and the split kernels may run);
+    ``want_amax``: publish max|out| as ``out._wsdl_amax`` (the output feeds another convolution directly)."""
+    if x_amax is None:
+        x_amax = amax_of(x, _split_kc(x.shape[1], wshape[2] * wshape[3]))
     x, x_bs = _planes(x, "x")
     B, Cin, H, W = x.shape
     Cout, Cin2, kh, kw = wshape
@@ -168,13 +224,18 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
             raise WsdlError("conv2d: residual shape mismatch")
     nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 0)
     ws = workspace(nws, x.device) if nws else None
+    y_amax = amax_slot(x.device) if (want_amax and CONV_ARITH[0] == 1) else None
     check(lib().wsdl_conv2d_fwd(_p(x), _p(wt_fwd), _p(out), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
-                                _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs,
+                                _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs, _p(x_amax), _p(y_amax),
                                 _p(ws), ws.numel() if ws is not None else 0, _stream()))
+    if y_amax is not None:
+        out._wsdl_amax = y_amax
     return out
 
 
-def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into=None):
+def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into=None, dy_amax=None):
+    if dy_amax is None:
+        dy_amax = amax_of(dy, _split_kc(wshape[0], wshape[2] * wshape[3]))
     dy, dy_bs = _planes(dy, "dy")
     B, Cin, H, W = xshape
     Cout, _, kh, kw = wshape
@@ -182,13 +243,21 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 1)
     ws = workspace(nws, dy.device) if nws else None
     check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
-                                  int(accumulate_into is not None), dy_bs, _p(ws), ws.numel() if ws is not None else 0,
-                                  _stream()))
+                                  int(accumulate_into is not None), dy_bs, _p(dy_amax), _p(ws),
+                                  ws.numel() if ws is not None else 0, _stream()))
     dx._wsdl_fresh = True        # a buffer this library has just produced and nobody else holds (see _owned)
     return dx
 
 
-def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False):
+def _wgrad_split(wshape):
+    return CONV_ARITH[0] == 1 and wshape[0] % 128 == 0 and wshape[1] % 128 == 0
+
+
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None):
+    if x_amax is None:
+        x_amax = amax_of(x, _wgrad_split(wshape))
+    if dy_amax is None:
+        dy_amax = amax_of(dy, _wgrad_split(wshape))
     x, x_bs = _planes(x, "x")
     dy, dy_bs = _planes(dy, "dy")
     B, Cin, H, W = x.shape
@@ -201,8 +270,8 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False):
     if out is None:
         out = torch.empty(wshape, device=x.device, dtype=torch.float32)
         accumulate = False
-    check(lib().wsdl_conv2d_wgrad(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(ws), ws.numel(),
-                                  _stream()))
+    check(lib().wsdl_conv2d_wgrad(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
+                                  _p(ws), ws.numel(), _stream()))
     return out
 
 
@@ -238,9 +307,12 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
     if residual is not None:
         residual = _dense(residual, "residual")
+    y_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
     check(lib().wsdl_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(invstd), _p(running_mean),
                                   _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
-                                  int(relu), y_bs, _p(ws), ws.numel(), _stream()))
+                                  int(relu), y_bs, _p(y_amax), _p(ws), ws.numel(), _stream()))
+    if y_amax is not None:
+        out._wsdl_amax = y_amax
     return out, mean, invstd
 
 
@@ -257,9 +329,12 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
+    dx_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if relu else None), _p(gamma), _p(mean), _p(invstd), _p(dx),
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, int(relu), int(acc), dy_bs, y_bs,
-                                  _p(ws), ws.numel(), _stream()))
+                                  _p(dx_amax), _p(ws), ws.numel(), _stream()))
+    if dx_amax is not None:
+        dx._wsdl_amax = dx_amax
     dx._wsdl_fresh = True
     if dres is not None:
         dres._wsdl_fresh = True
@@ -309,18 +384,23 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
-def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink):
+def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None):
     """d(param) = wgrad(x, dconv) written straight into param.grad (a slice of the flat gradient buffer)."""
     accumulate = not sink.take_fresh(param)
+    split = _wgrad_split(wshape)
+    x_amax = x_amax if x_amax is not None else amax_of(x, split)       # resolved on the MAIN stream (may launch a pass)
+    dy_amax = amax_of(dconv, split)
     if OVERLAP_WGRAD[0]:
         main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
         side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
         with torch.cuda.stream(side):
-            conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate)
+            conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
+                         dy_amax=dy_amax)
         x.record_stream(side)                       # keep the caching allocator from recycling them early
         dconv.record_stream(side)
     else:
-        conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate)
+        conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
+                     dy_amax=dy_amax)
     sink.grad_ready(param)
 
 
@@ -342,14 +422,19 @@ class _ConvBNAct(torch.autograd.Function):
         # passthrough: also hand x back as a second output (the identity branch of a bottleneck).  The gradient that
         # arrives for it is then added inside the dgrad kernel's epilogue instead of by a separate autograd add.
         wf, wd = _cached_prep(cache, weight, x.requires_grad)
-        conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil)
+        x_amax = amax_of(x, _split_kc(x.shape[1], weight.shape[2] * weight.shape[3]) or _wgrad_split(weight.shape))
+        conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, x_amax=x_amax)
         y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
                                        residual, relu)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
+        ctx.x_amax = x_amax              # saved tensors come back as new Python objects: keep the scalar explicitly
         ctx.save_for_backward(x, conv, y if relu else None, gamma, mean, invstd, wd)
         if passthrough:
-            return y, x.view_as(x)
+            xv = x.view_as(x)
+            if x_amax is not None:
+                xv._wsdl_amax = x_amax
+            return y, xv
         return y
 
     @staticmethod
@@ -372,9 +457,9 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
             if sw is not None:
-                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw)
+                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax)
             else:
-                dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil)
+                dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil, x_amax=ctx.x_amax)
         dx = None
         if ctx.needs_input_grad[0]:
             if wd is None:
@@ -398,7 +483,9 @@ class _ConvAffineAct(torch.autograd.Function):
     def forward(ctx, x, weight, scale, shift, residual, stride, pad, dil, relu, shift_is_param, cache=None):
         need_dx = x.requires_grad
         wf, wd = _cached_prep(cache, weight, need_dx)
-        y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu)
+        # a folded-BatchNorm convolution (eval mode) feeds the next convolution directly: its epilogue publishes the amax
+        y = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, scale, shift, residual, relu,
+                       want_amax=bool(relu) or scale is not None)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None, shift_is_param)
         ctx.params = (weight, shift if shift_is_param else None)
         need_w = weight.requires_grad
@@ -507,6 +594,8 @@ class _MaxPool3x3s2(torch.autograd.Function):
         check(lib().wsdl_maxpool3x3s2_fwd(_p(x), _p(y), _p(am), B * Cc, H, W, _stream()))
         ctx.save_for_backward(am)
         ctx.xshape = tuple(x.shape)
+        if getattr(x, "_wsdl_amax", None) is not None:
+            y._wsdl_amax = x._wsdl_amax          # max over windows of x: the input's bound holds (x >= 0 after ReLU or not)
         return y
 
     @staticmethod
