@@ -280,15 +280,17 @@ def cam_bench(device, iters=5, roofline=True):
         # whole-leg figure: needed-only FLOPs of the leg / its wall time; conv-kernel figure: executed FLOPs / event time
         leg_tf = CAM_GFLOP_PER_IMG * n_img / ms                        # GFLOP / ms = TFLOP/s (fp32-equivalent)
         conv_tf = exe / (kms * 1e-3) / 1e12 if kms else 0.0
+        nprod = 3.0 if ops.CONV_ARITH[0] == 1 else 6.0
         out["roofline"] = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "achieved": round(6.0 * leg_tf, 3), "frac": round(6.0 * leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "achieved": round(nprod * leg_tf, 3), "frac": round(nprod * leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
                            "achieved_fp32_equivalent": round(leg_tf, 3),
                            "conv_kernels_fp32_equivalent": round(conv_tf, 3),
-                           "conv_kernels_frac": round(6.0 * conv_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "conv_kernels_frac": round(nprod * conv_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "mfma_products_per_fp32_product": nprod,
                            "conv_kernel_ms_per_batch": round(kms / iters, 4),
                            "gflop_per_img": CAM_GFLOP_PER_IMG, "traffic": None,
-                           "note": "needed-only FLOPs (forward 12.4 + backward to layer3's output 5.9 GFLOP/img) x 6 bf16 MFMA "
-                                   "products per fp32 product / wall time of the whole leg, against the dense bf16 MFMA peak; "
+                           "note": "needed-only FLOPs (forward 12.4 + backward to layer3's output 5.9 GFLOP/img) x the 16-bit MFMA "
+                                   "products per fp32 product / wall time of the whole leg, against the dense 16-bit MFMA peak; "
                                    "conv_kernels_* = executed FLOPs of the instrumented conv launches / their HIP-event time"}
     return out
 
@@ -485,8 +487,12 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{cfg}: DeepLabV3-ResNet50 (SegmentationModel, aux head computed) {CONFIGS[cfg]['what']}, "
                                f"B={B}/GPU {S}x{S}x3, random-init weights, live dropout",
-                   "arithmetic": "fp32 tensors; conv products as 6 bf16 MFMAs on exact 3-way bf16 splits of both operands, "
-                                 "fp32 accumulate (fp32-level accuracy, tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
+                   "arithmetic": ("fp32 tensors; conv products as 3 fp16 MFMAs on exact 2-way fp16 splits of both operands (22 "
+                                  "significant bits, per-tensor power-of-two scales), fp32 accumulate"
+                                  if ops.CONV_ARITH[0] == 1 else
+                                  "fp32 tensors; conv products as 6 bf16 MFMAs on exact 3-way bf16 splits of both operands, "
+                                  "fp32 accumulate") + " - rms error vs fp64 at the level of the exact-fp32 MFMA chain "
+                                 "(tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
                    "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
                    "backend": (dist.get_backend() if world > 1 else None),
                    "final_loss": round(loss_val, 5)},
@@ -527,18 +533,22 @@ def main():
             nom = top["work"] / (top["total_ms"] * 1e-3) / 1e12
             split = "split" in top["kernel"]
             if split:
-                # bf16x3-split kernel: every fp32-equivalent FLOP is six bf16 MFMA FLOPs really issued; price those
-                # against the dense bf16 MFMA peak (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz)
-                mfma, peak = 6.0 * ach, BF16_MFMA_PEAK_TFLOPS
-                note = ("dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16); the kernel evaluates each fp32 product as six "
-                        "bf16 partial products (operands split exactly into three bf16 pieces, fp32 accumulate), so "
-                        "`achieved` = 6 x the fp32-equivalent rate `achieved_fp32_equivalent`")
+                # split kernel: every fp32-equivalent FLOP is NPROD 16-bit MFMA FLOPs really issued (3 for the default
+                # fp16x2 arithmetic, 6 for bf16x3); price those against the dense 16-bit MFMA peak
+                # (256 CUs x 4 SIMDs x 1024 FLOP/clk x 2.4 GHz; fp16 and bf16 MFMAs run at the same rate)
+                nprod = 3.0 if ops.CONV_ARITH[0] == 1 else 6.0
+                mfma, peak = nprod * ach, BF16_MFMA_PEAK_TFLOPS
+                note = ("dense 16-bit MFMA peak (v_mfma_f32_32x32x16_f16 / _bf16); the kernel evaluates each fp32 product as "
+                        f"{int(nprod)} 16-bit partial products (operands split exactly into 16-bit pieces, fp32 accumulate), so "
+                        f"`achieved` = {int(nprod)} x the fp32-equivalent rate `achieved_fp32_equivalent`; the fp32-equivalent "
+                        f"ceiling of the scheme is peak / {int(nprod)} = {BF16_MFMA_PEAK_TFLOPS / nprod:.0f} TFLOP/s")
             else:
                 mfma, peak = ach, FP32_MFMA_PEAK_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"
             result["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(mfma, 3),
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(mfma / peak, 4),
                                   "achieved_fp32_equivalent": round(ach, 3), "achieved_nominal": round(nom, 3),
+                                  "mfma_products_per_fp32_product": (nprod if split else 1),
                                   "traffic": pmc_traffic(top["kernel"]),
                                   "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
                                   "launches": top["launches"], "avg_launch_us": top["avg_us"],

@@ -115,7 +115,9 @@ int wsdl_prof_reset(void);
  * equals w itself.  Either destination of prep_weights may be NULL. */
 size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dgrad, int* is_plain);
 int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad,
-                             int Cout, int Cin, int kh, int kw, wsdl_stream_t stream);
+                             int Cout, int Cin, int kh, int kw,
+                             const float* w_amax /* optional device scalar max|w| (wsdl_multi_amax); NULL: reduced here */,
+                             wsdl_stream_t stream);
 
 /* y = act( scale[co]*conv(x) + shift[co] + residual ), any of scale/shift/residual may be NULL
  * (scale NULL = 1, shift NULL = 0).  relu != 0 applies max(.,0).  x_bs / y_bs / res_bs: batch strides
@@ -149,9 +151,13 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw,
                       int stride, int pad, int dil, int accumulate,
                       long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
-/* out = max|x| over B images of per_image contiguous floats (batch stride x_bs elements, 0 = dense); zeroes `out`
- * first.  For tensors whose producer did not publish an amax (network input, concatenations, dropout outputs). */
-int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, wsdl_stream_t stream);
+/* out = max|x| over B images of per_image contiguous floats (batch stride x_bs elements, 0 = dense); zero_first != 0
+ * zeroes `out` first (else the caller passes a zeroed scalar).  For tensors whose producer did not publish an amax
+ * (network input, concatenations, dropout outputs).  wsdl_multi_amax: n tensors in one launch - ptrs / counts are
+ * DEVICE arrays of n pointers / element counts, out[n] is zeroed first (every conv weight after the optimiser step). */
+int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, int zero_first,
+              wsdl_stream_t stream);
+int wsdl_multi_amax(const float* const* ptrs, const long long* counts, int n, float* out, wsdl_stream_t stream);
 
 /* dbias[co] = sum_{b,hw} dy  (classifier[4] / fc bias gradient). */
 int wsdl_bias_grad(const float* dy, float* dbias, int B, int C, int HW, long long dy_bs,
@@ -186,7 +192,9 @@ int wsdl_affine_act_fwd(const float* x, const float* scale, const float* shift, 
                         int relu, wsdl_stream_t stream);
 /* backward of y = act(scale*conv + shift + res) wrt conv: dconv = dy*[y>0]*scale ; dres = dy*[y>0] */
 int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, float* dconv, float* dres,
-                        int B, int C, int HW, int relu, wsdl_stream_t stream);
+                        int B, int C, int HW, int relu,
+                        float* dconv_amax /* optional: atomicMax of max|dconv| into a ZEROED device scalar */,
+                        wsdl_stream_t stream);
 
 /* ---- pooling / resampling / elementwise ----------------------------------------------------- */
 /* MaxPool2d(3, stride 2, pad 1) as in ResNet's stem; argmax (0..8, first max wins) kept as uint8 */

@@ -26,20 +26,21 @@ SIGNATURES = {
     "wsdl_prof_reset": (_i, []),
     "wsdl_prof_class_name": (C.c_char_p, [_i]),
     "wsdl_conv2d_weight_layout_bytes": (_sz, [_i, _i, _i, _i, _i, C.POINTER(_i)]),
-    "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
     "wsdl_conv2d_igemm_workspace": (_sz, [_i] * 11),
     "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _vp, _vp, _sz, _vp]),
     "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
-    "wsdl_amax": (_i, [_vp, _i, _ll, _ll, _vp, _vp]),
+    "wsdl_amax": (_i, [_vp, _i, _ll, _ll, _vp, _i, _vp]),
+    "wsdl_multi_amax": (_i, [_vp, _vp, _i, _vp, _vp]),
     "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),
     "wsdl_bn_workspace": (_sz, [_i]),
     "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _vp, _sz, _vp]),
     "wsdl_bn_train_bwd": (_i, [_vp] * 10 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _sz, _vp]),
     "wsdl_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wsdl_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp]),
+    "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp, _vp]),
     "wsdl_maxpool3x3s2_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsdl_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsdl_global_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _vp]),

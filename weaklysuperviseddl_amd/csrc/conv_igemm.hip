@@ -1576,7 +1576,7 @@ size_t wsdl_conv2d_weight_layout_bytes(int Cout, int Cin, int kh, int kw, int dg
 }
 
 int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int Cout, int Cin,
-                             int kh, int kw, wsdl_stream_t stream) {
+                             int kh, int kw, const float* w_amax, wsdl_stream_t stream) {
     WSDL_REQUIRE(w && (wt_fwd || wt_dgrad), "prep_weights: null pointer");
     WSDL_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0, "prep_weights: bad shape");
     const long long total = (long long)Cout * Cin * kh * kw;
@@ -1592,11 +1592,15 @@ int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int C
         if (g_conv_arith) {
             // the tensor's max|w| is reduced into the trailer of one layout; the layout kernel scales by it and copies it
             // into the other layout's trailer
-            const long long body = split_layout_bytes(1, (long long)T * Cin, Cout) - 16;
-            float* amax = reinterpret_cast<float*>((f8 ? f8 : d8) + body);
-            WSDL_HIP_CHECK(hipMemsetAsync(amax, 0, 16, wsdl::as_stream(stream)));
-            hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 1024)), dim3(256), 0,
-                               wsdl::as_stream(stream), w, total, total, total, amax);
+            const float* amax = w_amax;
+            if (!amax) {
+                const long long body = split_layout_bytes(1, (long long)T * Cin, Cout) - 16;
+                float* tr = reinterpret_cast<float*>((f8 ? f8 : d8) + body);
+                WSDL_HIP_CHECK(hipMemsetAsync(tr, 0, 16, wsdl::as_stream(stream)));
+                hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 1024)), dim3(256), 0,
+                                   wsdl::as_stream(stream), w, total, total, total, tr);
+                amax = tr;
+            }
             hipLaunchKernelGGL(prep_weights_split_kernel<1>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
                                T, amax);
         } else {
@@ -1875,11 +1879,20 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     return WSDL_OK;
 }
 
-int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, wsdl_stream_t stream) {
+int wsdl_multi_amax(const float* const* ptrs, const long long* counts, int n, float* out, wsdl_stream_t stream) {
+    WSDL_REQUIRE(ptrs && counts && out && n > 0 && n <= 65535, "multi_amax: bad arguments");
+    WSDL_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * (size_t)n, wsdl::as_stream(stream)));
+    hipLaunchKernelGGL(multi_amax_kernel, dim3(16, n), dim3(256), 0, wsdl::as_stream(stream), ptrs, counts, out);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_amax(const float* x, int B, long long per_image, long long x_bs, float* out, int zero_first,
+              wsdl_stream_t stream) {
     WSDL_REQUIRE(x && out && B > 0 && per_image > 0, "amax: bad arguments");
     if (!x_bs) x_bs = per_image;
     const long long total = (long long)B * per_image;
-    WSDL_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), wsdl::as_stream(stream)));
+    if (zero_first) WSDL_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float), wsdl::as_stream(stream)));
     hipLaunchKernelGGL(amax_kernel, dim3((int)std::min<long long>((total + 1023) / 1024, 2048)), dim3(256), 0,
                        wsdl::as_stream(stream), x, per_image, x_bs, total, out);
     WSDL_LAUNCH_CHECK();

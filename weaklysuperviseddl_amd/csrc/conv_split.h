@@ -420,6 +420,17 @@ __global__ void amax_kernel(const float* __restrict__ x, long long per, long lon
     publish_amax(m, out);
 }
 
+// max|.| of n tensors in one launch (every conv weight of the model after the optimiser step): blockIdx.y = tensor
+__global__ void multi_amax_kernel(const float* const* __restrict__ ptrs, const long long* __restrict__ counts,
+                                  float* __restrict__ out) {
+    const float* x = ptrs[blockIdx.y];
+    const long long n = counts[blockIdx.y];
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    publish_amax(m, out + blockIdx.y);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight layout for the split kernels: w[co][ci][tap] ->
 //   fwd  : [ (tap*Cin + ci) / 16 ][ co ][ piece ][ ci % 16 ]      (rows = co,  Cin  % 16 == 0)

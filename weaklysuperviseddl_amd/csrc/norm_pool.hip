@@ -370,7 +370,9 @@ __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __r
 
 __global__ void affine_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                       const float* __restrict__ scale, float* __restrict__ dconv,
-                                      float* __restrict__ dres, int C, int HW, int relu, int planes) {
+                                      float* __restrict__ dres, int C, int HW, int relu, int planes,
+                                      float* __restrict__ amax) {
+  float vmax = 0.f;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
     const int c = plane % C;
     const float sc = scale ? scale[c] : 1.f;
@@ -380,8 +382,10 @@ __global__ void affine_act_bwd_kernel(const float* __restrict__ dy, const float*
         if (relu && !(y[base + i] > 0.f)) g = 0.f;
         if (dconv) dconv[base + i] = g * sc;
         if (dres) dres[base + i] = g;
+        vmax = fmaxf(vmax, fabsf(g * sc));
     }
   }
+  if (amax) publish_amax(vmax, amax);
 }
 
 // y = act(scale[c]*x + shift[c]): a stand-alone eval-mode BatchNorm2d (folded running statistics) or a stand-alone ReLU
@@ -632,11 +636,11 @@ int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mea
 }
 
 int wsdl_affine_act_bwd(const float* dy, const float* y, const float* scale, float* dconv, float* dres,
-                        int B, int C, int HW, int relu, wsdl_stream_t stream) {
+                        int B, int C, int HW, int relu, float* dconv_amax, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && (dconv || dres) && B > 0 && C > 0 && HW > 0, "affine_act_bwd: bad arguments");
     WSDL_REQUIRE(!relu || y, "affine_act_bwd: relu mask needs y");
     hipLaunchKernelGGL(affine_act_bwd_kernel, plane_grid(B * C, HW), dim3(256), 0, wsdl::as_stream(stream), dy, y,
-                       scale, dconv, dres, C, HW, relu, B * C);
+                       scale, dconv, dres, C, HW, relu, B * C, dconv_amax);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -94,9 +94,10 @@ def prefetch_weight_layouts(convs):
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        for m in convs:
+        amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
+        for i, m in enumerate(convs):
             cache = m.__dict__.setdefault("_wsdl_cache", {})
-            wf, wd = prep_weights(m.weight, True, True)
+            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None)
             ev = torch.cuda.Event()
             ev.record(side)
             cache["prep_key"], cache["prep"], cache["prep_event"] = _weight_key(m.weight), (wf, wd), ev
@@ -167,7 +168,7 @@ def amax_of(t, needed=True):
         a = amax_slot(t.device)
         B = tt.shape[0] if tt.dim() == 4 else 1
         per = tt.numel() // B
-        check(lib().wsdl_amax(_p(tt), B, per, bs if tt.dim() == 4 else per, _p(a), _stream()))
+        check(lib().wsdl_amax(_p(tt), B, per, bs if tt.dim() == 4 else per, _p(a), 0, _stream()))    # the slot is zeroed
         try:
             t._wsdl_amax = a
         except AttributeError:
@@ -185,15 +186,37 @@ def _layout_buffer(w, dgrad):
     return torch.empty(nbytes // 4, device=w.device, dtype=torch.float32), True
 
 
-def prep_weights(w, want_fwd=True, want_dgrad=True):
-    """Opaque layout buffers (wt_fwd, wt_dgrad) for conv2d_fwd / conv2d_dgrad (include/wsdl_hip.h)."""
+def prep_weights(w, want_fwd=True, want_dgrad=True, w_amax=None):
+    """Opaque layout buffers (wt_fwd, wt_dgrad) for conv2d_fwd / conv2d_dgrad (include/wsdl_hip.h).  ``w_amax``: device
+    scalar max|w| if the caller already has it (``multi_amax``); otherwise the library reduces it."""
     w = _dense(w, "weight")
     Cout, Cin, kh, kw = w.shape
     wf = _layout_buffer(w, False)[0] if want_fwd else None
     wd, make_wd = _layout_buffer(w, True) if want_dgrad else (None, False)
     if want_fwd or make_wd:
-        check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd if make_wd else None), Cout, Cin, kh, kw, _stream()))
+        check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd if make_wd else None), Cout, Cin, kh, kw, _p(w_amax),
+                                             _stream()))
     return wf, wd
+
+
+_multi_amax_cache = {}
+
+
+def multi_amax(tensors):
+    """max|t| of every tensor of a FIXED list in one launch -> (n,) device tensor.  The pointer / count tables live on
+    the device and are built once per list (parameters keep their addresses inside the flat optimiser buffer)."""
+    key = tuple((t.data_ptr(), t.numel()) for t in tensors)
+    ent = _multi_amax_cache.get(key)
+    dev = tensors[0].device
+    if ent is None:
+        ptrs = torch.tensor([k[0] for k in key], dtype=torch.int64).to(dev)
+        counts = torch.tensor([k[1] for k in key], dtype=torch.int64).to(dev)
+        ent = _multi_amax_cache[key] = (ptrs, counts)
+        if len(_multi_amax_cache) > 64:
+            _multi_amax_cache.pop(next(iter(_multi_amax_cache)))
+    out = torch.empty(len(tensors), device=dev, dtype=torch.float32)
+    check(lib().wsdl_multi_amax(_p(ent[0]), _p(ent[1]), len(tensors), _p(out), _stream()))
+    return out
 
 
 def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, residual=None, relu=False, out=None,
@@ -357,8 +380,11 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
     B, Cc, H, W = dy.shape
     dconv = torch.empty_like(dy) if want_dconv else None
     dres = torch.empty_like(dy) if want_dres else None
+    amax = amax_slot(dy.device) if (want_dconv and CONV_ARITH[0] == 1) else None
     check(lib().wsdl_affine_act_bwd(_p(dy), _p(_dense(y) if relu else None), _p(scale), _p(dconv), _p(dres), B, Cc,
-                                    H * W, int(relu), _stream()))
+                                    H * W, int(relu), _p(amax), _stream()))
+    if amax is not None:
+        dconv._wsdl_amax = amax
     return dconv, dres
 
 
@@ -565,7 +591,7 @@ class _AffineAct(torch.autograd.Function):
         if not ctx.relu and scale is None:
             return dy, None, None, None
         dx = torch.empty_like(dy)
-        check(lib().wsdl_affine_act_bwd(_p(dy), _p(y), _p(scale), _p(dx), _vp(0), B, Cc, HW, int(ctx.relu), _stream()))
+        check(lib().wsdl_affine_act_bwd(_p(dy), _p(y), _p(scale), _p(dx), _vp(0), B, Cc, HW, int(ctx.relu), _vp(0), _stream()))
         return dx, None, None, None
 
 
