@@ -242,13 +242,21 @@ int wsdl_softmax_ce_fwd_bwd(const float* logits, const int64_t* labels, float* l
  *   apply_softmax=0, normalise=1                 : ConstrainToBoundaryLossSingle.forward
  *                                  (TraditionalModel/AlternatingDirectionBoundaryLoss.py:12-70)
  * loss: 1 float (normalise=0) or B floats (normalise=1).  dpreds (optional) = d loss / d preds for
- * an upstream gradient of 1 (per image for normalise=1). */
+ * an upstream gradient of 1 (per image for normalise=1).
+ * cache (optional): the image's colour affinities from wsdl_pairwise_cache (same B, H, W, window, sigma_color); the
+ * kernel then reads them instead of evaluating 24 exponentials per pixel - refine_pseudo_mask evaluates the loss 10 x 5
+ * times on one image (AlternatingDirectionCutLoss.py:736-757, :803-810).  Bit-identical results either way. */
 int wsdl_pairwise_affinity_loss_fwd_bwd(const float* preds, const float* image, float* loss,
                                         float* dpreds, int B, int C, int H, int W, int window,
                                         float sigma_color, float sigma_space, int apply_softmax,
-                                        int normalise, void* ws, size_t ws_bytes,
+                                        int normalise, const float* cache, void* ws, size_t ws_bytes,
                                         wsdl_stream_t stream);
 size_t wsdl_pairwise_workspace(int B, int H, int W);
+/* exp(-|I_q - I_p|^2 / (2 sigma_color^2)) for the (window^2 - 1) / 2 "forward" offsets of every pixel (the affinity
+ * is symmetric): cache[(window^2-1)/2][B][H][W] floats, wsdl_pairwise_cache_bytes of them. */
+size_t wsdl_pairwise_cache_bytes(int B, int H, int W, int window);
+int wsdl_pairwise_cache(const float* image, float* cache, int B, int H, int W, int window, float sigma_color,
+                        wsdl_stream_t stream);
 /* compute_affinities (TraditionalModel/AlternatingDirectionCutLoss.py:612-637): K=(w*w-1) maps,
  * out[(k*B + b)*H*W + p]. */
 int wsdl_compute_affinities(const float* image, float* out, int B, int H, int W, int window,

@@ -474,3 +474,21 @@ def test_standalone_batchnorm_and_relu_modules(dev):
     relu.register_forward_hook(lambda m, i, o: h.append(o))
     out = relu(torch.tensor([[-1.0, 2.0]], device=dev))
     assert out.tolist() == [[0.0, 2.0]] and len(h) == 1
+
+
+def test_aux_head_is_lazy_in_eval_mode_only(dev, seg_models):
+    """model(x)['out'] is all the reference ever reads; the aux head has no side effect in eval mode, so it is computed on
+    first access there - and eagerly in train mode, where its BatchNorm running statistics move as in torchvision."""
+    ref, mine = seg_models
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(21))
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        r, m = ref(x), mine(x.to(dev))
+    assert "aux" in m and len(m) == 2 and "aux" in m._lazy           # not computed yet
+    assert rel_err(m["out"], r["out"]) < 1e-3
+    assert rel_err(m["aux"], r["aux"]) < 1e-3 and not m._lazy and list(m.keys()) == ["out", "aux"]
+    mine.train()
+    rm0 = mine.aux_classifier[1].running_mean.clone()
+    out = mine(x.to(dev))
+    assert not out._lazy and not torch.equal(mine.aux_classifier[1].running_mean, rm0)
+    mine.load_state_dict({k: v for k, v in ref.state_dict().items()})

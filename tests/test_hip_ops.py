@@ -535,3 +535,22 @@ def test_softmax_kl(dev):
     assert_close(out, ref.detach(), rel=1e-4)
     out.backward()
     assert_close(xd.grad, xr.grad, rel=1e-4)
+
+
+@pytest.mark.parametrize("shape,window", [((2, 2, 40, 70), 5), ((1, 3, 9, 33), 3), ((3, 2, 17, 23), 7), ((2, 2, 64, 64), 5)])
+def test_pairwise_loss_with_cached_affinities_is_bit_identical(dev, shape, window):
+    """wsdl_pairwise_cache + the cached kernel variant (what refine_pseudo_mask uses: the image is fixed over its steps)
+    against the kernel that evaluates the affinities itself: same loss, same gradient, bit for bit, for both epilogues."""
+    from conftest import smooth_image
+    from weaklysuperviseddl_amd import ops
+    B, C, H, W = shape
+    img = smooth_image(B, H, W, 7).to(dev)
+    preds = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(8)).to(dev)
+    cache = ops.pairwise_cache(img, window, 0.1)
+    assert tuple(cache.shape) == ((window * window - 1) // 2, B, H, W)
+    for softmax, norm, space in ((True, 0, 0.0), (False, 1, 5.0), (True, 1, 0.0)):
+        p1, p2 = preds.clone().requires_grad_(), preds.clone().requires_grad_()
+        l1 = ops.pairwise_affinity_loss(p1, img, window, 0.1, space, softmax, norm)
+        l2 = ops.pairwise_affinity_loss(p2, img, window, 0.1, space, softmax, norm, cache=cache)
+        l1.sum().backward(), l2.sum().backward()
+        assert torch.equal(l1, l2) and torch.equal(p1.grad, p2.grad), (softmax, norm, space)

@@ -76,6 +76,53 @@ class _Backbone(nn.Module):
         return OrderedDict(out=self.layer4(f3), aux=f3)
 
 
+class _Outputs(OrderedDict):
+    """The result dict of ``forward``.  In eval mode the aux head - which no caller of the reference ever reads
+    ("computed every forward, unused by every loss") and which has no side effect there (eval-mode
+    BatchNorm, no dropout) - is computed when 'aux' is first looked at instead of on every forward: refine_pseudo_mask
+    and evaluate_model only take ['out'].  In train mode it is computed eagerly, as torchvision does (its BatchNorm
+    running statistics move)."""
+
+    def __init__(self):
+        super().__init__()
+        self._lazy = {}
+
+    def _resolve(self, key):
+        fn = self._lazy.pop(key, None)
+        if fn is not None:
+            super().__setitem__(key, fn())
+
+    def __getitem__(self, key):
+        self._resolve(key)
+        return super().__getitem__(key)
+
+    def __contains__(self, key):
+        return key in self._lazy or super().__contains__(key)
+
+    def _all(self):
+        for k in list(self._lazy):
+            self._resolve(k)
+
+    def keys(self):
+        self._all()
+        return super().keys()
+
+    def values(self):
+        self._all()
+        return super().values()
+
+    def items(self):
+        self._all()
+        return super().items()
+
+    def __iter__(self):
+        self._all()
+        return super().__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._lazy)
+
+
 class SegmentationModel(nn.Module):
     def __init__(self, num_classes=2, aux_loss=True, aux_classes=21):
         super().__init__()
@@ -92,10 +139,19 @@ class SegmentationModel(nn.Module):
     def forward(self, x):
         size = x.shape[-2:]
         feats = self.backbone(x)
-        res = OrderedDict()
+        res = _Outputs()
         res["out"] = ops.bilinear_resize(self.classifier(feats["out"]), size)
         if self.aux_classifier is not None:
-            res["aux"] = ops.bilinear_resize(self.aux_classifier(feats["aux"]), size)
+            f3 = feats["aux"]
+            if self.training:
+                res["aux"] = ops.bilinear_resize(self.aux_classifier(f3), size)
+            else:
+                grad = torch.is_grad_enabled()
+
+                def aux():
+                    with torch.set_grad_enabled(grad):
+                        return ops.bilinear_resize(self.aux_classifier(f3), size)
+                res._lazy["aux"] = aux
         return res
 
 

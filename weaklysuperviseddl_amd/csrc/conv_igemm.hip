@@ -1882,7 +1882,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
 int wsdl_multi_amax(const float* const* ptrs, const long long* counts, int n, float* out, wsdl_stream_t stream) {
     WSDL_REQUIRE(ptrs && counts && out && n > 0 && n <= 65535, "multi_amax: bad arguments");
     WSDL_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(float) * (size_t)n, wsdl::as_stream(stream)));
-    hipLaunchKernelGGL(multi_amax_kernel, dim3(16, n), dim3(256), 0, wsdl::as_stream(stream), ptrs, counts, out);
+    hipLaunchKernelGGL(multi_amax_kernel, dim3(64, n), dim3(256), 0, wsdl::as_stream(stream), ptrs, counts, out);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -420,14 +420,21 @@ __global__ void amax_kernel(const float* __restrict__ x, long long per, long lon
     publish_amax(m, out);
 }
 
-// max|.| of n tensors in one launch (every conv weight of the model after the optimiser step): blockIdx.y = tensor
+// max|.| of n tensors in one launch (every conv weight of the model after the optimiser step): blockIdx.y = tensor,
+// 16-byte loads where the tensor allows them
 __global__ void multi_amax_kernel(const float* const* __restrict__ ptrs, const long long* __restrict__ counts,
                                   float* __restrict__ out) {
     const float* x = ptrs[blockIdx.y];
     const long long n = counts[blockIdx.y];
     float m = 0.f;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(x[i]));
+    if ((n & 3) == 0 && (reinterpret_cast<unsigned long long>(x) & 15) == 0) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n / 4; i += (long long)gridDim.x * blockDim.x)
+            m = amax4(m, x4[i]);
+    } else {
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+            m = fmaxf(m, fabsf(x[i]));
+    }
     publish_amax(m, out + blockIdx.y);
 }
 

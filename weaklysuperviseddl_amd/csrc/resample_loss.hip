@@ -197,14 +197,61 @@ __global__ void ce_finalize_kernel(const float* __restrict__ part, int blocks, f
 // ------------------------------------------------------------------------------- pairwise loss
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
+// exp(-|dI|^2 / (2 sigma^2)) with the arithmetic pinned (explicit fma chain, symmetric in the sign of the differences):
+// the loss kernel and the affinity-cache kernel must produce the same bits for the same pixel pair.
+__device__ __forceinline__ float colour_affinity(float d0, float d1, float d2, float inv2sc) {
+    const float s = fmaf(d2, d2, fmaf(d1, d1, d0 * d0));
+    return __expf(-s * inv2sc);                            // v_exp_f32: 2 instructions, ~1 ulp
+}
+
 constexpr int kTileW = 32, kTileH = 8;
 
+// Colour affinities of the "forward" half of the window - offsets (dy > 0) or (dy == 0, dx > 0), K/2 maps - for every
+// pixel q whose partner p = q + offset is inside the image (0 otherwise; reflect padding is folded into the pair
+// weights by the loss kernel, so only in-image pairs exist).  The affinity is symmetric: the loss kernel reads the
+// backward half from the partner's forward entry.  cache[k][b][H][W].  Used when the image stays fixed over many loss
+// evaluations (refine_pseudo_mask: 10 Adam steps x 5 passes on one image): 24 exp + ~200 VALU ops per pixel and
+// evaluation become 24 loads.
 template <int R>
+__global__ void pairwise_cache_kernel(const float* __restrict__ image, float* __restrict__ cache, int B, int H, int W,
+                                      float inv2sc) {
+    constexpr int D = 2 * R + 1;
+    const int HW = H * W;
+    const long long total = (long long)B * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW), g = (int)(i - (long long)b * HW);
+        const int y = g / W, x = g - y * W;
+        const float* ib = image + (long long)b * 3 * HW;
+        const float i0 = ib[g], i1 = ib[HW + g], i2 = ib[2 * HW + g];
+        int k = 0;
+#pragma unroll
+        for (int jy = R; jy < D; ++jy)
+#pragma unroll
+            for (int jx = 0; jx < D; ++jx) {
+                if (jy == R && jx <= R) continue;
+                const int py = y + jy - R, px = x + jx - R;
+                float cc = 0.f;
+                if (py < H && px >= 0 && px < W) {
+                    const int n = py * W + px;
+                    const float d0 = i0 - ib[n], d1 = i1 - ib[HW + n], d2 = i2 - ib[2 * HW + n];
+                    cc = colour_affinity(d0, d1, d2, inv2sc);
+                }
+                cache[((long long)k * B + b) * HW + g] = cc;
+                ++k;
+            }
+    }
+}
+
+constexpr int kRegClasses = 8;     // classes whose gradients stay in registers until the single store
+
+template <int R, bool CACHED>
 __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__ preds,
                                                        const float* __restrict__ image,
                                                        float* __restrict__ part, float* __restrict__ dpreds,
                                                        int C, int H, int W, float inv2sc, float inv2ss,
-                                                       int use_space, int apply_softmax, float grad_norm) {
+                                                       int use_space, int apply_softmax, float grad_norm,
+                                                       const float* __restrict__ cache, int B) {
     constexpr int D = 2 * R + 1;
     constexpr int TW = kTileW + 2 * R, TH = kTileH + 2 * R, TS = TW * TH;
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [3 + C][TH][TW]
@@ -221,8 +268,10 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
         const int gy = y0 - R + ty, gx = x0 - R + tx;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int g = in ? gy * W + gx : 0;
+        if constexpr (!CACHED) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) lds[c * TS + t] = in ? ib[c * HW + g] : 0.f;
+            for (int c = 0; c < 3; ++c) lds[c * TS + t] = in ? ib[c * HW + g] : 0.f;
+        }
         if (!in) {
             for (int c = 0; c < C; ++c) lds[(3 + c) * TS + t] = 0.f;
         } else if (apply_softmax) {
@@ -291,7 +340,14 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
         }
         // ---- colour affinities for the whole window (registers), then one sweep per class
         const int tq = (ly + R) * TW + lx + R;
-        const float i0 = lds[tq], i1 = lds[TS + tq], i2 = lds[2 * TS + tq];
+        float i0 = 0.f, i1 = 0.f, i2 = 0.f;
+        if constexpr (!CACHED) {
+            i0 = lds[tq];
+            i1 = lds[TS + tq];
+            i2 = lds[2 * TS + tq];
+        }
+        const float* cq = CACHED ? cache + (long long)b * HW + qy * W + qx : nullptr;
+        const long long cstride = (long long)B * HW;       // between the cache's offset maps
         float af[D * D], ab[D * D];   // forward weight, forward+reverse weight
 #pragma unroll
         for (int jy = 0; jy < D; ++jy)
@@ -302,38 +358,64 @@ __global__ __launch_bounds__(256) void pairwise_kernel(const float* __restrict__
                     af[k] = ab[k] = 0.f;
                     continue;
                 }
-                const int tp = tq + (jy - R) * TW + (jx - R);
-                const float d0 = i0 - lds[tp], d1 = i1 - lds[TS + tp], d2 = i2 - lds[2 * TS + tp];
-                const float cc = __expf(-(d0 * d0 + d1 * d1 + d2 * d2) * inv2sc);   // v_exp_f32: 2 instructions, ~1 ulp
+                float cc;
+                if constexpr (CACHED) {
+                    // forward half: this pixel's own entry; backward half: the partner's entry for the mirrored offset
+                    const bool fwd = jy > R || (jy == R && jx > R);
+                    const int my = fwd ? jy : 2 * R - jy, mx = fwd ? jx : 2 * R - jx;        // mirrored -> forward offset
+                    const int kf = (my - R) * D + mx - (R + 1);                                   // index among the K/2 maps
+                    const int py = qy + jy - R, px = qx + jx - R;
+                    const bool inb = py >= 0 && py < H && px >= 0 && px < W;
+                    cc = inb ? cq[kf * cstride + (fwd ? 0 : (jy - R) * W + (jx - R))] : 0.f;
+                } else {
+                    const int tp = tq + (jy - R) * TW + (jx - R);
+                    const float d0 = i0 - lds[tp], d1 = i1 - lds[TS + tp], d2 = i2 - lds[2 * TS + tp];
+                    cc = colour_affinity(d0, d1, d2, inv2sc);
+                }
                 const float wf = wyF[jy] * wxF[jx], wr = wyR[jy] * wxR[jx];
                 af[k] = wf * cc;
                 ab[k] = (wf + wr) * cc;
             }
         float dot = 0.f;
         float* dq = dpreds ? dpreds + (long long)b * C * HW + qy * W + qx : nullptr;
-        for (int c = 0; c < C; ++c) {
-            const float* pl = lds + (3 + c) * TS;
-            const float pq = pl[tq];
-            float G = 0.f;
+        float Gr[kRegClasses];           // per-class gradients stay in registers until the single store (C <= 8)
+        for (int c0 = 0; c0 < C; c0 += kRegClasses) {
 #pragma unroll
-            for (int jy = 0; jy < D; ++jy)
+            for (int cc = 0; cc < kRegClasses; ++cc) {
+                const int c = c0 + cc;
+                Gr[cc] = 0.f;
+                if (c < C) {
+                    const float* pl = lds + (3 + c) * TS;
+                    const float pq = pl[tq];
+                    float G = 0.f;
 #pragma unroll
-                for (int jx = 0; jx < D; ++jx) {
-                    const int k = jy * D + jx;
-                    const float df = pq - pl[tq + (jy - R) * TW + (jx - R)];
-                    loss += af[k] * df * df;
-                    G += ab[k] * df;
+                    for (int jy = 0; jy < D; ++jy)
+#pragma unroll
+                        for (int jx = 0; jx < D; ++jx) {
+                            const int k = jy * D + jx;
+                            const float df = pq - pl[tq + (jy - R) * TW + (jx - R)];
+                            loss = fmaf(af[k] * df, df, loss);          // pinned: both kernel variants round alike
+                            G = fmaf(ab[k], df, G);
+                        }
+                    if (dq) {
+                        G *= grad_norm;
+                        dot += pq * G;
+                        Gr[cc] = G;
+                        if (!apply_softmax || C > kRegClasses) dq[(long long)c * HW] = G;
+                    }
                 }
-            if (dq) {
-                G *= grad_norm;
-                dot += pq * G;
-                dq[(long long)c * HW] = G;
             }
         }
         if (dq && apply_softmax) {
-            for (int c = 0; c < C; ++c) {
-                const float pq = lds[(3 + c) * TS + tq];
-                dq[(long long)c * HW] = pq * (dq[(long long)c * HW] - dot);
+            if (C <= kRegClasses) {
+#pragma unroll
+                for (int c = 0; c < kRegClasses; ++c)
+                    if (c < C) dq[(long long)c * HW] = lds[(3 + c) * TS + tq] * (Gr[c] - dot);
+            } else {
+                for (int c = 0; c < C; ++c) {
+                    const float pq = lds[(3 + c) * TS + tq];
+                    dq[(long long)c * HW] = pq * (dq[(long long)c * HW] - dot);
+                }
             }
         }
     }
@@ -506,9 +588,9 @@ size_t wsdl_pairwise_workspace(int B, int H, int W) {
 
 int wsdl_pairwise_affinity_loss_fwd_bwd(const float* preds, const float* image, float* loss, float* dpreds,
                                         int B, int C, int H, int W, int window, float sigma_color,
-                                        float sigma_space, int apply_softmax, int normalise, void* ws,
-                                        size_t ws_bytes, wsdl_stream_t stream) {
-    WSDL_REQUIRE(preds && image && loss && ws, "pairwise_loss: null pointer");
+                                        float sigma_space, int apply_softmax, int normalise,
+                                        const float* cache, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+    WSDL_REQUIRE(preds && (image || cache) && loss && ws, "pairwise_loss: null pointer");
     WSDL_REQUIRE(B > 0 && B <= 65535 && C > 0 && C <= 32 && H > 0 && W > 0, "pairwise_loss: bad shape (C <= 32)");
     WSDL_REQUIRE(window == 3 || window == 5 || window == 7, "pairwise_loss: window must be 3, 5 or 7");
     const int R = window / 2;
@@ -533,21 +615,46 @@ int wsdl_pairwise_affinity_loss_fwd_bwd(const float* preds, const float* image, 
     const double bytes = (double)B * H * W * 4.0 * ((C + 3) + (dpreds ? C : 0));
     {
         wsdl::ProfScope prof(WSDL_PROF_PAIRWISE, s, bytes);
-        if (R == 1)
-            hipLaunchKernelGGL((pairwise_kernel<1>), grid, dim3(256), lds, s, preds, image, part, dpreds, C, H, W,
-                               inv2sc, inv2ss, use_space, apply_softmax, gnorm);
-        else if (R == 2)
-            hipLaunchKernelGGL((pairwise_kernel<2>), grid, dim3(256), lds, s, preds, image, part, dpreds, C, H, W,
-                               inv2sc, inv2ss, use_space, apply_softmax, gnorm);
-        else
-            hipLaunchKernelGGL((pairwise_kernel<3>), grid, dim3(256), lds, s, preds, image, part, dpreds, C, H, W,
-                               inv2sc, inv2ss, use_space, apply_softmax, gnorm);
+#define WSDL_PAIRWISE(RR, CA)                                                                                     \
+    hipLaunchKernelGGL((pairwise_kernel<RR, CA>), grid, dim3(256), lds, s, preds, image, part, dpreds, C, H, W, inv2sc, \
+                       inv2ss, use_space, apply_softmax, gnorm, cache, B)
+        if (cache) {
+            if (R == 1) WSDL_PAIRWISE(1, true);
+            else if (R == 2) WSDL_PAIRWISE(2, true);
+            else WSDL_PAIRWISE(3, true);
+        } else {
+            if (R == 1) WSDL_PAIRWISE(1, false);
+            else if (R == 2) WSDL_PAIRWISE(2, false);
+            else WSDL_PAIRWISE(3, false);
+        }
+#undef WSDL_PAIRWISE
     }
     WSDL_LAUNCH_CHECK();
     if (normalise == 0)
         hipLaunchKernelGGL(finalize_sum_kernel, dim3(1), dim3(256), 0, s, part, B * tiles, 1, (float)(1.0 / N), loss);
     else
         hipLaunchKernelGGL(finalize_sum_kernel, dim3(B), dim3(256), 0, s, part, tiles, B, (float)(1.0 / N), loss);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+size_t wsdl_pairwise_cache_bytes(int B, int H, int W, int window) {
+    if (B <= 0 || H <= 0 || W <= 0 || (window != 3 && window != 5 && window != 7)) return 0;
+    return (size_t)((window * window - 1) / 2) * B * H * W * sizeof(float);
+}
+
+int wsdl_pairwise_cache(const float* image, float* cache, int B, int H, int W, int window, float sigma_color,
+                        wsdl_stream_t stream) {
+    WSDL_REQUIRE(image && cache && B > 0 && H > 0 && W > 0, "pairwise_cache: bad arguments");
+    WSDL_REQUIRE(window == 3 || window == 5 || window == 7, "pairwise_cache: window must be 3, 5 or 7");
+    WSDL_REQUIRE(sigma_color > 0.f, "pairwise_cache: sigma_color must be positive");
+    const int R = window / 2;
+    const float inv2sc = 1.f / (2.f * sigma_color * sigma_color);
+    const int blocks = flat_blocks((long long)B * H * W);
+    hipStream_t s = wsdl::as_stream(stream);
+    if (R == 1) hipLaunchKernelGGL((pairwise_cache_kernel<1>), dim3(blocks), dim3(256), 0, s, image, cache, B, H, W, inv2sc);
+    else if (R == 2) hipLaunchKernelGGL((pairwise_cache_kernel<2>), dim3(blocks), dim3(256), 0, s, image, cache, B, H, W, inv2sc);
+    else hipLaunchKernelGGL((pairwise_cache_kernel<3>), dim3(blocks), dim3(256), 0, s, image, cache, B, H, W, inv2sc);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

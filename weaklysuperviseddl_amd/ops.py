@@ -776,7 +776,7 @@ class _SoftmaxCE(torch.autograd.Function):
 
 class _PairwiseAffinityLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, preds, image, window, sigma_color, sigma_space, apply_softmax, normalise):
+    def forward(ctx, preds, image, window, sigma_color, sigma_space, apply_softmax, normalise, cache=None):
         preds, image = _dense(preds, "preds"), _dense(image, "image")
         B, Cc, H, W = preds.shape
         if tuple(image.shape) != (B, 3, H, W):
@@ -787,7 +787,7 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
         ws = workspace(lib().wsdl_pairwise_workspace(B, H, W), preds.device)
         check(lib().wsdl_pairwise_affinity_loss_fwd_bwd(_p(preds), _p(image), _p(loss), _p(dp), B, Cc, H, W,
                                                         int(window), float(sigma_color), float(sigma_space or 0.0),
-                                                        int(apply_softmax), int(normalise), _p(ws), ws.numel(),
+                                                        int(apply_softmax), int(normalise), _p(cache), _p(ws), ws.numel(),
                                                         _stream()))
         ctx.save_for_backward(dp)
         ctx.normalise = normalise
@@ -807,7 +807,7 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
         else:
             out = torch.empty_like(dp)
             check(lib().wsdl_scale_by_device_scalar(_p(dp), _p(_dense(g.reshape(1))), _p(out), dp.numel(), _stream()))
-        return out, None, None, None, None, None, None
+        return out, None, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------ functional API
@@ -877,9 +877,19 @@ def cross_entropy(logits, labels, ignore_index=-100):
 
 
 def pairwise_affinity_loss(preds, image, window=5, sigma_color=0.1, sigma_space=0.0, apply_softmax=True,
-                           normalise=0):
+                           normalise=0, cache=None):
+    """``cache``: ``pairwise_cache(image, window, sigma_color)`` when the image stays fixed over many evaluations."""
     return _PairwiseAffinityLoss.apply(preds, image, window, sigma_color, sigma_space, bool(apply_softmax),
-                                       int(normalise))
+                                       int(normalise), cache)
+
+
+def pairwise_cache(image, window=5, sigma_color=0.1):
+    """The image's colour affinities for the forward half of the window ((window^2-1)/2, B, H, W)."""
+    image = _dense(image, "image")
+    B, _, H, W = image.shape
+    out = torch.empty((window * window - 1) // 2, B, H, W, device=image.device, dtype=torch.float32)
+    check(lib().wsdl_pairwise_cache(_p(image), _p(out), B, H, W, int(window), float(sigma_color), _stream()))
+    return out
 
 
 def compute_affinities(image, sigma_color=0.1, sigma_space=5, window_size=5):
