@@ -173,9 +173,11 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       const float* residual, int relu, long long y_bs,
                       float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
-/* Backward of the above.  y (the forward output) is needed only when relu != 0 (mask = y > 0).
+/* Backward of the above.  relu = 1: the ReLU mask is read from the forward output y (needed when a residual was
+ * added); relu = 2: the mask is recomputed from x - y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
+ * expression - so y is neither read nor needs keeping (y may be NULL, beta is required); relu = 0: no activation.
  * dres (optional) receives the masked upstream gradient (the residual branch's gradient). */
-int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd,
                       float* dx, float* dgamma, float* dbeta, float* dres,
                       int B, int C, int HW, int relu, int accumulate_param_grads,

@@ -268,6 +268,12 @@ def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     assert_close(dbeta, br.grad, what="bn dbeta")
     if res:
         assert_close(dres, rr.grad, what="bn dres")
+    if relu and not res:
+        # the mask recomputed from x (what the fused conv -> BN node uses: y is neither kept nor read) is THE SAME mask
+        dx2, dg2, db2, _ = ops.bn_train_bwd(x.to(dev), dy.to(dev), None, gamma.to(dev), mean, invstd, True, False,
+                                            beta=beta.to(dev))
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+        assert torch.equal((y > 0), (torch.nn.functional.relu(y) > 0))
 
 
 def test_bn_fold_and_affine_bwd(dev):

@@ -26,8 +26,11 @@ static int stat_splits(int C, int HW) {
 __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                 const float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ part, int B, int C,
-                                int HW, long long dy_bs, long long y_bs, int relu, int backward, int nsplit) {
+                                int HW, long long dy_bs, long long y_bs, int relu, int backward, int nsplit,
+                                const float* __restrict__ gamma, const float* __restrict__ beta) {
     // forward : part = (sum x, sum x^2) ; backward: part = (sum dy', sum dy'*xhat), dy' = dy*[y>0]
+    // relu == 2: the mask [y > 0] is recomputed from x (y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
+    // expression - no residual was added): y is not read
     __shared__ double sm[16];
     const int c = blockIdx.x, s = blockIdx.y;
     const int slice = (HW + nsplit - 1) / nsplit;
@@ -35,9 +38,14 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
     const int len = min(slice, HW - r0);
     double a0 = 0.0, a1 = 0.0;
     float mu = 0.f, is = 0.f;
+    float mg = 0.f, mb = 0.f;
     if (backward) {
         mu = mean[c];
         is = invstd[c];
+        if (relu == 2) {
+            mg = is * gamma[c];
+            mb = beta[c];
+        }
     }
     const int total = len > 0 ? B * len : 0;
     const bool vec = ((len | r0 | HW) & 3) == 0 && ((dy_bs | y_bs) & 3) == 0;
@@ -51,7 +59,12 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
                 a1 += (double)xv.x * xv.x + (double)xv.y * xv.y + (double)xv.z * xv.z + (double)xv.w * xv.w;
             } else {
                 float4 g = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
-                if (relu) {
+                if (relu == 2) {
+                    if (!(fmaf(xv.x - mu, mg, mb) > 0.f)) g.x = 0.f;
+                    if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) g.y = 0.f;
+                    if (!(fmaf(xv.z - mu, mg, mb) > 0.f)) g.z = 0.f;
+                    if (!(fmaf(xv.w - mu, mg, mb) > 0.f)) g.w = 0.f;
+                } else if (relu) {
                     const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
                     if (!(yv.x > 0.f)) g.x = 0.f;
                     if (!(yv.y > 0.f)) g.y = 0.f;
@@ -72,7 +85,9 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
             a1 += (double)xv * xv;
         } else {
             float g = dy[(long long)b * dy_bs + (long long)c * HW + r];
-            if (relu && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
+            if (relu == 2) {
+                if (!(fmaf(xv - mu, mg, mb) > 0.f)) g = 0.f;
+            } else if (relu && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
             a0 += g;
             a1 += (double)g * ((xv - mu) * is);
         }
@@ -124,8 +139,8 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     if ((HW & 3) == 0 && (y_bs & 3) == 0) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
             float4 v = *reinterpret_cast<const float4*>(xp + i);
-            v.x = (v.x - mu) * g + be; v.y = (v.y - mu) * g + be;
-            v.z = (v.z - mu) * g + be; v.w = (v.w - mu) * g + be;
+            v.x = fmaf(v.x - mu, g, be); v.y = fmaf(v.y - mu, g, be);      // pinned: the backward recomputes the ReLU mask
+            v.z = fmaf(v.z - mu, g, be); v.w = fmaf(v.w - mu, g, be);
             if (rp) {
                 const float4 r = *reinterpret_cast<const float4*>(rp + i);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -136,7 +151,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
         }
     } else {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-            float v = (xp[i] - mu) * g + be;
+            float v = fmaf(xp[i] - mu, g, be);
             if (rp) v += rp[i];
             if (relu) v = fmaxf(v, 0.f);
             yp[i] = v;
@@ -155,7 +170,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ dbeta, int accumulate, long long n, int nsplit,
                                     float* __restrict__ dx,
                                     float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
-                                    int relu, int planes, float* __restrict__ amax) {
+                                    int relu, int planes, float* __restrict__ amax, const float* __restrict__ beta) {
   float vmax = 0.f;
   for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
     const int b = plane / C, c = plane - b * C;
@@ -172,22 +187,28 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     }
     const float k0 = (float)(s0 / (double)n), k1 = (float)(s1 / (double)n);
     const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
+    const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
     const float* xp = x + (long long)plane * HW;
     const float* gp = dy + (long long)b * dy_bs + (long long)c * HW;
-    const float* yp = relu ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
+    const float* yp = relu == 1 ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
     float* dxp = dx + (long long)plane * HW;
     float* drp = dres ? dres + (long long)plane * HW : nullptr;
     if ((HW & 3) == 0 && ((dy_bs | y_bs) & 3) == 0) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
             float4 g = *reinterpret_cast<const float4*>(gp + i);
+            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
             if (yp) {
                 const float4 yv = *reinterpret_cast<const float4*>(yp + i);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
                 if (!(yv.w > 0.f)) g.w = 0.f;
+            } else if (relu == 2) {
+                if (!(fmaf(xv.x - mu, mg, mb) > 0.f)) g.x = 0.f;
+                if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) g.y = 0.f;
+                if (!(fmaf(xv.z - mu, mg, mb) > 0.f)) g.z = 0.f;
+                if (!(fmaf(xv.w - mu, mg, mb) > 0.f)) g.w = 0.f;
             }
-            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
             float4 o;
             o.x = gi * (g.x - k0 - (xv.x - mu) * is * k1);
             o.y = gi * (g.y - k0 - (xv.y - mu) * is * k1);
@@ -201,6 +222,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
         float g = gp[i];
         if (yp && !(yp[i] > 0.f)) g = 0.f;
+        if (relu == 2 && !(fmaf(xp[i] - mu, mg, mb) > 0.f)) g = 0.f;
         const float xh = (xp[i] - mu) * is;
         const float o = gi * (g - k0 - xh * k1);
         dxp[i] = o;
@@ -268,8 +290,8 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
         if (i4 < n4) {
             const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
             float4 o = v[k];
-            o.x = (o.x - mu) * g + be; o.y = (o.y - mu) * g + be;
-            o.z = (o.z - mu) * g + be; o.w = (o.w - mu) * g + be;
+            o.x = fmaf(o.x - mu, g, be); o.y = fmaf(o.y - mu, g, be);
+            o.z = fmaf(o.z - mu, g, be); o.w = fmaf(o.w - mu, g, be);
             if (res) {
                 const float4 q = *reinterpret_cast<const float4*>(res + ((long long)b * C + c) * HW + r);
                 o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
@@ -288,13 +310,14 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
-    float* __restrict__ amax) {
+    float* __restrict__ amax, const float* __restrict__ beta) {
     constexpr int V = 16;
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int HW4 = HW >> 2, n4 = B * HW4;
     const float mu = mean[c], is = invstd[c];
+    const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
     float4 g[V], xh[V];                            // dy' = dy*[y>0] and xhat, kept for the second phase
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -306,7 +329,12 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
             const float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
             float4 gv = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
-            if (relu) {
+            if (relu == 2) {
+                if (!(fmaf(xv.x - mu, mg, mb) > 0.f)) gv.x = 0.f;
+                if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) gv.y = 0.f;
+                if (!(fmaf(xv.z - mu, mg, mb) > 0.f)) gv.z = 0.f;
+                if (!(fmaf(xv.w - mu, mg, mb) > 0.f)) gv.w = 0.f;
+            } else if (relu) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
                 if (!(yv.x > 0.f)) gv.x = 0.f;
                 if (!(yv.y > 0.f)) gv.y = 0.f;
@@ -579,7 +607,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
-                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns);
+                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns, nullptr, nullptr);
     hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, part, save_mean,
                        save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, ns, residual, y, C,
                        HW, y_bs, relu, B * C, y_amax);
@@ -587,13 +615,15 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     return WSDL_OK;
 }
 
-int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma,
+int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, float* dres, int B, int C, int HW, int relu,
                       int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax, void* ws,
                       size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
-    WSDL_REQUIRE(!relu || y, "bn_train_bwd: relu mask needs the forward output y");
+    WSDL_REQUIRE(relu != 1 || y, "bn_train_bwd: relu = 1 takes the mask from the forward output y");
+    WSDL_REQUIRE(relu != 2 || beta, "bn_train_bwd: relu = 2 recomputes the mask from x and needs beta");
+    WSDL_REQUIRE(relu >= 0 && relu <= 2, "bn_train_bwd: relu must be 0, 1 or 2");
     WSDL_REQUIRE(B > 0 && C > 0 && HW > 0, "bn_train_bwd: bad shape");
     if (ws_bytes < wsdl_bn_workspace(C)) {
         wsdl::set_error("bn_train_bwd: workspace too small");
@@ -606,21 +636,21 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
         if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax);
+                               dx_amax, beta);
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax);
+                               dx_amax, beta);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
-                       part, B, C, HW, dy_bs, y_bs, relu, 1, ns);
+                       part, B, C, HW, dy_bs, y_bs, relu, 1, ns, gamma, beta);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, part, dgamma, dbeta, accumulate_param_grads, (long long)B * HW, ns, dx, dres, C, HW,
-                       dy_bs, y_bs, relu, B * C, dx_amax);
+                       dy_bs, y_bs, relu, B * C, dx_amax, beta);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

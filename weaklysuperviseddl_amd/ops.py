@@ -339,13 +339,23 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     return out, mean, invstd
 
 
-def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None, accumulate=False):
+def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None, accumulate=False,
+                 beta=None):
+    """``relu``: True with ``y`` = the forward output (mask read from it), or True with ``y=None`` and ``beta`` given:
+    the mask is recomputed from x (no residual was added in the forward) and y is never touched."""
     x = _dense(x, "x")
     dy, dy_bs = _planes(dy, "dy")
     B, Cc, H, W = x.shape
     y_bs = 0
+    mode = 0
     if relu:
-        y, y_bs = _planes(y, "y")
+        if y is None:
+            if beta is None:
+                raise WsdlError("bn_train_bwd: relu needs the forward output or beta")
+            mode = 2
+        else:
+            mode = 1
+            y, y_bs = _planes(y, "y")
     dx = torch.empty_like(x)
     acc = bool(accumulate) and dgamma_out is not None and dbeta_out is not None
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
@@ -353,8 +363,9 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
     dx_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
-    check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if relu else None), _p(gamma), _p(mean), _p(invstd), _p(dx),
-                                  _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, int(relu), int(acc), dy_bs, y_bs,
+    check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if mode == 1 else None), _p(gamma),
+                                  _p(_dense(beta) if mode == 2 else None), _p(mean), _p(invstd), _p(dx),
+                                  _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, mode, int(acc), dy_bs, y_bs,
                                   _p(dx_amax), _p(ws), ws.numel(), _stream()))
     if dx_amax is not None:
         dx._wsdl_amax = dx_amax
@@ -455,7 +466,9 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
         ctx.x_amax = x_amax              # saved tensors come back as new Python objects: keep the scalar explicitly
-        ctx.save_for_backward(x, conv, y if relu else None, gamma, mean, invstd, wd)
+        # the ReLU mask is recomputed from the conv output in the backward unless a residual was added (then y is kept)
+        ctx.save_for_backward(x, conv, y if (relu and residual is not None) else None, gamma, mean, invstd, wd,
+                              beta if relu else None)
         if passthrough:
             xv = x.view_as(x)
             if x_amax is not None:
@@ -465,7 +478,7 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dxres=None):
-        x, conv, y, gamma, mean, invstd, wd = ctx.saved_tensors
+        x, conv, y, gamma, mean, invstd, wd, beta_s = ctx.saved_tensors
         stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
         pw, pg, pb = ctx.params
         need_res = has_res and ctx.needs_input_grad[4]
@@ -473,12 +486,12 @@ class _ConvBNAct(torch.autograd.Function):
         if sg is not None:
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
             dconv, _, _, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res,
-                                             pg.grad, pb.grad, accumulate=not fresh)
+                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_s)
             dgamma = dbeta = None
             sg.grad_ready(pg)
             sg.grad_ready(pb)
         else:
-            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res)
+            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s)
         dw = None
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
