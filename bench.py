@@ -357,7 +357,7 @@ def spawn_ranks(args, argv):
         raise SystemExit(f"bench ranks exited with {rcs}")
 
 
-def build_workload(cfg, B, S, device, rank):
+def build_workload(cfg, B, S, device, rank, graph=False):
     """-> (step callable returning the loss tensor, description)."""
     from weaklysuperviseddl_amd import ops
     from weaklysuperviseddl_amd.TraditionalModel import (build_segmentation_model, train_step, LocalNormalizedCutLoss,
@@ -397,9 +397,17 @@ def build_workload(cfg, B, S, device, rank):
             std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
             img = ((smooth_images(B, S, S, 11 + rank) - mean) / std).to(device)
 
-        def step():
+        def eager_step():
             return train_step(model, opt, img, masks, extra)
-    return model, opt, step, extra
+        step = eager_step
+        if graph:
+            from weaklysuperviseddl_amd.graph import GraphedTrainStep
+            gstep = GraphedTrainStep(model, opt, extra, warmup=2)
+
+            def step():
+                return gstep(img, masks)
+        return model, opt, step, eager_step
+    return model, opt, step, step
 
 
 def main():
@@ -447,7 +455,10 @@ def main():
     cfg = args.config
     B = args.batch or CONFIGS[cfg]["batch"]
     S = args.size or CONFIGS[cfg]["size"]
-    model, opt, step, extra = build_workload(cfg, B, S, device, rank)
+    use_graph = bool(args.graph) if args.graph is not None else False
+    if use_graph and (world > 1 or cfg == "cfg4"):
+        raise SystemExit("--graph 1: hipGraph replay covers the single-process training step (cfg2 / cfg3 / cfg5)")
+    model, opt, step, eager_step = build_workload(cfg, B, S, device, rank, graph=use_graph)
     reducer = GradBucketReducer(opt, modules=[model]) if world > 1 else None   # noqa: F841  (hooks live on the optimizer)
 
     if rank == 0:
@@ -495,6 +506,7 @@ def main():
                                  "(tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
                    "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
                    "backend": (dist.get_backend() if world > 1 else None),
+                   "launch": "hipGraph replay (one host call per step)" if use_graph else "eager (one host call per kernel)",
                    "final_loss": round(loss_val, 5)},
         "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5), "issue_ms_per_step": round(host_issue_s / args.steps * 1e3, 3),
                  "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
@@ -512,7 +524,7 @@ def main():
             ops.prof_reset()
             ops.prof_enable(True)
         for _ in range(args.steps):
-            step()
+            eager_step()                  # HIP events around the launches: eager, never the graph replay
         torch.cuda.synchronize()
         ops.prof_enable(False)
         ops.OVERLAP_WGRAD[0] = not args.serial

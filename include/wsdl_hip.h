@@ -215,9 +215,12 @@ int wsdl_bilinear_fwd(const float* x, float* y, int B, int C, int h, int w, int 
 int wsdl_bilinear_bwd(const float* dy, float* dx, int B, int C, int h, int w, int H, int W,
                       long long dy_bs, wsdl_stream_t stream);
 /* Dropout: mask is uint8 0/1.  If gen_mask != 0 the mask is drawn (counter hash of seed, element
- * index) and written; else it is read (injected mask, parity tests).  y = x*mask/(1-p). */
+ * index) and written; else it is read (injected mask, parity tests).  y = x*mask/(1-p).
+ * seed_dev (optional): a device-resident call counter mixed into the seed - a captured (hipGraph) launch replays with a
+ * frozen host `seed`, the counter (bumped on the stream by the caller) keeps the masks changing. */
 int wsdl_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p,
-                     unsigned long long seed, int gen_mask, wsdl_stream_t stream);
+                     unsigned long long seed, int gen_mask, const unsigned long long* seed_dev,
+                     wsdl_stream_t stream);
 int wsdl_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, size_t n, float p,
                      wsdl_stream_t stream);
 /* y = a + b (optionally relu), y = alpha*x, strided channel-slice copy */
@@ -280,9 +283,11 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
 int wsdl_plane_relu_minmax(const float* x, float* y, int planes, int hw, wsdl_stream_t stream);
 
 /* ---- optimiser: torch.optim.Adam defaults (TraditionalModel/SegmentationModel.py:91,109-111) -
- * one launch over a flat parameter / gradient buffer; grad_scale folds the 1/world_size of DP. */
+ * one launch over a flat parameter / gradient buffer; grad_scale folds the 1/world_size of DP.
+ * step_dev (optional): the step number as a device int (bias corrections computed in the kernel) - for captured
+ * (hipGraph) launches, where a host `step` would be frozen at capture time. */
 int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                   float beta2, float eps, int step, float grad_scale, wsdl_stream_t stream);
+                   float beta2, float eps, int step, const int* step_dev, float grad_scale, wsdl_stream_t stream);
 
 /* ---- refine_pseudo_mask inner step (TraditionalModel/AlternatingDirectionCutLoss.py:736-757) -
  * KL(softmax(X) || S) with log(X+1e-8), reduction 'batchmean', and its gradient wrt softmax(X). */

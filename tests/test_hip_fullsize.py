@@ -254,3 +254,34 @@ def test_keep_largest_idempotent_full_size():
     m = (rng.rand(224, 224) < 0.5).astype(np.uint8)
     a = keep_largest(m)
     assert np.array_equal(keep_largest(a), a) and a.sum() <= m.sum() and ((a == 1) <= (m == 1)).all()
+
+
+def test_hipgraph_replay_equals_eager_steps(dev):
+    """weaklysuperviseddl_amd.graph.GraphedTrainStep: forward + CE + backward + Adam + weight re-layout captured once
+    and replayed.  Same kernels, same order, device-resident step / dropout counters: after 6 steps (2 eager warm-up +
+    capture + 4 replays) the parameters, Adam moments, BatchNorm statistics and losses are BIT-identical to six eager
+    steps - with live dropout (the masks come from per-module device counters in both modes)."""
+    import bench
+    from weaklysuperviseddl_amd.graph import GraphedTrainStep
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+
+    def run(graphed):
+        torch.manual_seed(0)
+        model = build_segmentation_model().to(dev).train()
+        opt = make_optimizer(model, lr=1e-4)
+        img, masks = bench.synthetic_batch(4, 128, 128, dev, 1)
+        step = GraphedTrainStep(model, opt, warmup=2) if graphed else (lambda i, m: train_step(model, opt, i, m))
+        losses = [step(img, masks).item() for _ in range(6)]
+        torch.cuda.synchronize()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        return losses, opt.flat_param.clone(), opt.exp_avg_sq.clone(), sd, opt.step_count, (step if graphed else None)
+
+    le, pe, ve, sde, ne, _ = run(False)
+    lg, pg, vg, sdg, ng, gs = run(True)
+    assert gs.graph is not None and gs.calls == 6
+    assert le == lg, (le, lg)
+    assert torch.equal(pe, pg) and torch.equal(ve, vg) and ne == ng == 6
+    for k in sde:
+        assert torch.equal(sde[k], sdg[k]), k                     # running statistics and num_batches_tracked too
+    assert len(set(le)) == 6 and all(np.isfinite(le))

@@ -47,7 +47,7 @@ SIGNATURES = {
     "wsdl_global_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "wsdl_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
     "wsdl_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
-    "wsdl_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _i, _vp]),
+    "wsdl_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _i, _vp, _vp]),
     "wsdl_dropout_bwd": (_i, [_vp, _vp, _vp, _sz, _f, _vp]),
     "wsdl_add": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "wsdl_scale_by_device_scalar": (_i, [_vp, _vp, _vp, _sz, _vp]),
@@ -63,7 +63,7 @@ SIGNATURES = {
     "wsdl_layercam_epilogue": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                                     _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
     "wsdl_plane_relu_minmax": (_i, [_vp, _vp, _i, _i, _vp]),
-    "wsdl_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _f, _vp]),
+    "wsdl_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "wsdl_kl_div_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
     "wsdl_kl_div_per_image_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _vp, _sz, _vp]),
     "wsdl_refine_combine": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _sz, _vp]),

@@ -151,7 +151,15 @@ __global__ void layercam_upsample_kernel(CamLayers L, const float* __restrict__ 
 // torch.optim.Adam (no amsgrad, no weight decay): exp_avg, exp_avg_sq, bias corrections as torch
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float b1, float b2, float eps, float step_size,
-                            float sqrt_bc2, float gscale) {
+                            float sqrt_bc2, float gscale, const int* __restrict__ step_dev, float lr) {
+    if (step_dev) {
+        // the step number lives on the device (hipGraph replay: the host value is frozen at capture time); same
+        // double-precision bias corrections as the host path
+        const int st = *step_dev;
+        const double bc1 = 1.0 - pow((double)b1, (double)st), bc2 = 1.0 - pow((double)b2, (double)st);
+        step_size = (float)((double)lr / bc1);
+        sqrt_bc2 = (float)sqrt(bc2);
+    }
     const size_t n4 = n / 4;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -250,8 +258,9 @@ int wsdl_plane_relu_minmax(const float* x, float* y, int planes, int hw, wsdl_st
 }
 
 int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                   float beta2, float eps, int step, float grad_scale, wsdl_stream_t stream) {
-    WSDL_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+                   float beta2, float eps, int step, const int* step_dev, float grad_scale, wsdl_stream_t stream) {
+    WSDL_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || step_dev), "adam_step: bad arguments");
+    if (step < 1) step = 1;
     WSDL_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                   reinterpret_cast<uintptr_t>(v)) % 16 == 0, "adam_step: buffers must be 16-byte aligned");
     const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
@@ -259,7 +268,7 @@ int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
     const float sqrt_bc2 = (float)std::sqrt(bc2);
     const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 8192);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), p, g, m, v, n, beta1,
-                       beta2, eps, step_size, sqrt_bc2, grad_scale);
+                       beta2, eps, step_size, sqrt_bc2, grad_scale, step_dev, lr);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -519,7 +519,8 @@ __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned 
 
 __global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                    uint8_t* __restrict__ mask, size_t n, float p, float inv_keep,
-                                   unsigned long long seed, int gen) {
+                                   unsigned long long seed, int gen, const unsigned long long* __restrict__ seed_dev) {
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;      // per-call counter kept on the device (hipGraph replay)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint8_t m;
         if (gen) {
@@ -721,10 +722,10 @@ int wsdl_global_avgpool_bwd(const float* dy, float* dx, int BC, int HW, int accu
 }
 
 int wsdl_dropout_fwd(const float* x, float* y, uint8_t* mask, size_t n, float p, unsigned long long seed,
-                     int gen_mask, wsdl_stream_t stream) {
+                     int gen_mask, const unsigned long long* seed_dev, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && y && mask && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad arguments");
     hipLaunchKernelGGL(dropout_fwd_kernel, dim3(flat_blocks(n)), dim3(256), 0, wsdl::as_stream(stream), x, y,
-                       mask, n, p, 1.f / (1.f - p), seed, gen_mask);
+                       mask, n, p, 1.f / (1.f - p), seed, gen_mask, seed_dev);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -79,6 +79,8 @@ def sync_initial_state(optimizer, modules=(), group=None, src=0):
     step = torch.tensor([optimizer.step_count], dtype=torch.int64)
     dist.broadcast(step, src=src, group=control_group(group))
     optimizer.step_count = int(step.item())
+    if getattr(optimizer, "step_dev", None) is not None:
+        optimizer.step_dev.fill_(optimizer.step_count)
     for m in modules:
         for b in m.buffers():
             dist.broadcast(b, src=src, group=group)

@@ -91,9 +91,18 @@ class Dropout(nn.Module):
         super().__init__()
         self.p = p
         self.injected_mask = None   # parity tests: uint8 mask used instead of the device RNG
+        self._seed = None           # host seed, drawn once; the per-call variation is a device counter (graph-safe)
+        self._counter = None
 
     def forward(self, x):
-        return ops.dropout(x, self.p, self.training, mask=self.injected_mask)
+        if not self.training or self.p == 0.0:
+            return x
+        if self.injected_mask is not None:
+            return ops.dropout(x, self.p, True, mask=self.injected_mask)
+        if self._seed is None or self._counter is None or self._counter.device != x.device:
+            self._seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) + ops.DROPOUT_SEED_OFFSET[0]) % (1 << 62)
+            self._counter = torch.zeros(1, dtype=torch.int64, device=x.device)
+        return ops.dropout(x, self.p, True, seed=self._seed, counter=self._counter)
 
 
 class Linear(nn.Module):

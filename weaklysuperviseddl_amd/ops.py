@@ -85,9 +85,13 @@ def _cached_prep(cache, weight, need_dx):
     return wf, wd
 
 
-def prefetch_weight_layouts(convs):
+LAYOUT_EPOCH = [0]     # bumped by options that change what a layout buffer holds / how large it is
+
+
+def prefetch_weight_layouts(convs, use_events=True):
     """Lay out next step's weights on the side stream (called right after the optimiser step): the ~0.6 ms of
-    re-layout kernels leave the forward chain; each conv waits on its own event."""
+    re-layout kernels leave the forward chain; each conv waits on its own event (``use_events=False``: the main stream
+    joins the side stream instead - inside a captured graph)."""
     if not convs:
         return
     dev = convs[0].weight.device
@@ -97,10 +101,16 @@ def prefetch_weight_layouts(convs):
         amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
         for i, m in enumerate(convs):
             cache = m.__dict__.setdefault("_wsdl_cache", {})
-            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None)
-            ev = torch.cuda.Event()
-            ev.record(side)
+            old = cache.get("prep") if cache.get("prep_layout") == LAYOUT_EPOCH[0] else None
+            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=old)
+            ev = None
+            if use_events:
+                ev = torch.cuda.Event()
+                ev.record(side)
             cache["prep_key"], cache["prep"], cache["prep_event"] = _weight_key(m.weight), (wf, wd), ev
+            cache["prep_layout"] = LAYOUT_EPOCH[0]
+    if not use_events:
+        main.wait_stream(side)          # graph capture: no cross-replay events - the step ends with the layouts complete
 
 
 def workspace(nbytes, device):
@@ -127,6 +137,7 @@ def set_option(name, value):
     check(lib().wsdl_set_option(name.encode(), int(value)))
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
+    LAYOUT_EPOCH[0] += 1
     bump_param_epoch()
 
 
@@ -144,12 +155,19 @@ def amax_slot(device):
     pool = _amax_pools.get(device)
     if pool is None or pool[1] >= pool[0].numel():
         buf = torch.zeros(4096, device=device, dtype=torch.float32)
-        buf.record_stream(side_stream(device))        # read by weight-gradient kernels on the side stream
+        if not torch.cuda.is_current_stream_capturing():
+            buf.record_stream(side_stream(device))    # read by weight-gradient kernels on the side stream
         pool = [buf, 0]
         _amax_pools[device] = pool
     i = pool[1]
     pool[1] += 1
     return pool[0][i:i + 1]
+
+
+def reset_amax_pool(device):
+    """Forget the current slot pool: the next request allocates (and zeroes) a new one - graph.py brackets a capture
+    with it so that the captured step's slots are re-zeroed by every replay."""
+    _amax_pools.pop(device if isinstance(device, torch.device) else torch.device(device), None)
 
 
 def _split_kc(kc, taps):
@@ -186,11 +204,19 @@ def _layout_buffer(w, dgrad):
     return torch.empty(nbytes // 4, device=w.device, dtype=torch.float32), True
 
 
-def prep_weights(w, want_fwd=True, want_dgrad=True, w_amax=None):
+def prep_weights(w, want_fwd=True, want_dgrad=True, w_amax=None, reuse=None):
     """Opaque layout buffers (wt_fwd, wt_dgrad) for conv2d_fwd / conv2d_dgrad (include/wsdl_hip.h).  ``w_amax``: device
-    scalar max|w| if the caller already has it (``multi_amax``); otherwise the library reduces it."""
+    scalar max|w| if the caller already has it (``multi_amax``); otherwise the library reduces it.  ``reuse``: a
+    previous (wt_fwd, wt_dgrad) pair of this weight to overwrite in place (the per-step re-layout keeps its buffers:
+    no allocator churn, and a captured graph keeps reading the addresses it was captured with)."""
     w = _dense(w, "weight")
     Cout, Cin, kh, kw = w.shape
+    if reuse is not None and reuse[0] is not None and (reuse[1] is not None or not want_dgrad):
+        wf, wd = reuse
+        make_wd = wd is not None and wd.data_ptr() != w.data_ptr()
+        check(lib().wsdl_conv2d_prep_weights(_p(w), _p(wf), _p(wd if make_wd else None), Cout, Cin, kh, kw, _p(w_amax),
+                                             _stream()))
+        return wf, wd
     wf = _layout_buffer(w, False)[0] if want_fwd else None
     wd, make_wd = _layout_buffer(w, True) if want_dgrad else (None, False)
     if want_fwd or make_wd:
@@ -686,7 +712,7 @@ class _Bilinear(torch.autograd.Function):
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, p, seed, mask):
+    def forward(ctx, x, p, seed, mask, counter=None):
         x = _dense(x, "x")
         y = torch.empty_like(x)
         gen = mask is None
@@ -694,7 +720,10 @@ class _Dropout(torch.autograd.Function):
             mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
         else:
             mask = _req(mask, "dropout mask", torch.uint8).contiguous()
-        check(lib().wsdl_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), int(gen), _stream()))
+        check(lib().wsdl_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), int(gen), _p(counter),
+                                     _stream()))
+        if counter is not None and gen:
+            counter.add_(1)             # on the stream, behind the kernel that read it (a node of a captured graph too)
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         return y
@@ -705,7 +734,7 @@ class _Dropout(torch.autograd.Function):
         dy = _dense(dy, "dy")
         dx = torch.empty_like(dy)
         check(lib().wsdl_dropout_bwd(_p(dy), _p(mask), _p(dx), dy.numel(), ctx.p, _stream()))
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 class _ConcatChannels(torch.autograd.Function):
@@ -869,12 +898,14 @@ def bilinear_resize(x, size):
 DROPOUT_SEED_OFFSET = [0]      # dp.init_distributed: a different offset on every rank, so replicas draw different masks
 
 
-def dropout(x, p, training=True, seed=None, mask=None):
+def dropout(x, p, training=True, seed=None, mask=None, counter=None):
+    """``counter``: a device int64 call counter (nn.Dropout keeps one): the mask then depends on (seed, counter) and the
+    module draws its host seed only once - required for hipGraph replay, where a per-call host seed would be frozen."""
     if not training or p == 0.0:
         return x
     if seed is None:
         seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) + DROPOUT_SEED_OFFSET[0]) % (1 << 62)
-    return _Dropout.apply(x, p, seed, mask)
+    return _Dropout.apply(x, p, seed, mask, counter)
 
 
 def concat_channels(xs):
@@ -951,11 +982,12 @@ def plane_relu_minmax(x):
     return y
 
 
-def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None):
+    """``step_dev``: device int32 step number (used instead of ``step`` - hipGraph replay)."""
     for t in (p, g, m, v):
         _req(t, "adam buffer")
     check(lib().wsdl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
-                               float(eps), int(step), float(grad_scale), _stream()))
+                               float(eps), int(step), _p(step_dev), float(grad_scale), _stream()))
 
 
 def softmax_channels(x):

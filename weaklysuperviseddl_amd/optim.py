@@ -20,6 +20,7 @@ class FlatAdam:
         dev = self.params[0].device
         self.lr, self.betas, self.eps, self.grad_scale = lr, betas, eps, grad_scale
         self.step_count = 0
+        self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32) if dev.type == "cuda" else None   # device twin
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
@@ -71,8 +72,11 @@ class FlatAdam:
         self.step_count += 1
         ops.bump_param_epoch()          # parameters change behind torch's version counters
         if self.flat_param.is_cuda:
+            # the kernel reads the step number from the device: a captured (hipGraph) step replays correctly
+            self.step_dev.add_(1)
             ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr,
-                               self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale)
+                               self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
+                               step_dev=self.step_dev)
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
         if self.post_step_hook is not None:
