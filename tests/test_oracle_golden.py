@@ -184,3 +184,92 @@ def test_model_shapes_small():
         logits, feats = cam(torch.randn(1, 3, 64, 64))
     assert logits.shape == (1, 37)
     assert [tuple(f.shape[1:]) for f in feats] == [(512, 8, 8), (1024, 4, 4), (2048, 4, 4)]
+
+
+def _run_trunk(t, x):
+    x = t.maxpool(t.relu(t.bn1(t.conv1(x))))
+    x = t.layer4(t.layer3(t.layer2(t.layer1(x))))
+    return t.fc(t.avgpool(x).flatten(1))
+
+
+def _conv_macs(model, size, run=None):
+    """(total MACs, {name: (Cin, Cout, k, stride, dilation, Hout)}) of every nn.Conv2d / nn.Linear, by shape inference on
+    the meta device (no arithmetic)."""
+    macs, table, hooks = [0], {}, []
+    names = {m: k for k, m in model.named_modules()}
+
+    def hook(m, inp, out):
+        if isinstance(m, nn.Conv2d):
+            macs[0] += out.numel() // out.shape[0] * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+            table[names[m]] = (m.in_channels, m.out_channels, m.kernel_size[0], m.stride[0], m.dilation[0], out.shape[-1])
+        else:
+            macs[0] += m.in_features * m.out_features
+    for m in model.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)):
+            hooks.append(m.register_forward_hook(hook))
+    model = model.to("meta").eval()
+    with torch.no_grad():
+        x = torch.empty(1, 3, size, size, device="meta")
+        run(model, x) if run is not None else model(x)
+    for h in hooks:
+        h.remove()
+    return macs[0], table
+
+
+def test_model_wiring_is_pinned_by_published_op_counts_and_the_shape_table():
+    """Parameter counts cannot see a misplaced stride or dilation; multiply-accumulate counts and per-layer output sizes
+    can.  torchvision's model cards: resnet50 4.09 GMACs @224, deeplabv3_resnet50 (21 classes, aux head) 178.72 GMACs
+    @520; the per-layer table is SURVEY.md 8a (256 x 256 input)."""
+    macs, _ = _conv_macs(oracle.ResNet50Trunk(), 224, _run_trunk)
+    assert abs(macs / 1e9 - 4.089) < 0.005, macs
+    macs, _ = _conv_macs(oracle.DeepLabV3ResNet50(21, True), 520)
+    assert abs(macs / 1e9 - 178.72) < 0.05, macs
+    macs, table = _conv_macs(oracle.build_segmentation_model(), 256)
+    assert abs(macs / 1e9 - 43.31) < 0.02, macs                       # BASELINE.md section 3: 43.31 GMACs with the aux head
+    want = {  # name: (Cin, Cout, k, stride, dilation, Hout)
+        "backbone.conv1": (3, 64, 7, 2, 1, 128),
+        "backbone.layer1.0.conv2": (64, 64, 3, 1, 1, 64),
+        "backbone.layer2.0.conv2": (128, 128, 3, 2, 1, 32),
+        "backbone.layer2.0.downsample.0": (256, 512, 1, 2, 1, 32),
+        "backbone.layer3.0.conv2": (256, 256, 3, 1, 1, 32),          # stride replaced by dilation: block 0 keeps d = 1
+        "backbone.layer3.1.conv2": (256, 256, 3, 1, 2, 32),
+        "backbone.layer3.5.conv2": (256, 256, 3, 1, 2, 32),
+        "backbone.layer3.0.downsample.0": (512, 1024, 1, 1, 1, 32),
+        "backbone.layer4.0.conv2": (512, 512, 3, 1, 2, 32),
+        "backbone.layer4.1.conv2": (512, 512, 3, 1, 4, 32),
+        "backbone.layer4.2.conv3": (512, 2048, 1, 1, 1, 32),
+        "classifier.0.convs.0.0": (2048, 256, 1, 1, 1, 32),
+        "classifier.0.convs.1.0": (2048, 256, 3, 1, 12, 32),
+        "classifier.0.convs.2.0": (2048, 256, 3, 1, 24, 32),
+        "classifier.0.convs.3.0": (2048, 256, 3, 1, 36, 32),
+        "classifier.0.convs.4.1": (2048, 256, 1, 1, 1, 1),
+        "classifier.0.project.0": (1280, 256, 1, 1, 1, 32),
+        "classifier.1": (256, 256, 3, 1, 1, 32),
+        "classifier.4": (256, 2, 1, 1, 1, 32),
+        "aux_classifier.0": (1024, 256, 3, 1, 1, 32),
+        "aux_classifier.4": (256, 21, 1, 1, 1, 32),
+    }
+    for k, v in want.items():
+        assert table[k] == v, (k, table[k], v)
+    assert len(table) == 63                                            # SURVEY.md 8a: 63 convolutions
+    # FrozenResNetCAM: layer4 dilated (stride-16 features), layer3 strided
+    _, t = _conv_macs(oracle.FrozenResNetCAM(37), 224)
+    assert t["layer3.0.conv2"] == (256, 256, 3, 2, 1, 14) and t["layer4.0.conv2"] == (512, 512, 3, 1, 1, 14)
+    assert t["layer4.1.conv2"] == (512, 512, 3, 1, 2, 14) and t["layer0.0"] == (3, 64, 7, 2, 1, 112)
+
+
+def test_product_models_are_wired_like_the_oracle():
+    """The HIP path's modules (weaklysuperviseddl_amd.nn) carry the same (in, out, kernel, stride, padding, dilation) per
+    state_dict name as the oracle's torch.nn modules - construction only, no kernel runs."""
+    from weaklysuperviseddl_amd import nn as wnn
+    from weaklysuperviseddl_amd.TraditionalModel import FrozenResNetCAM, build_segmentation_model
+
+    def geom_ref(m):
+        return {k: (c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], c.padding[0], c.dilation[0], c.bias is not None)
+                for k, c in m.named_modules() if isinstance(c, nn.Conv2d)}
+
+    def geom_mine(m):
+        return {k: (c.in_channels, c.out_channels, c.kernel_size, c.stride, c.padding, c.dilation, c.bias is not None)
+                for k, c in m.named_modules() if isinstance(c, wnn.Conv2d)}
+    assert geom_mine(build_segmentation_model()) == geom_ref(oracle.build_segmentation_model())
+    assert geom_mine(FrozenResNetCAM(37)) == geom_ref(oracle.FrozenResNetCAM(37))

@@ -1184,7 +1184,7 @@ int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 
 int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
 
 template <int BM, int BN, int WM, int BK>
-void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
+int launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     constexpr size_t static_lds = 2 * BK * (BM + BN) * sizeof(float) + 64 * sizeof(int);
     static std::once_flag once;
@@ -1195,6 +1195,8 @@ void launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
     size_t pad = occupancy_pad((long long)grid.x * grid.y, static_lds);
     if (pad > (size_t)kLdsPerCU - static_lds - 2048) pad = (size_t)kLdsPerCU - static_lds - 2048;
     hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), pad, s, p);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
 }
 
 // bf16x3-split kernels (conv_split.h): which (rows, K-channels, taps) shapes use them.  A function of the
@@ -1227,7 +1229,7 @@ int choose_xcd_py(const ConvP& p, int gx, int gy) {
 }
 
 template <int BM, int BN, int WM, int BK>
-void launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
+int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
@@ -1235,12 +1237,14 @@ void launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
     else
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 0>), grid, dim3(kThreads), 0, s, p);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
 }
 
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
 int g_t256_bk32 = 1;      // K chunks of 32 in the 256x128 form (half the barriers; +3.5 % measured on the bf16x3 kernel)
-void launch_split_256x128(const ConvP& p_in, hipStream_t s) {
+int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
@@ -1252,30 +1256,32 @@ void launch_split_256x128(const ConvP& p_in, hipStream_t s) {
         if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 0>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
     }
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
 }
 
 template <int BM, int BN, int WM>
-void launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
+int launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, BN), wsdl::cdiv(p.Cout, BM));
     constexpr bool kSmallTile = BM * BN <= 128 * 64;      // K chunks of 32 only where registers / LDS allow them
     if (split) {
         if constexpr (kSmallTile) {
             if (g_split_bk32 && p.Cin % 32 == 0) {
-                launch_split<BM, BN, WM, 32>(p, s, grid);
-                return;
+                return launch_split<BM, BN, WM, 32>(p, s, grid);
             }
         }
-        launch_split<BM, BN, WM, 16>(p, s, grid);
+        return launch_split<BM, BN, WM, 16>(p, s, grid);
     } else if (aligned) {
         if constexpr (kSmallTile) {
             if (g_bk32 && p.Cin % 32 == 0) {
-                launch_fast<BM, BN, WM, 32>(p, s, grid);
-                return;
+                return launch_fast<BM, BN, WM, 32>(p, s, grid);
             }
         }
-        launch_fast<BM, BN, WM, 16>(p, s, grid);
+        return launch_fast<BM, BN, WM, 16>(p, s, grid);
     } else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, false>), grid, dim3(kThreads), 0, s, p);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
 }
 
 // Tile choice: 128x128 (64x64 per wave) when that already gives every CU ~2 blocks; otherwise halve the
@@ -1377,15 +1383,17 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         }
         q.b_tile0[nb > 1 ? nb : 0] = tiles;
         q.grid_x = nb > 1 ? tiles : 0;
+        int rc;
         if (t256) {
-            launch_split_256x128(q, s);
+            rc = launch_split_256x128(q, s);
         } else
         switch (cfg) {
-            case 0: launch_cfg<128, 128, 2>(q, s, aligned, split); break;
-            case 1: launch_cfg<128, 64, 2>(q, s, aligned, split); break;
-            case 2: launch_cfg<64, 256, 1>(q, s, aligned, split); break;
-            default: launch_cfg<64, 128, 1>(q, s, aligned, split); break;
+            case 0: rc = launch_cfg<128, 128, 2>(q, s, aligned, split); break;
+            case 1: rc = launch_cfg<128, 64, 2>(q, s, aligned, split); break;
+            case 2: rc = launch_cfg<64, 256, 1>(q, s, aligned, split); break;
+            default: rc = launch_cfg<64, 128, 1>(q, s, aligned, split); break;
         }
+        if (rc) return rc;
     }
     if (p.ksplit > 1) {
         const long long total = (long long)p.Cout * p.P;
@@ -1536,9 +1544,11 @@ bool wgrad_role_swap(int Cin, int Cout, int kh, int kw, int stride, int pad) {
 }
 
 template <int BM, int BN, int WM>
-void launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
+int launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
     dim3 grid(p.N / BN, p.Cout / BM, S);
     hipLaunchKernelGGL((conv_wgrad_fast_kernel<BM, BN, WM, 16>), grid, dim3(kThreads), 2 * (BM + BN) * 17 * sizeof(float), s, p);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
 }
 
 }  // namespace
@@ -1827,11 +1837,13 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
                     hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                    WSDL_LAUNCH_CHECK();
                     hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
                                        (unsigned)dys_bytes, dy_amax);
                 } else {
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,
                                        static_cast<const float*>(nullptr));
+                    WSDL_LAUNCH_CHECK();
                     hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 0>), grid, dim3(kThreads), 0, s, p, dys,
                                        (unsigned)dys_bytes, static_cast<const float*>(nullptr));
                 }
@@ -1847,10 +1859,12 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     q.b_own[i] = bands[i].own;
                     q.b_cps[i] = wsdl::cdiv(wsdl::cdiv((long long)B * OH * bands[i].own, 32), S);
                 }
-                if (tBM == 128 && tBN == 128) launch_wgrad_fast<128, 128, 2>(q, s, S_total);
-                else if (tBM == 128) launch_wgrad_fast<128, 64, 2>(q, s, S_total);
-                else if (tBN == 128) launch_wgrad_fast<64, 128, 1>(q, s, S_total);
-                else launch_wgrad_fast<64, 64, 2>(q, s, S_total);
+                int rc;
+                if (tBM == 128 && tBN == 128) rc = launch_wgrad_fast<128, 128, 2>(q, s, S_total);
+                else if (tBM == 128) rc = launch_wgrad_fast<128, 64, 2>(q, s, S_total);
+                else if (tBN == 128) rc = launch_wgrad_fast<64, 128, 1>(q, s, S_total);
+                else rc = launch_wgrad_fast<64, 64, 2>(q, s, S_total);
+                if (rc) return rc;
             }
         } else if (Cout <= 64) {
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
