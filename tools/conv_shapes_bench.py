@@ -2,7 +2,10 @@
 """Per-shape timing of the conv kernels on the unique DeepLabV3-R50 shapes at 256x256.
 
     python tools/conv_shapes_bench.py [--batch 16] [--reps 10] [--only fwd|dgrad|wgrad]
-Prints one line per (shape, pass): microseconds, nominal TFLOP/s, fraction of the fp32 MFMA peak.
+Prints one line per (shape, pass): microseconds; nominal TFLOP/s (dense FLOPs, padding taps counted - an fp32-equivalent
+rate, NOT a utilisation); executed TFLOP/s (padding-only K chunks the kernel skips left out); and `frac` = the MFMA work
+really issued against the peak of the MFMA type that ran it: executed x (16-bit products per fp32 product: 3 for the
+fp16x2 split kernels, 6 for bf16x3) / 2516.6 for the split kernels, executed / 157.3 for the fp32-MFMA kernels.
 """
 import argparse
 import os
@@ -12,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from weaklysuperviseddl_amd import ops  # noqa: E402
 
-PEAK = 157.3
+PEAK32, PEAK16 = 157.3, 2516.6
 # (count, Cin, Cout, k, stride, dil, Hin, name)
 SHAPES = [
     (1, 3, 64, 7, 2, 1, 256, "conv1"),
@@ -75,7 +78,7 @@ def main():
             ops.set_option(k, v)
     B = args.batch
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
-    print(f"{'shape':24s} {'pass':6s} {'us':>9s} {'TFLOP/s':>8s} {'frac':>6s}  x count")
+    print(f"{'shape':24s} {'pass':6s} {'us':>9s} {'nominal':>8s} {'executed':>9s} {'frac':>6s}  x count   kernel")
     want = [w for w in args.shapes.split(",") if w]
     for cnt, Cin, Cout, k, s, d, H, name in SHAPES:
         if want and not any(w in name for w in want):
@@ -100,12 +103,30 @@ def main():
                 continue
             us = timeit(fn, args.reps)
             tf = flops / us / 1e6
+            # one instrumented launch: which kernel class ran, and how much of the nominal work it executed
+            ops.prof_reset()
+            ops.prof_enable(True)
+            fn()
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+            kname, work, exe = "?", flops, flops
+            for c in range(ops.PROF_NCLASSES):
+                n, _, w_, e_, _ = ops.prof_collect(c)
+                if n and "conv" in ops.prof_class_name(c):
+                    kname, work, exe = ops.prof_class_name(c), w_, e_
+            ops.prof_reset()
+            etf = tf * (exe / work if work else 1.0)
+            split = "split" in kname
+            nprod = (3.0 if ops.CONV_ARITH[0] == 1 else 6.0) if split else 1.0
+            frac = etf * nprod / (PEAK16 if split else PEAK32)
             tot[pname][0] += us * cnt
             tot[pname][1] += flops * cnt
-            print(f"{name:24s} {pname:6s} {us:9.1f} {tf:8.1f} {tf / PEAK:6.3f}  x{cnt}")
-    for pname, (us, fl) in tot.items():
+            tot[pname].append(exe / work * flops * cnt if work else flops * cnt)
+            print(f"{name:24s} {pname:6s} {us:9.1f} {tf:8.1f} {etf:9.1f} {frac:6.3f}  x{cnt}   {kname}")
+    for pname, v in tot.items():
+        us, fl, ex = v[0], v[1], sum(v[2:])
         if us:
-            print(f"TOTAL {pname:6s} {us / 1e3:8.2f} ms  {fl / us / 1e6:6.1f} TFLOP/s nominal ({fl / us / 1e6 / PEAK:.3f} of peak)")
+            print(f"TOTAL {pname:6s} {us / 1e3:8.2f} ms  {fl / us / 1e6:6.1f} TFLOP/s nominal, {ex / us / 1e6:6.1f} TFLOP/s executed (fp32-equivalent)")
 
 
 if __name__ == "__main__":

@@ -30,10 +30,21 @@ step "PMC: MFMA busy cycles of the whole step"
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/b_m -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 --serial > /dev/null 2>&1 || exit 1
 python3 $R/tools/pmc_table.py $O/b_m > $O/pmc_mfma_busy.txt 2>&1
 
-step "per-shape conv table"
+step "per-shape conv table (default fp16x2, bf16x3, fp32-MFMA kernels)"
 python3 $R/tools/conv_shapes_bench.py > $O/conv_shapes.txt 2>&1 || exit 1
+python3 $R/tools/conv_shapes_bench.py --opt conv_arith=0 > $O/conv_shapes_bf16x3.txt 2>&1 || exit 1
 python3 $R/tools/conv_shapes_bench.py --opt conv_split=0,wgrad_split=0 > $O/conv_shapes_fp32.txt 2>&1 || exit 1
 python3 $R/tools/conv_accuracy.py > $O/conv_accuracy.txt 2>&1 || exit 1
+
+step "MFMA busy of the 3x3 convolutions, per shape"
+$R/tools/mfma_busy_3x3.sh > $O/mfma_busy_3x3.txt 2> $O/mfma_busy_3x3.err || exit 1
+cd /tmp
+
+step "other BASELINE configs through bench.py, 2-rank rehearsal, bf16x3 A/B, hipGraph A/B"
+for c in cfg3 cfg4 cfg5; do python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err || exit 1; done
+python3 $R/bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_n2_gloo_one_gpu.json 2> $O/bench_n2.err || exit 1
+python3 $R/bench.py --no-cpu-baseline --no-cam --opt conv_arith=0 > $O/bench_n1_bf16x3.json 2> /dev/null || exit 1
+python3 $R/bench.py --no-cpu-baseline --no-cam --graph 1 > $O/bench_n1_hipgraph.json 2> /dev/null || exit 1
 
 step "loss / CAM kernels, other configs"
 python3 $R/tools/loss_cam_bench.py > $O/loss_cam_kernels.txt 2>&1 || exit 1
