@@ -123,7 +123,10 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
         return None
-    k = json.load(open(files[-1])).get("kernels", {}).get(kernel)
+    from weaklysuperviseddl_amd import ops
+    # the library's timing classes name the arithmetic template argument "AR"; rocprofv3 prints its value
+    name = kernel.replace(", AR>", f", {ops.CONV_ARITH[0]}>")
+    k = json.load(open(files[-1])).get("kernels", {}).get(name)
     return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
 
 
@@ -444,6 +447,8 @@ def main():
         return
     if args.serial:
         ops.OVERLAP_WGRAD[0] = False
+    if os.environ.get("WSDL_WGRAD_AFTER_DGRAD"):
+        ops.WGRAD_AFTER_DGRAD[0] = True             # A/B: enqueue the input gradient before the weight gradient
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")

@@ -429,6 +429,7 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
 # Weight gradients are only consumed by the optimiser step, so they run on a side HIP stream: the MFMA-bound
 # wgrad kernels overlap the HBM-bound BatchNorm backward / gradient-reduce kernels of the main chain.
 OVERLAP_WGRAD = [True]
+WGRAD_AFTER_DGRAD = [False]     # measured: 21.2 ms/step against 20.9 with the weight gradient enqueued first (profiles/r02_notes.md)
 _side_streams = {}
 
 
@@ -518,6 +519,26 @@ class _ConvBNAct(torch.autograd.Function):
             sg.grad_ready(pb)
         else:
             dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s)
+        def input_grad():
+            dx = None
+            if ctx.needs_input_grad[0]:
+                if wd is None:
+                    raise WsdlError("conv backward: dgrad weights were not prepared")
+                into = None
+                if _owned(dxres) and tuple(dxres.shape) == tuple(xshape):
+                    into = dxres        # the identity branch's gradient (a fresh BN-backward output): dx = dgrad(...) + it
+                dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into)
+                if into is None and dxres is not None:
+                    dx = dx + dxres
+            elif dxres is not None:
+                dx = dxres
+            return dx
+
+        # Order of the two MFMA-bound kernels.  The weight gradient runs on the side stream behind everything enqueued on
+        # the main stream so far.  WGRAD_AFTER_DGRAD: enqueue the input gradient FIRST, so the weight gradient starts when
+        # it has finished and runs beside the NEXT layer's BatchNorm backward (HBM-bound) instead of beside this layer's
+        # input gradient (two MFMA-bound kernels sharing one power budget gain nothing from overlapping).
+        dx = input_grad() if WGRAD_AFTER_DGRAD[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
@@ -525,18 +546,8 @@ class _ConvBNAct(torch.autograd.Function):
                 _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax)
             else:
                 dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil, x_amax=ctx.x_amax)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if wd is None:
-                raise WsdlError("conv backward: dgrad weights were not prepared")
-            into = None
-            if _owned(dxres) and tuple(dxres.shape) == tuple(xshape):
-                into = dxres        # the identity branch's gradient (a fresh BN-backward output): dx = dgrad(...) + it
-            dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into)
-            if into is None and dxres is not None:
-                dx = dx + dxres
-        elif dxres is not None:
-            dx = dxres
+        if not WGRAD_AFTER_DGRAD[0]:
+            dx = input_grad()
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
                 dres, None, None, None, None, None, None, None, None, None, None)
 
