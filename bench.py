@@ -461,10 +461,13 @@ def main():
     B = args.batch or CONFIGS[cfg]["batch"]
     S = args.size or CONFIGS[cfg]["size"]
     use_graph = bool(args.graph) if args.graph is not None else False
-    if use_graph and (world > 1 or cfg == "cfg4"):
+    if use_graph and (world > 1 or dist.is_initialized() or cfg == "cfg4"):
         raise SystemExit("--graph 1: hipGraph replay covers the single-process training step (cfg2 / cfg3 / cfg5)")
     model, opt, step, eager_step = build_workload(cfg, B, S, device, rank, graph=use_graph)
-    reducer = GradBucketReducer(opt, modules=[model]) if world > 1 else None   # noqa: F841  (hooks live on the optimizer)
+    # WSDL_FORCE_DIST=1 puts the data-parallel machinery (RCCL broadcasts / bucketed all-reduces, control exchange) on a
+    # single rank as well: the one-GPU rehearsal of the code path the 8-GPU run takes
+    dp_on = world > 1 or (dist.is_available() and dist.is_initialized())
+    reducer = GradBucketReducer(opt, modules=[model]) if dp_on else None   # noqa: F841  (hooks live on the optimizer)
 
     if rank == 0:
         log(f"{cfg} on {device}, world={world}, B={B}, {S}x{S}; warm-up {args.warmup} steps")
@@ -510,13 +513,13 @@ def main():
                                   "fp32 accumulate") + " - rms error vs fp64 at the level of the exact-fp32 MFMA chain "
                                  "(tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
                    "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
-                   "backend": (dist.get_backend() if world > 1 else None),
+                   "backend": (dist.get_backend() if dp_on else None),
                    "launch": "hipGraph replay (one host call per step)" if use_graph else "eager (one host call per kernel)",
                    "final_loss": round(loss_val, 5)},
         "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5), "issue_ms_per_step": round(host_issue_s / args.steps * 1e3, 3),
                  "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
     }
-    if world > 1:
+    if dp_on:
         result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches}
 
     if not args.no_roofline:
@@ -607,6 +610,7 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

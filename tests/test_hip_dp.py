@@ -125,6 +125,53 @@ def test_hip_dp_reduced_gradients_equal_the_sum_of_the_shard_gradients(dev, tmp_
     assert torch.equal(got["params"][0], got["params"][1])       # replicas stay bit-identical
 
 
+def _worker_rccl_single(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      WSDL_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("WSDL_DIST_BACKEND", None)
+    torch.set_num_threads(2)
+    import torch.distributed as dist
+    from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer, average_bn_buffers
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    dev = torch.device("cuda:0")
+    init_distributed()
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    model = _seg_model(dev, seed=0)
+    opt = make_optimizer(model, lr=1e-4)
+    red = GradBucketReducer(opt, modules=[model])      # RCCL broadcasts of parameters / moments / buffers
+    assert red.active
+    img, masks = (t.to(dev) for t in _shard(0))
+    losses, early = [], []
+    for _ in range(3):                                 # RCCL all-reduces enqueued from the side stream by the hooks
+        losses.append(float(train_step(model, opt, img, masks)))
+        early.append(red.last_early_launches)
+    average_bn_buffers([model])
+    torch.cuda.synchronize()
+    torch.save({"params": opt.flat_param.detach().cpu(), "losses": losses, "early": early,
+                "buckets": len(red.bucket_size)}, out)
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_path_equals_the_plain_step(dev, tmp_path):
+    """The RCCL calls themselves on the one GPU there is (WSDL_FORCE_DIST=1: backend "nccl", world 1): broadcasts,
+    bucketed all-reduces launched from backward hooks on the side stream, the gloo control exchange.  A one-rank sum is
+    the identity and 1/world = 1, so three steps must reproduce the plain single-process steps bit for bit."""
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    out = str(tmp_path / "single.pt")
+    mp.spawn(_worker_rccl_single, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    model = _seg_model(dev, seed=0)
+    opt = make_optimizer(model, lr=1e-4)
+    img, masks = (t.to(dev) for t in _shard(0))
+    losses = [float(train_step(model, opt, img, masks)) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert got["losses"] == losses
+    assert torch.equal(got["params"], opt.flat_param.detach().cpu())
+    assert got["buckets"] == 4 and got["early"][-1] == 4       # every bucket left from a hook once the aux head was known
+
+
 def _cam_loader(n_batches=4, B=2):
     g = torch.Generator().manual_seed(41)
     return [(torch.rand(B, 3, 224, 224, generator=g), ((torch.arange(B) + 5 * j) % 37, None)) for j in range(n_batches)]

@@ -8,7 +8,9 @@ from weaklysuperviseddl_amd import ops
 dev = torch.device("cuda:0")
 opts = [kv.split("=") for kv in sys.argv[1].split(",")]
 shapes = [(16, 512, 512, 3, 1, 4, 32), (16, 512, 2048, 1, 1, 1, 32), (16, 2048, 256, 3, 1, 12, 32), (16, 256, 256, 3, 1, 2, 32),
-          (16, 256, 1024, 1, 1, 1, 32), (8, 512, 512, 3, 1, 4, 64), (32, 1024, 512, 1, 1, 1, 32), (16, 2048, 512, 1, 1, 1, 32)]
+          (16, 256, 1024, 1, 1, 1, 32), (8, 512, 512, 3, 1, 4, 64), (32, 1024, 512, 1, 1, 1, 32), (16, 2048, 512, 1, 1, 1, 32),
+          (2, 64, 64, 3, 1, 1, 64), (4, 128, 128, 3, 2, 1, 32), (2, 256, 64, 1, 1, 1, 16), (8, 2048, 256, 3, 1, 24, 28),
+          (16, 64, 256, 1, 1, 1, 64), (16, 128, 128, 3, 1, 1, 32), (3, 48, 80, 3, 1, 1, 17), (16, 1024, 256, 3, 1, 1, 32)]
 ok = True
 for B, Cin, Cout, k, s, d, H in shapes:
     g = torch.Generator(device=dev).manual_seed(Cin + Cout)

@@ -43,6 +43,7 @@ cd /tmp
 step "other BASELINE configs through bench.py, 2-rank rehearsal, bf16x3 A/B, hipGraph A/B"
 for c in cfg3 cfg4 cfg5; do python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err || exit 1; done
 python3 $R/bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_n2_gloo_one_gpu.json 2> $O/bench_n2.err || exit 1
+WSDL_FORCE_DIST=1 python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline > $O/bench_n1_rccl_single_rank.json 2> /dev/null || exit 1
 python3 $R/bench.py --no-cpu-baseline --no-cam --opt conv_arith=0 > $O/bench_n1_bf16x3.json 2> /dev/null || exit 1
 python3 $R/bench.py --no-cpu-baseline --no-cam --graph 1 > $O/bench_n1_hipgraph.json 2> /dev/null || exit 1
 

@@ -1209,6 +1209,7 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
+int g_conv_glds = 0;      // weights of the fp16x2 kernels by LDS-DMA: bit 0 the 256x128 form, bit 1 the 4-wave forms
 int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
@@ -1233,9 +1234,10 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    if (g_conv_arith)
-        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
-    else
+    if (g_conv_arith) {
+        if (g_conv_glds & 2) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
+    } else
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 0>), grid, dim3(kThreads), 0, s, p);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -1250,7 +1252,8 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     const bool bk32 = g_t256_bk32 && p.Cin % 32 == 0;
     if (g_conv_arith) {
-        if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
+        if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
+        else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
     } else {
         if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 0>), grid, dim3(512), 0, s, p);
@@ -1567,6 +1570,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
     if (!strcmp(name, "t256_bk32")) { g_t256_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
+    if (!strcmp(name, "conv_glds")) { g_conv_glds = value; return WSDL_OK; }
     if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }

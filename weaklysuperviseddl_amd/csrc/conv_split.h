@@ -104,6 +104,19 @@ __device__ __forceinline__ f32x16 split_products(const F (&a)[SplitArith<AR>::NP
     return c;
 }
 
+// One LDS-DMA wave-instruction: lane i copies 16 bytes from its own buffer offset to LDS byte `lds_addr` + 16 i
+// (lds_addr wave-uniform).  Inline assembly so that the compiler, which would drain vmcnt(0) before any later ds_read
+// that might alias the DMA's destination, keeps the copy in flight behind the MFMAs; the caller counts it in its own
+// s_waitcnt vmcnt.  M0 (the destination base) is compiler-reserved: saved and restored inside the statement.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+                 : "memory");
+}
+
 constexpr int split_k16_bytes(int AR) { return AR ? 64 : 96; }     // one row's 16 k values: NP pieces x 16 x 2 bytes
 // the layout buffers end in a 16-byte trailer holding the tensor's amax (AR = 1)
 __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_total, long long rows) {
@@ -118,7 +131,14 @@ __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_t
 // The kernel re-labels its workgroup so that XCD c owns a (pixel-group, row-group) rectangle of the tile grid:
 // py row groups x 8/py pixel groups.  Each XCD then streams 1/py of the weights and py/8 of the activations instead of
 // all the weights and 1/8 of the activations; the host picks py per launch from the two operands' byte counts.
-template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1>
+//
+// GL (weights by LDS-DMA): the pre-split weights need no arithmetic on their way to LDS, so `buffer_load_dwordx4 ... lds`
+// copies them without passing through VGPRs or ds_write_b128 (13 cycles per wave-instruction on the VGPR->LDS path).
+// One wave-instruction fills 1 KiB of consecutive LDS bytes, lane by lane; the padded row image is kept by giving
+// every lane the SOURCE address of the 16-byte unit that belongs at its destination (the pad unit re-reads its
+// neighbour).  The DMA of chunk q+1 is issued after the barrier that retired the buffer's last readers and is waited
+// for with a counted vmcnt (the activation loads of chunk q+2 stay in flight) before the barrier that publishes it.
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool GL = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
     using Ar = SplitArith<AR>;
     using frag = typename Ar::frag;
@@ -134,6 +154,10 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     constexpr int A_UPS = BM * UPR;                      // 16-byte units of one k16 slab of the row tile
     constexpr int A_U = (KS * A_UPS + NT - 1) / NT;      // units per thread per chunk
     constexpr bool A_EXACT = A_U * NT == KS * A_UPS;
+    constexpr int RU = ROW / 16;                         // 16-byte units per LDS row, the last one padding
+    constexpr int G_TU = BM * RU;                        // units of the padded A image (a multiple of 64)
+    constexpr int G_U = (G_TU + NT - 1) / NT;            // LDS-DMA instructions per thread per chunk
+    static_assert(!GL || G_TU % 64 == 0, "whole wave-instructions");
     constexpr int B_STEP = NT / BN;                      // threads sharing one pixel
     constexpr int B_PER = BK / B_STEP;                   // consecutive k (input channels) per thread
     static_assert(B_PER == 4 || B_PER == 8 || B_PER == 16 || B_PER == 32, "B tile");
@@ -244,6 +268,20 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
         lds_a[e] = (unsigned)(row * ROW + ks * K16B + part * 16);
     }
 
+    // LDS-DMA form: unit u of the padded image = (row, 16-byte slot of the row); slot RU-1 is the padding
+    unsigned voff_g[GL ? G_U : 1];
+    if constexpr (GL) {
+#pragma unroll
+        for (int e = 0; e < G_U; ++e) {
+            const int u = tid + e * NT;
+            const int row = u / RU;
+            int part = u - row * RU;
+            part = part == RU - 1 ? RU - 2 : part;
+            const int ks = part / UPR, pp = part - ks * UPR;
+            voff_g[e] = (m0 + row < p.Cout && u < G_TU) ? (unsigned)(ks * p.Cout * K16B + ((m0 + row) * UPR + pp) * 16) : kOOB;
+        }
+    }
+
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -252,7 +290,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[A_U];
+    u32x4 ra[GL ? 1 : A_U];
     unsigned rb[B_PER];
     int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
     unsigned voff_b = kOOB;
@@ -270,21 +308,45 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             ++ld_vi;
             set_tap(ld_vi);
         }
-        const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
-        const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
+        if constexpr (!GL) {
+            const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
+            const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+            for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
+        }
         const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
             rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
         ++ld_c;
     };
+    // LDS-DMA of the weight chunk `wq` (its own cursor: it runs one chunk behind the activation loads)
+    int wq_vi = q0 / cpt, wq_c = q0 - (q0 / cpt) * cpt;
+    const int wave_base = __builtin_amdgcn_readfirstlane(wid) * 1024;
+    const unsigned as_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)&As[0][0];
+    const unsigned long long wt_addr = reinterpret_cast<unsigned long long>(p.wt);
+    const i32x4 rw_words = {(int)(unsigned)wt_addr, (int)(unsigned)(wt_addr >> 32), wbytes, 0x00020000};
+    auto dma_weights = [&](int buf) {
+        if (wq_c == cpt) {
+            wq_c = 0;
+            ++wq_vi;
+        }
+        const int tap = __builtin_amdgcn_readfirstlane(vtaps[wq_vi]);
+        const int c16 = (tap * p.Cin + wq_c * BK) / 16;
+        const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
+#pragma unroll
+        for (int e = 0; e < G_U; ++e)
+            if ((e + 1) * NT <= G_TU || wave_base + e * NT * 16 < G_TU * 16)
+                lds_dma16(rw_words, voff_g[e], soff_a, as_base + (unsigned)(buf * (BM * ROW) + e * NT * 16 + wave_base));
+        ++wq_c;
+    };
     // this thread's k run [kr*B_PER, kr*B_PER + B_PER) inside the chunk -> (k-step, offset inside the 16)
     auto store_tiles = [&](int buf) {
+        if constexpr (!GL) {
 #pragma unroll
-        for (int e = 0; e < A_U; ++e)
-            if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
+            for (int e = 0; e < A_U; ++e)
+                if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
+        }
         unsigned pc[NP][B_PER / 2];
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e) {
@@ -312,11 +374,18 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     };
 
     if (nq > 0) {
+        if constexpr (GL) dma_weights(0);
         load_next();
         store_tiles(0);
         if (nq > 1) load_next();
+        if constexpr (GL) {
+            // the DMA is older than the second chunk's activation loads: leave those in flight
+            if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
-    __syncthreads();
+    if constexpr (GL) lds_barrier();
+    else __syncthreads();
     const int l31 = lane & 31, lh = lane >> 5;
     auto mfma_chunk = [&](int cur) {
         const unsigned char* Ab = As[cur] + (wm * (MI * 32) + l31) * ROW + lh * 16;
@@ -342,9 +411,16 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     };
     for (int q = 0; q < nq; ++q) {
         const int cur = q & 1;
-        if (q + 1 < nq) store_tiles(cur ^ 1);            // the registers hold chunk q + 1
+        if (q + 1 < nq) {
+            store_tiles(cur ^ 1);                        // the registers hold chunk q + 1
+            if constexpr (GL) dma_weights(cur ^ 1);
+        }
         if (q + 2 < nq) load_next();
         mfma_chunk(cur);
+        if constexpr (GL) {
+            if (q + 2 < nq) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         lds_barrier();
     }
 

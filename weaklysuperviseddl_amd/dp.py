@@ -34,12 +34,22 @@ import torch
 import torch.distributed as dist
 
 
+def _forced():
+    """WSDL_FORCE_DIST=1: run the whole data-parallel machinery (process group, broadcasts, bucketed all-reduces, control
+    exchange) even with ONE rank - the only way to put the RCCL calls themselves on a one-GPU box."""
+    return os.environ.get("WSDL_FORCE_DIST") == "1"
+
+
+def _single(group=None):
+    return dist.get_world_size(group) == 1 and not _forced()
+
+
 def init_distributed(backend=None):
     """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -72,7 +82,7 @@ def control_group(group=None):
 
 def sync_initial_state(optimizer, modules=(), group=None, src=0):
     """Broadcast the flat parameter buffer, the Adam moments / step count and every buffer of ``modules`` from ``src``."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _single(group):
         return
     for t in (optimizer.flat_param, optimizer.exp_avg, optimizer.exp_avg_sq):
         dist.broadcast(t, src=src, group=group)
@@ -92,7 +102,7 @@ def sync_initial_state(optimizer, modules=(), group=None, src=0):
 def average_bn_buffers(modules, group=None):
     """Replace every floating-point buffer (BatchNorm running_mean / running_var) by its mean over the ranks; call
     it before saving a state_dict, which would otherwise hold the saving rank's statistics only."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or _single(group):
         return
     world = dist.get_world_size(group)
     for m in modules:
@@ -109,6 +119,7 @@ class GradBucketReducer:
         self.opt = optimizer
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or _forced())
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step_hook = self.wait
         n = optimizer.numel
@@ -143,7 +154,7 @@ class GradBucketReducer:
         self._remaining = list(self.bucket_size)
         self._accumulating = False
         self._hooks = {}
-        if self.world > 1:
+        if self.active:
             self._control = control_group(process_group)
             self._bitmap = torch.zeros(nparams, dtype=torch.uint8)
             if sync_state:
@@ -240,7 +251,7 @@ class GradBucketReducer:
         """Launch any bucket whose hooks did not all fire, reduce late gradients of excluded parameters, join, and
         learn which parameters to leave out next step - all from the bitmap every rank agrees on."""
         opt = self.opt
-        if self.world > 1:
+        if self.active:
             fired = self._agree()
             self._launch_ready(early=False)
             late = sorted(self._excluded & fired)
