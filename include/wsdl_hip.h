@@ -53,6 +53,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
  *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
+ *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms);
+ *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
