@@ -53,6 +53,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
  *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
+ *   wgrad_wide     0*  split weight-gradient kernel: a lane stages 8-pixel runs of two x rows (16-byte loads / LDS stores)
+ *                      instead of one pixel of sixteen rows (stride 1, OW % 8 == 0); bit-identical
+ *   wgrad_xcd      0*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
+ *                      -1.4 % on the kernel sweep, nothing on the step
  *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms);
  *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers

@@ -170,6 +170,35 @@ def test_fp16x2_scales_cover_extreme_magnitudes(dev):
     assert not torch.isfinite(ops.conv2d_fwd(bad, wf, w.shape, 1, 1, 1)).all()   # an inf input is not silently dropped
 
 
+@pytest.mark.parametrize("opt,val", [("conv_glds", 3), ("wgrad_wide", 1), ("wgrad_xcd", 1), ("wgrad_xcd", 2), ("xcd_map", 0),
+                                     ("t256_bk32", 0)])
+def test_scheduling_options_reproduce_the_default_bit_for_bit(dev, opt, val):
+    """Options that change how operands travel (LDS-DMA weights, 8-pixel-run staging, XCD-aware tile orders, K chunk) and
+    not what is computed: forward, input gradient and weight gradient equal the default's bit for bit, on shapes that
+    reach the 256x128 and the 4-wave forms, a dilated 3x3 with masked row ends, a strided conv and a ragged one."""
+    from weaklysuperviseddl_amd import ops
+    shapes = [(16, 512, 512, 3, 1, 2, 32), (4, 256, 256, 3, 1, 4, 16), (2, 128, 128, 3, 2, 1, 32), (16, 256, 1024, 1, 1, 1, 32),
+              (3, 48, 80, 3, 1, 1, 17), (2, 128, 256, 3, 1, 36, 24)]
+    default = {"conv_glds": 0, "wgrad_wide": 0, "wgrad_xcd": 0, "xcd_map": 1, "t256_bk32": 1}[opt]
+    try:
+        for B, Cin, Cout, k, st, d, H in shapes:
+            g = torch.Generator(device=dev).manual_seed(Cin + Cout + H)
+            pad = (k // 2) * d
+            x = torch.randn(B, Cin, H, H, device=dev, generator=g)
+            w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) * 0.05
+            res = []
+            for v in (default, val):
+                ops.set_option(opt, v)
+                wf, wd = ops.prep_weights(w)
+                y = ops.conv2d_fwd(x, wf, w.shape, st, pad, d)
+                dy = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+                res.append((y, ops.conv2d_dgrad(dy, wd, w.shape, x.shape, st, pad, d), ops.conv2d_wgrad(x, dy, w.shape, st, pad, d)))
+            for a, b, what in zip(res[0], res[1], ("fwd", "dgrad", "wgrad")):
+                assert torch.equal(a, b), (opt, val, what, (B, Cin, Cout, k, st, d, H))
+    finally:
+        ops.set_option(opt, default)
+
+
 def test_weight_layout_sizes(dev):
     """The opaque layout buffers: 4 bytes per weight (fp32 k-major; two fp16 pieces + a 16-byte amax trailer) or 6 (three
     bf16 pieces + trailer), by shape and option."""

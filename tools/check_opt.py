@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Bit-compare a library option against the default on a few conv shapes (fwd + dgrad): an option that only changes
-scheduling must reproduce the default's output exactly.   python tools/check_opt.py pipe=1"""
+scheduling must reproduce the default's output exactly.   python tools/check_opt.py wgrad_wide=1
+(the option's value 0 is the baseline)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,9 @@ opts = [kv.split("=") for kv in sys.argv[1].split(",")]
 shapes = [(16, 512, 512, 3, 1, 4, 32), (16, 512, 2048, 1, 1, 1, 32), (16, 2048, 256, 3, 1, 12, 32), (16, 256, 256, 3, 1, 2, 32),
           (16, 256, 1024, 1, 1, 1, 32), (8, 512, 512, 3, 1, 4, 64), (32, 1024, 512, 1, 1, 1, 32), (16, 2048, 512, 1, 1, 1, 32),
           (2, 64, 64, 3, 1, 1, 64), (4, 128, 128, 3, 2, 1, 32), (2, 256, 64, 1, 1, 1, 16), (8, 2048, 256, 3, 1, 24, 28),
-          (16, 64, 256, 1, 1, 1, 64), (16, 128, 128, 3, 1, 1, 32), (3, 48, 80, 3, 1, 1, 17), (16, 1024, 256, 3, 1, 1, 32)]
+          (16, 64, 256, 1, 1, 1, 64), (16, 128, 128, 3, 1, 1, 32), (3, 48, 80, 3, 1, 1, 17), (16, 1024, 256, 3, 1, 1, 32),
+          (2, 128, 128, 3, 1, 1, 8), (1, 256, 128, 3, 1, 2, 16), (3, 128, 256, 3, 1, 3, 24), (2, 256, 256, 3, 1, 36, 32),
+          (2, 128, 128, 3, 1, 1, 28), (16, 2048, 256, 3, 1, 36, 32), (5, 128, 128, 5, 1, 1, 40)]
 ok = True
 for B, Cin, Cout, k, s, d, H in shapes:
     g = torch.Generator(device=dev).manual_seed(Cin + Cout)
@@ -25,9 +28,10 @@ for B, Cin, Cout, k, s, d, H in shapes:
         y = ops.conv2d_fwd(x, wf, w.shape, s, pad, d)
         dy = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
         dx = ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d)
-        res[tag] = (y, dx)
+        dw = ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)
+        res[tag] = (y, dx, dw)
     e = [bool(torch.equal(a, b)) for a, b in zip(res["base"], res["opt"])]
     md = [((a - b).abs().max() / a.abs().max()).item() for a, b in zip(res["base"], res["opt"])]
-    print((B, Cin, Cout, k, s, d, H), "fwd/dgrad bit-equal:", e, "max rel diff", md)
+    print((B, Cin, Cout, k, s, d, H), "fwd/dgrad/wgrad bit-equal:", e, "max rel diff", md)
     ok &= all(e)
 print("ALL EQUAL" if ok else "DIFFERENCES")

@@ -594,6 +594,7 @@ struct WgradP {
     unsigned x_bytes, dy_bytes;   // extents for the buffer-descriptor fast path (0 = not eligible)
     int ow0, own;                 // output-column window (fast kernel): P = B*OH*own
     int slab0;                    // first slab index of this launch
+    int xcd_order;                // split32 kernel: 0 launch order, 1 XCD-contiguous (slab, row tile, N tile) order, 2 + 2x2 blocks
     int nb, splits;               // column bands inside one launch: blockIdx.z = band * splits + split
     int b_ow0[4], b_own[4], b_cps[4];   // per band: window and 32-pixel chunks per split
     const float* x_amax;                // split kernel, fp16x2 arithmetic: device scalar >= max|x|
@@ -1461,6 +1462,8 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
+int g_wgrad_xcd = 0;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
+int g_wgrad_wide = 0;        // 8-pixel runs per lane in the x staging of the split weight-gradient kernel (stride 1, OW % 8 == 0)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
 bool wgrad_chunk32(int Cout, int Cin, int N) {
@@ -1575,6 +1578,8 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_wide")) { g_wgrad_wide = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1837,13 +1842,18 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
                 const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
                 dim3 grid(p.N / 128, Cout / 128, S);
+                p.xcd_order = ((long long)grid.x * grid.y * grid.z) % 8 == 0 ? g_wgrad_xcd : 0;
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
                     hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                     WSDL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
-                                       (unsigned)dys_bytes, dy_amax);
+                    if (g_wgrad_wide && stride == 1 && OW % 8 == 0)
+                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                           (unsigned)dys_bytes, dy_amax);
+                    else
+                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
+                                           (unsigned)dys_bytes, dy_amax);
                 } else {
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,
                                        static_cast<const float*>(nullptr));

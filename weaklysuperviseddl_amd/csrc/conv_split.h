@@ -668,7 +668,13 @@ __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __r
 // SIMD sit in the same phase), producer / consumer waves with a 3-deep register ring (the pure consumer loop - one
 // wave per SIMD, operand reads exposed after every barrier - already runs at half the MFMA rate).
 // `dy_amax` / p.x_amax: the scales of the two operands (AR = 1); the slab receives acc / (s_dy * s_x).
-template <int BM, int BN, int AR>
+//
+// WX (stride 1, OW % 8 == 0): a lane owns 8 CONSECUTIVE pixels of two x rows instead of one pixel of sixteen: two
+// 16-byte loads per row (an 8-pixel run of one output row maps to 8 consecutive input pixels; the run may start before
+// / end after the input row - those elements are masked to the padding's zeros), no neighbour exchange, and one
+// ds_write_b128 per (row, piece) instead of eight ds_write_b32: 4 loads + 4 LDS stores per chunk where the one-pixel
+// form issues 16 + 32.  Same LDS image, same MFMA order: bit-identical results.
+template <int BM, int BN, int AR, bool WX = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
     static_assert(BM == 128 && BN == 128, "tile");
@@ -689,8 +695,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int zsplit = blockIdx.z, w_cps = p.chunks_per_split;
+    // XCD-aware tile order (p.xcd_order): workgroups are dealt round-robin to the 8 XCDs in launch order, so in launch
+    // order every XCD's L2 sees every (row tile, slab) of dY - 8 x the unique bytes measured at the fabric.  Re-labelled,
+    // XCD c owns a contiguous eighth of the (slab, row tile, N tile) sequence: about one and a half (row tile, slab)
+    // pairs of dY and the x rows under them.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_order) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int L = (bz * gy + by) * gx + bx, eighth = (gx * gy * (int)gridDim.z) >> 3;
+        const int Lp = (L & 7) * eighth + (L >> 3);
+        bz = Lp / (gx * gy);
+        const int r = Lp - bz * (gx * gy);
+        if (p.xcd_order == 2 && (gy & 1) == 0 && (p.Cin / BN & 1) == 0) {
+            // blocks of (2 row tiles x 2 channel blocks x all taps): the taps of a channel block share x rows
+            const int cb = p.Cin / BN, T = gx / cb, blk = 4 * T;
+            const int b = r / blk, q = r - b * blk;
+            const int mp = b / (cb / 2), cp = b - mp * (cb / 2);
+            const int t = q >> 2, ml = (q >> 1) & 1, cl = q & 1;
+            by = 2 * mp + ml;
+            bx = t * cb + 2 * cp + cl;
+        } else {
+            by = r / gx;
+            bx = r - by * gx;
+        }
+    }
+    const int n0 = bx * BN, m0 = by * BM;
+    const int zsplit = bz, w_cps = p.chunks_per_split;
     const int W_P = p.P;
     const int OHOW = p.OH * p.OW, HW = p.H * p.W;
     const int px = tid & 31, hw = tid >> 5;
@@ -737,8 +767,31 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
 
     const bool row_chunks = (p.OW % BK) == 0;
     unsigned nvb = kOOB;
+    // WX: run = the lane's 8-pixel run of the chunk; its two rows are wx_row and wx_row + 64, with the low two bits of
+    // the row index swapped so that the 8 lanes of a ds_write_b128 group hold rows R and R + 2 (row stride 144 bytes:
+    // rows one apart would share banks)
+    const int wx_run = tid & 3, wx_g = tid >> 2;
+    const int wx_row = (wx_g & ~3) | ((wx_g & 1) << 1) | ((wx_g >> 1) & 1);
+    int wx_off = 0;                    // element offset of the run's first input pixel (may be negative / past the row)
+    unsigned wx_mask = 0;              // bit e: pixel e of the run reads a real input pixel
     auto decode = [&](int c) {
         nvb = kOOB;
+        if constexpr (WX) {
+            wx_mask = 0;
+            const int pix0 = c * BK + 8 * wx_run;
+            if (pix0 < W_P) {
+                const int pb = pix0 / OHOW, rr = pix0 - pb * OHOW;
+                const int oh = rr / p.OW, ow0 = rr - oh * p.OW;
+                const int ih = oh + t_dh, iw0 = ow0 + t_dw;
+                if (ih >= 0 && ih < p.H && iw0 + 7 >= 0 && iw0 < p.W) {
+                    const int lo = iw0 < 0 ? -iw0 : 0, hi = p.W - iw0 < 8 ? p.W - iw0 : 8;     // valid elements [lo, hi)
+                    wx_mask = (0xffu >> (8 - hi)) & (0xffu << lo);
+                    wx_off = (int)((long long)pb * p.x_bs) + (ci0 + wx_row) * HW + ih * p.W + iw0;
+                    nvb = 0;
+                }
+            }
+            return;
+        }
         if (row_chunks) {
             const int first = c * BK;
             const int grow = first / p.OW, ow = first - grow * p.OW + px;
@@ -764,10 +817,33 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
         }
         return c;
     };
+    unsigned ld_mask = 0;              // wx_mask of the chunk whose x values sit in rb
     auto load_tiles = [&](int c) {
         const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+        if constexpr (WX) {
+            ld_mask = wx_mask;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // the four pixels [4h, 4h + 4) of row j: one 16-byte load wherever the quad lies inside the tensor
+                    const int off = wx_off + j * 64 * HW + 4 * h;
+                    const unsigned m4 = (wx_mask >> (4 * h)) & 15u;
+                    u32x4 q = {0u, 0u, 0u, 0u};
+                    if (off >= 0 && (unsigned)off * 4u + 16u <= p.x_bytes) {
+                        q = __builtin_amdgcn_raw_buffer_load_b128(rx, m4 ? (unsigned)off * 4u : kOOB, 0, 0);
+                    } else if (m4) {               // the tensor's first / last row: element by element
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            q[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, ((m4 >> e) & 1u) ? (unsigned)(off + e) * 4u : kOOB, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[j * 8 + 4 * h + e] = q[e];
+                }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
             rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
@@ -775,9 +851,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     const bool even = (px & 1) == 0;
     const int pair = px >> 1;
     const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * K16B + (pair & 7) * 4);
+    const unsigned st_wx = (unsigned)(wx_row * ROW + (wx_run >> 1) * K16B + (wx_run & 1) * 16);
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
+        if constexpr (WX) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                unsigned pc[NP][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // values past the row's ends are whatever lies there in memory: the padding's zeros instead
+                    const float x0 = ((ld_mask >> (2 * e)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e]) : 0.f;
+                    const float x1 = ((ld_mask >> (2 * e + 1)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e + 1]) : 0.f;
+                    if constexpr (AR == 0)
+                        split3(x0, x1, pc[0][e], pc[1][e], pc[2][e]);
+                    else
+                        split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
+                }
+                unsigned char* d = Bs + st_wx + j * 64 * ROW;
+#pragma unroll
+                for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(d + c * 32) = u32x4{pc[c][0], pc[c][1], pc[c][2], pc[c][3]};
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < B_PER / 2; ++i) {
             const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];
@@ -831,7 +928,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
         c0 = c1;
     }
 
-    float* slab = p.slab + (long long)(p.slab0 + blockIdx.z) * p.Cout * p.N;
+    float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + wn * 64 + j * 32 + l31;

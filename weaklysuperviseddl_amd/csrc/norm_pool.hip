@@ -100,20 +100,20 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
-// y = act((x-mean)*invstd*gamma + beta + res); one block row per (b,c) plane.  The channel statistics are finished
-// here from the partial sums (a handful of doubles per plane, block-uniform) instead of by a separate 5-us launch;
-// the block that owns (b = 0, first column chunk) of a channel publishes save_mean / save_invstd and updates the
-// running statistics.
+// y = act((x-mean)*invstd*gamma + beta + res).  grid = (W, C): workgroup (w, c) owns the w-th of W equal runs of channel
+// c's B*HW values (in (b, hw) order) - a few thousand values per workgroup, so that the prologue (the channel statistics
+// finished from the partial sums: a dependent chain of loads and double arithmetic) is paid once per 8-16 float4 of a
+// thread and not once per float4 (the former one-plane-slice-per-workgroup grid: 1.9 TB/s on the layer1 tensors).
+// Workgroup (0, c) publishes save_mean / save_invstd and updates the running statistics.
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const double* __restrict__ part,
                                 float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                 long long n, int nsplit, const float* __restrict__ res,
-                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int planes,
+                                float* __restrict__ y, int C, int HW, long long y_bs, int relu, int B,
                                 float* __restrict__ amax) {
-  float vmax = 0.f;
-  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
-    const int b = plane / C, c = plane - b * C;
+    float vmax = 0.f;
+    const int c = blockIdx.y;
     double s0 = 0.0, s1 = 0.0;
     for (int s = 0; s < nsplit; ++s) {
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
@@ -123,7 +123,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     double var = s1 / (double)n - mean_d * mean_d;
     if (var < 0.0) var = 0.0;
     const float mu = (float)mean_d, istd = (float)(1.0 / sqrt(var + (double)eps));
-    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         save_mean[c] = mu;
         save_invstd[c] = istd;
         if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
@@ -133,33 +133,39 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
         }
     }
     const float g = istd * gamma[c], be = beta[c];
-    const float* xp = x + (long long)plane * HW;
-    const float* rp = res ? res + (long long)plane * HW : nullptr;
-    float* yp = y + (long long)b * y_bs + (long long)c * HW;
     if ((HW & 3) == 0 && (y_bs & 3) == 0) {
-        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
-            float4 v = *reinterpret_cast<const float4*>(xp + i);
+        const int HW4 = HW >> 2, n4 = B * HW4;
+        const int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lo = blockIdx.x * per, hi = min(lo + per, n4);
+        for (int i4 = lo + threadIdx.x; i4 < hi; i4 += blockDim.x) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const long long src = ((long long)b * C + c) * HW + r;
+            float4 v = *reinterpret_cast<const float4*>(x + src);
             v.x = fmaf(v.x - mu, g, be); v.y = fmaf(v.y - mu, g, be);      // pinned: the backward recomputes the ReLU mask
             v.z = fmaf(v.z - mu, g, be); v.w = fmaf(v.w - mu, g, be);
-            if (rp) {
-                const float4 r = *reinterpret_cast<const float4*>(rp + i);
-                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            if (res) {
+                const float4 q = *reinterpret_cast<const float4*>(res + src);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
             }
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(yp + i) = v;
+            *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = v;
             vmax = amax4(vmax, v);
         }
     } else {
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-            float v = fmaf(xp[i] - mu, g, be);
-            if (rp) v += rp[i];
+        const int nn = B * HW;
+        const int per = (nn + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lo = blockIdx.x * per, hi = min(lo + per, nn);
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const int b = i / HW, r = i - b * HW;
+            const long long src = ((long long)b * C + c) * HW + r;
+            float v = fmaf(x[src] - mu, g, be);
+            if (res) v += res[src];
             if (relu) v = fmaxf(v, 0.f);
-            yp[i] = v;
+            y[(long long)b * y_bs + (long long)c * HW + r] = v;
             vmax = fmaxf(vmax, fabsf(v));
         }
     }
-  }
-  if (amax) publish_amax(vmax, amax);
+    if (amax) publish_amax(vmax, amax);
 }
 
 // dx = gamma*invstd*(dy' - k0 - xhat*k1) ; dres = dy'
@@ -170,10 +176,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ dbeta, int accumulate, long long n, int nsplit,
                                     float* __restrict__ dx,
                                     float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
-                                    int relu, int planes, float* __restrict__ amax, const float* __restrict__ beta) {
-  float vmax = 0.f;
-  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
-    const int b = plane / C, c = plane - b * C;
+                                    int relu, int B, float* __restrict__ amax, const float* __restrict__ beta) {
+    // grid = (W, C), as bn_apply_kernel: one prologue per run of a few thousand values of channel c
+    float vmax = 0.f;
+    const int c = blockIdx.y;
     // finish the channel's two sums (sum dy', sum dy'*xhat) from the partials; one block publishes the parameter
     // gradients (same arithmetic as the former finalize kernel: fixed order, double)
     double s0 = 0.0, s1 = 0.0;
@@ -181,24 +187,24 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
         s0 += part[((long long)c * kStatSplit + s) * 2 + 0];
         s1 += part[((long long)c * kStatSplit + s) * 2 + 1];
     }
-    if (b == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s1 : (float)s1;
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s0 : (float)s0;
     }
     const float k0 = (float)(s0 / (double)n), k1 = (float)(s1 / (double)n);
     const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
     const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
-    const float* xp = x + (long long)plane * HW;
-    const float* gp = dy + (long long)b * dy_bs + (long long)c * HW;
-    const float* yp = relu == 1 ? y + (long long)b * y_bs + (long long)c * HW : nullptr;
-    float* dxp = dx + (long long)plane * HW;
-    float* drp = dres ? dres + (long long)plane * HW : nullptr;
     if ((HW & 3) == 0 && ((dy_bs | y_bs) & 3) == 0) {
-        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += gridDim.x * blockDim.x * 4) {
-            float4 g = *reinterpret_cast<const float4*>(gp + i);
-            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
-            if (yp) {
-                const float4 yv = *reinterpret_cast<const float4*>(yp + i);
+        const int HW4 = HW >> 2, n4 = B * HW4;
+        const int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lo = blockIdx.x * per, hi = min(lo + per, n4);
+        for (int i4 = lo + threadIdx.x; i4 < hi; i4 += blockDim.x) {
+            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const long long src = ((long long)b * C + c) * HW + r;
+            float4 g = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
+            const float4 xv = *reinterpret_cast<const float4*>(x + src);
+            if (relu == 1) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
                 if (!(yv.x > 0.f)) g.x = 0.f;
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
@@ -214,23 +220,28 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
             o.y = gi * (g.y - k0 - (xv.y - mu) * is * k1);
             o.z = gi * (g.z - k0 - (xv.z - mu) * is * k1);
             o.w = gi * (g.w - k0 - (xv.w - mu) * is * k1);
-            *reinterpret_cast<float4*>(dxp + i) = o;
+            *reinterpret_cast<float4*>(dx + src) = o;
             vmax = amax4(vmax, o);
-            if (drp) *reinterpret_cast<float4*>(drp + i) = g;
+            if (dres) *reinterpret_cast<float4*>(dres + src) = g;
         }
-    } else
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
-        float g = gp[i];
-        if (yp && !(yp[i] > 0.f)) g = 0.f;
-        if (relu == 2 && !(fmaf(xp[i] - mu, mg, mb) > 0.f)) g = 0.f;
-        const float xh = (xp[i] - mu) * is;
-        const float o = gi * (g - k0 - xh * k1);
-        dxp[i] = o;
-        vmax = fmaxf(vmax, fabsf(o));
-        if (drp) drp[i] = g;
+    } else {
+        const int nn = B * HW;
+        const int per = (nn + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int lo = blockIdx.x * per, hi = min(lo + per, nn);
+        for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const int b = i / HW, r = i - b * HW;
+            const long long src = ((long long)b * C + c) * HW + r;
+            float g = dy[(long long)b * dy_bs + (long long)c * HW + r];
+            if (relu == 1 && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
+            if (relu == 2 && !(fmaf(x[src] - mu, mg, mb) > 0.f)) g = 0.f;
+            const float xh = (x[src] - mu) * is;
+            const float o = gi * (g - k0 - xh * k1);
+            dx[src] = o;
+            vmax = fmaxf(vmax, fabsf(o));
+            if (dres) dres[src] = g;
+        }
     }
-  }
-  if (amax) publish_amax(vmax, amax);
+    if (amax) publish_amax(vmax, amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,6 +581,14 @@ inline dim3 plane_grid(int planes, int HW, int per_thread = 1) {
     if (gx < 1) gx = 1;
     return dim3(gx, planes > 65535 ? 65535 : planes);
 }
+// grid (W, C) of the two-pass BatchNorm apply kernels: about 2048 workgroups, at least 1024 float4 per workgroup
+inline dim3 channel_grid(int B, int C, int HW) {
+    const long long n4 = (long long)B * HW / 4;
+    long long w = (2048 + C - 1) / C;
+    if (w > n4 / 1024) w = n4 / 1024;
+    if (w < 1) w = 1;
+    return dim3((unsigned)w, (unsigned)C);
+}
 inline int flat_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); }
 
 }  // namespace
@@ -585,7 +604,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
                       float* y_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
-    WSDL_REQUIRE(B > 0 && C > 0 && HW > 0 , "bn_train_fwd: bad shape");
+    WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_fwd: bad shape");
     WSDL_REQUIRE((long long)B * HW > 1, "bn_train_fwd: needs more than one value per channel (as torch)");
     if (ws_bytes < wsdl_bn_workspace(C)) {
         wsdl::set_error("bn_train_fwd: workspace too small");
@@ -609,9 +628,9 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
                        nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns, nullptr, nullptr);
-    hipLaunchKernelGGL(bn_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, gamma, beta, part, save_mean,
+    hipLaunchKernelGGL(bn_apply_kernel, channel_grid(B, C, HW), dim3(256), 0, s, x, gamma, beta, part, save_mean,
                        save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, ns, residual, y, C,
-                       HW, y_bs, relu, B * C, y_amax);
+                       HW, y_bs, relu, B, y_amax);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -625,7 +644,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     WSDL_REQUIRE(relu != 1 || y, "bn_train_bwd: relu = 1 takes the mask from the forward output y");
     WSDL_REQUIRE(relu != 2 || beta, "bn_train_bwd: relu = 2 recomputes the mask from x and needs beta");
     WSDL_REQUIRE(relu >= 0 && relu <= 2, "bn_train_bwd: relu must be 0, 1 or 2");
-    WSDL_REQUIRE(B > 0 && C > 0 && HW > 0, "bn_train_bwd: bad shape");
+    WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_bwd: bad shape");
     if (ws_bytes < wsdl_bn_workspace(C)) {
         wsdl::set_error("bn_train_bwd: workspace too small");
         return WSDL_EWORKSPACE;
@@ -649,9 +668,9 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
                        part, B, C, HW, dy_bs, y_bs, relu, 1, ns, gamma, beta);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, plane_grid(B * C, HW, 4), dim3(256), 0, s, x, dy, y, gamma, save_mean,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, channel_grid(B, C, HW), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, part, dgamma, dbeta, accumulate_param_grads, (long long)B * HW, ns, dx, dres, C, HW,
-                       dy_bs, y_bs, relu, B * C, dx_amax, beta);
+                       dy_bs, y_bs, relu, B, dx_amax, beta);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
