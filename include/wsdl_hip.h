@@ -59,7 +59,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      -1.4 % on the kernel sweep, nothing on the step
  *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms);
  *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)
- *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers
+ *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
+ *                      192 channels, n > 1 = from n channels; measured: resident wins at every channel count)
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
  *   occupancy_cap  0*  pad the conv kernels' LDS request so that a CU holds at most ceil(blocks/256) workgroups

@@ -8,6 +8,13 @@
 int wsdl::g_bn_resident = 1;
 
 namespace {
+// i / d for the (b, hw) decompositions of the BatchNorm kernels: the plane sizes of the networks are powers of two, and
+// a division by a runtime divisor costs ~30 VALU instructions per element
+__device__ __forceinline__ int fast_div(int i, int d, int shift) { return shift >= 0 ? i >> shift : i / d; }
+__device__ __forceinline__ int pow2_shift(int d) { return (d & (d - 1)) == 0 ? __ffs(d) - 1 : -1; }
+}  // namespace
+
+namespace {
 
 constexpr int kStatSplit = 32;  // max partial sums per channel (workspace stride); the count used is a fixed
                                 // function of (C, HW), so results stay bitwise reproducible
@@ -134,11 +141,11 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
     const float g = istd * gamma[c], be = beta[c];
     if ((HW & 3) == 0 && (y_bs & 3) == 0) {
-        const int HW4 = HW >> 2, n4 = B * HW4;
+        const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
         const int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lo = blockIdx.x * per, hi = min(lo + per, n4);
         for (int i4 = lo + threadIdx.x; i4 < hi; i4 += blockDim.x) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long src = ((long long)b * C + c) * HW + r;
             float4 v = *reinterpret_cast<const float4*>(x + src);
             v.x = fmaf(v.x - mu, g, be); v.y = fmaf(v.y - mu, g, be);      // pinned: the backward recomputes the ReLU mask
@@ -195,11 +202,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     const float mu = mean[c], is = invstd[c], gi = gamma[c] * is;
     const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
     if ((HW & 3) == 0 && ((dy_bs | y_bs) & 3) == 0) {
-        const int HW4 = HW >> 2, n4 = B * HW4;
+        const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
         const int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
         const int lo = blockIdx.x * per, hi = min(lo + per, n4);
         for (int i4 = lo + threadIdx.x; i4 < hi; i4 += blockDim.x) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long src = ((long long)b * C + c) * HW + r;
             float4 g = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
             const float4 xv = *reinterpret_cast<const float4*>(x + src);
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int HW4 = HW >> 2, n4 = B * HW4;
+    const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
     float4 v[V];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
         const int i4 = tid + k * NT;
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i4 < n4) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             v[k] = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
             a0 += (double)((v[k].x + v[k].y) + (v[k].z + v[k].w));
             a1 += (double)v[k].x * v[k].x + (double)v[k].y * v[k].y + (double)v[k].z * v[k].z + (double)v[k].w * v[k].w;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
         if (i4 < n4) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             float4 o = v[k];
             o.x = fmaf(o.x - mu, g, be); o.y = fmaf(o.y - mu, g, be);
             o.z = fmaf(o.z - mu, g, be); o.w = fmaf(o.w - mu, g, be);
@@ -326,7 +333,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const int HW4 = HW >> 2, n4 = B * HW4;
+    const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
     const float mu = mean[c], is = invstd[c];
     const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
     float4 g[V], xh[V];                            // dy' = dy*[y>0] and xhat, kept for the second phase
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
         g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         xh[k] = g[k];
         if (i4 < n4) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
             float4 gv = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
             if (relu == 2) {
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
         if (i4 < n4) {
-            const int b = i4 / HW4, r = (i4 - b * HW4) << 2;
+            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long o = ((long long)b * C + c) * HW + r;
             float4 d;
             d.x = gi * (g[k].x - k0 - xh[k].x * k1);
@@ -391,7 +398,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
 static int resident_threads(int C, long long n, int HW) {
-    if (!wsdl::g_bn_resident || C < 192 || (HW & 3) != 0) return 0;
+    // g_bn_resident: 0 off, 1 = from 192 channels (fewer workgroups than that leave most CUs idle), n > 1 = from n channels
+    const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 192;
+    if (!wsdl::g_bn_resident || C < min_c || (HW & 3) != 0) return 0;
     if (n <= 256 * 64) return 256;
     if (n <= 512 * 64) return 512;
     return 0;
