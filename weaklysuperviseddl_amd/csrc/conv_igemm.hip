@@ -954,6 +954,35 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
+// The same reduction for MANY slabs of a small matrix (the 7x7 stem: 64 x 147 values in 256 pixel slabs): four waves
+// share 64 consecutive outputs, wave w adds slabs w, w + 4, ... and the four partial sums are combined in wave order -
+// a fixed order again, a quarter of the dependent chain and four times the loads in flight (62 -> 20 us).
+__global__ void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                         int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+    __shared__ float part[4][64];
+    const long long total = (long long)Cout * Cin * T;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long long idx = (long long)blockIdx.x * 64 + l;
+    const int N = Cin * T;
+    int co = 0, tap = 0, ci = 0;
+    float s = 0.f;
+    if (idx < total) {
+        co = (int)(idx / N);
+        const int n = (int)(idx - (long long)co * N);
+        tap = n / Cin;
+        ci = n - tap * Cin;
+        if (tap >= 64 || ((live >> tap) & 1ull))
+            for (int z = w; z < S; z += 4) s += slab[(long long)z * total + idx];
+    }
+    part[w][l] = s;
+    __syncthreads();
+    if (w == 0 && idx < total) {
+        const float r = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+        const long long o = ((long long)co * Cin + ci) * T + tap;
+        dw[o] = accumulate ? dw[o] + r : r;
+    }
+}
+
 // T == 1 (1x1 kernels: slab layout == dw layout): 16 bytes per thread, four slabs in flight per step.  The sum
 // order is fixed (pairs of pairs), so the result stays bitwise reproducible.
 __global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int S,
@@ -1898,6 +1927,9 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         const long long total4 = total / 4;
         hipLaunchKernelGGL(wgrad_reduce_vec4_kernel, dim3((int)std::min<long long>((total4 + 255) / 256, 8192)), dim3(256), 0, s,
                            reinterpret_cast<const float4*>(p.slab), reinterpret_cast<float4*>(dw), S_total, total4, accumulate);
+    } else if (S_total >= 16 && total <= (1ll << 24)) {
+        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, p.slab, dw, S_total,
+                           Cout, Cin, T, accumulate, live_mask);
     } else {
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate,
