@@ -4,7 +4,8 @@
 One "step" = one pass of the hot path over one synthetic batch: DeepLabV3-ResNet50 forward (aux head
 included, as the reference computes it), 2-class cross-entropy, backward, Adam - fp32, inputs resident
 in HBM before the timed region.  N > 1: one process per GPU, the batch of 16 is PER GPU (weak scaling),
-gradients all-reduced over RCCL in 4 buckets overlapped with backward.
+gradients all-reduced over RCCL in buckets that grow from the first layers (1 MB) to the last (48 MB), overlapped with
+backward; each bucket's Adam launch and weight re-layout follow its collective on the side stream.
 
 Launching: ``python bench.py --gpus N`` from a bare shell starts its own N ranks (child processes, before
 this process touches the GPU) and prints rank 0's JSON line; under ``torchrun`` (WORLD_SIZE set) it is one

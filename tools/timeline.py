@@ -36,3 +36,14 @@ for k in range(max(1, len(adam) - 3), len(adam)):
     for r in seg:
         queues[r[3]] = queues.get(r[3], 0) + (r[1] - r[0])
     print("   kernel time per queue (ms):", {q: round(v / 1e6, 2) for q, v in queues.items()})
+
+if "--tail" in sys.argv:
+    # the last kernels of a step (what Adam waits for) and the first ones of the next: queue, start (us before / after the
+    # adam launch), duration
+    n = int(sys.argv[sys.argv.index("--tail") + 1])
+    k = len(adam) - 2
+    a = adam[k]
+    t_adam = rows[a][0]
+    for r in rows[max(0, a - n): a + n]:
+        nm = r[2].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:58]
+        print(f"  q{r[3]:>2} {(r[0] - t_adam) / 1e3:9.1f} us  {(r[1] - r[0]) / 1e3:7.1f} us  {nm}")

@@ -19,6 +19,8 @@ AlternatingDirectionCutLoss.py:693-703): clamp masks to {0,1}, forward, CrossEnt
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -173,12 +175,30 @@ def train_step(model, optimizer, images, masks, extra_loss=None):
     return loss.detach()
 
 
-def make_optimizer(model, lr=1e-4):
-    """torch.optim.Adam(model.parameters(), lr) semantics on one flat buffer / one kernel launch."""
-    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=lr)
+def make_optimizer(model, lr=1e-4, early_step=None):
+    """torch.optim.Adam(model.parameters(), lr) semantics on one flat buffer.  Single process: one Adam launch per step,
+    then the re-layout of every convolution weight on the side stream.  Under ``dp.GradBucketReducer`` the buffer is
+    stepped in segments (optim.FlatAdam.enable_early_step): each segment's Adam launch and the re-layout of its
+    convolution weights follow its gradient all-reduce.  ``early_step=True`` (or WSDL_EARLY_STEP=1) uses the segments
+    in a single process too."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FlatAdam(params, lr=lr)
     convs = [m for m in model.modules() if isinstance(m, wnn.Conv2d) and m.weight.requires_grad and m.weight.is_cuda]
     if convs:
-        opt.post_step_hook = lambda: ops.prefetch_weight_layouts(convs)
+        index = {id(p): i for i, p in enumerate(params)}
+        by_param = {index[id(m.weight)]: m for m in convs}
+
+        def relayout(_k, param_indices, use_events):
+            seg_convs = [by_param[i] for i in param_indices if i in by_param]
+            # runs before step() bumps the parameter epoch; in eager mode into the spare buffers (this step's remaining
+            # input-gradient kernels still read the current ones), inside a captured graph in place
+            ops.prefetch_weight_layouts(seg_convs, use_events=use_events, epoch_ahead=1, pingpong=use_events)
+
+        opt.post_step_hook = lambda: ops.prefetch_weight_layouts(convs)     # after the single-launch step
+        opt.enable_early_step(relayout)
+        if early_step is None:
+            early_step = os.environ.get("WSDL_EARLY_STEP", "0") == "1"
+        opt.early_step = bool(early_step)
     return opt
 
 

@@ -44,7 +44,11 @@ class GraphedTrainStep:
         self.s_images, self.s_masks = images.clone(), masks.clone()
         opt = self.opt
         saved_hook = opt.post_step_hook
-        # weight layouts: end-of-step re-layout without events (the captured step joins the side stream)
+        # weight layouts: end-of-step re-layout in place and without events (the captured step joins the side stream;
+        # a replay must find the layouts at the addresses the captured forward reads)
+        segmented = getattr(opt, "segments", None) is not None
+        if segmented:
+            opt.capture_mode = True
         opt.post_step_hook = lambda: ops.prefetch_weight_layouts(self._convs, use_events=False)
         torch.cuda.synchronize(dev)
         for m in self._convs:                   # no waits on events recorded outside the capture
@@ -58,6 +62,8 @@ class GraphedTrainStep:
                 ops.join_side_stream(dev)
         finally:
             opt.post_step_hook = saved_hook
+            if segmented:
+                opt.capture_mode = False
             ops.reset_amax_pool(dev)            # eager code must not hand out the graph's slots
         # capturing executed the Python side of one step but no kernel: undo its host bookkeeping (replay redoes it)
         opt.step_count = count0

@@ -88,10 +88,13 @@ def _cached_prep(cache, weight, need_dx):
 LAYOUT_EPOCH = [0]     # bumped by options that change what a layout buffer holds / how large it is
 
 
-def prefetch_weight_layouts(convs, use_events=True):
-    """Lay out next step's weights on the side stream (called right after the optimiser step): the ~0.6 ms of
+def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=False):
+    """Lay out next step's weights on the side stream (called right after the optimiser step of these weights): the
     re-layout kernels leave the forward chain; each conv waits on its own event (``use_events=False``: the main stream
-    joins the side stream instead - inside a captured graph)."""
+    joins the side stream instead - inside a captured graph).
+    ``epoch_ahead``: the caller will bump the parameter epoch this many times before the layouts are used (early
+    segment steps run before ``FlatAdam.step`` does).  ``pingpong``: write into the conv's spare pair of buffers and swap -
+    input-gradient kernels of the CURRENT step that are still to be enqueued keep reading the pair they were given."""
     if not convs:
         return
     dev = convs[0].weight.device
@@ -101,13 +104,18 @@ def prefetch_weight_layouts(convs, use_events=True):
         amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
         for i, m in enumerate(convs):
             cache = m.__dict__.setdefault("_wsdl_cache", {})
-            old = cache.get("prep") if cache.get("prep_layout") == LAYOUT_EPOCH[0] else None
-            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=old)
+            fresh = cache.get("prep_layout") == LAYOUT_EPOCH[0]
+            old = cache.get("prep") if fresh else None
+            target = (cache.get("prep_spare") if fresh else None) if pingpong else old
+            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=target)
             ev = None
             if use_events:
                 ev = torch.cuda.Event()
                 ev.record(side)
-            cache["prep_key"], cache["prep"], cache["prep_event"] = _weight_key(m.weight), (wf, wd), ev
+            w = m.weight
+            cache["prep_key"] = (PARAM_EPOCH[0] + epoch_ahead, w._version, w.data_ptr())
+            cache["prep"], cache["prep_event"] = (wf, wd), ev
+            cache["prep_spare"] = old if pingpong else None
             cache["prep_layout"] = LAYOUT_EPOCH[0]
     if not use_events:
         main.wait_stream(side)          # graph capture: no cross-replay events - the step ends with the layouts complete

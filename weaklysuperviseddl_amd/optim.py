@@ -4,7 +4,20 @@ reference TraditionalModel/SegmentationModel.py:91) as ONE kernel launch over fl
 Parameters are re-homed into one contiguous fp32 buffer (``p.data`` become views) and so are their
 gradients (``p.grad`` views of one flat buffer), which is also what the data-parallel gradient
 all-reduce buckets (``dp.GradBucketReducer``) operate on: 39.6 M parameters = 158.5 MB per replica.
+
+Segment steps (``enable_early_step``; used under data parallelism, opt-in for a single process - measured 0.4 %
+slower there: six Adam launches instead of one, nothing left to hide).  The update is element-wise, so the flat buffer
+can be stepped in pieces.
+Backward fills it from the last layer to the first; the buffer is cut (on parameter boundaries) into segments that grow
+geometrically from the FIRST layers - 1 MB, 5 MB, 25 MB, then at most 48 MB each - and a segment's Adam launch, the
+amax of its convolution weights and their re-layout for the next step are enqueued on the side stream as soon as
+its last expected gradient has been announced, behind the weight-gradient kernels that produce it.  What is left when
+``step()`` is called is the small first segment: the stem and layer1.  Which parameters are "expected" is learnt from the previous step (the aux head of the
+segmentation model never receives a gradient); a gradient that turns up for a parameter whose segment has already been
+stepped raises.  The same segments are the data-parallel reducer's buckets: the all-reduce exposed at the end of
+backward is the 1 MB one.
 """
+import contextlib
 import torch
 
 from . import ops
@@ -36,6 +49,7 @@ class FlatAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+        self.segments = None           # early segment steps: [(lo, hi)] on parameter boundaries, None = one launch in step()
         self.pre_step_hook = None      # e.g. wait for the gradient all-reduce
         self.post_step_hook = None     # e.g. prefetch next step's weight layouts on the side stream
         # direct gradient delivery: the HIP backward kernels write each parameter's gradient straight into
@@ -44,6 +58,114 @@ class FlatAdam:
         self.grad_ready_hooks = []     # callables(param): fired when a parameter's gradient has been written
         for p in self.params:
             p._wsdl_grad_sink = self
+
+    # ---------------------------------------------------------------------------------- early segment steps
+    def enable_early_step(self, segment_hook=None, first=1 << 18, growth=5, cap=12_000_000):
+        """Cut the flat buffer into segments and step each as soon as its gradients are complete (module docstring).
+        ``segment_hook(k, param_indices, use_events)`` runs right after segment k's Adam launch (side stream already
+        behind it): the place to re-lay-out that segment's convolution weights."""
+        if not self.flat_param.is_cuda:
+            return self
+        bounds, target = [0], first
+        for off in self.offsets[1:]:
+            if off - bounds[-1] >= target:
+                bounds.append(off)
+                target = min(target * growth, cap)
+        if len(bounds) > 1 and self.numel - bounds[-1] < first:
+            bounds.pop()                               # no crumb at the end
+        bounds.append(self.numel)
+        self.segments = [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1)]
+        self.seg_of = []
+        for off in self.offsets:
+            self.seg_of.append(max(k for k, (lo, _hi) in enumerate(self.segments) if lo <= off))
+        self.seg_params = [[i for i, k in enumerate(self.seg_of) if k == kk] for kk in range(len(self.segments))]
+        self.segment_hook = segment_hook
+        self.early_step = False         # True: step segments as backward completes them (False: one launch in step(),
+                                        # unless a data-parallel reducer drives the segments - external_trigger)
+        self.external_trigger = False   # True: someone else (the DP reducer) decides when a segment is complete
+        self.capture_mode = False       # inside hipGraph capture: no cross-replay events
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._expected = None           # parameter indices that fired in the previous step
+        self._fired = set()
+        self._stepped = [False] * len(self.segments)
+        self._remaining = None
+        self._accumulating = False
+        self._adam_event = None
+        for i, p in enumerate(self.params):
+            p.register_post_accumulate_grad_hook(lambda q, i=i: self._announce(i))
+        self.grad_ready_hooks.append(lambda p: self._announce(self._index[id(p)]))
+        return self
+
+    @contextlib.contextmanager
+    def accumulate(self):
+        """Backward passes inside the context only accumulate gradients (no early segment step)."""
+        self._accumulating = True
+        try:
+            yield
+        finally:
+            self._accumulating = False
+
+    def _announce(self, i):
+        if i in self._fired:
+            return
+        self._fired.add(i)
+        k = self.seg_of[i]
+        if self._stepped[k]:
+            raise RuntimeError(
+                f"FlatAdam: a gradient for parameter {i} {tuple(self.params[i].shape)} arrived after its segment had been "
+                "stepped (a parameter that received no gradient in the previous step, or a second backward before "
+                "step()).  Wrap extra backward passes in optimizer.accumulate() or set optimizer.early_step = False.")
+        if self.external_trigger or not self.early_step or self.capture_mode or self._accumulating or self._expected is None:
+            return
+        if i in self._expected:
+            self._remaining[k] -= 1
+        # segments leave in backward order, a segment only once every later one has left
+        for kk in range(len(self.segments) - 1, -1, -1):
+            if self._stepped[kk]:
+                continue
+            if self._remaining[kk] > 0:
+                break
+            self.step_segment(kk)
+
+    def step_segment(self, k, after=None):
+        """Adam on segment k, enqueued on the side stream behind the main stream's work so far (BatchNorm / bias
+        gradients, the input-gradient kernels that still read this segment's weight layouts) and behind ``after``
+        (a collective's work handle)."""
+        dev = self.flat_param.device
+        lo, hi = self.segments[k]
+        main, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if after is not None:
+                after.wait()
+            if not any(self._stepped):
+                self.step_count += 1
+                self.step_dev.add_(1)
+            ops.adam_step_flat(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                               self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
+                               step_dev=self.step_dev)
+            if not self.capture_mode:
+                self._adam_event = torch.cuda.Event()
+                self._adam_event.record(side)
+        self._stepped[k] = True
+        if self.segment_hook is not None:
+            self.segment_hook(k, self.seg_params[k], not self.capture_mode)
+
+    def _finish_segments(self):
+        dev = self.flat_param.device
+        for k in range(len(self.segments) - 1, -1, -1):
+            if not self._stepped[k]:
+                self.step_segment(k)
+        main = torch.cuda.current_stream(dev)
+        if self.capture_mode or self._adam_event is None:
+            main.wait_stream(ops.side_stream(dev))
+        else:
+            main.wait_event(self._adam_event)        # the parameters, not the re-layouts behind them on the side stream
+        self._expected = set(self._fired)
+        self._fired = set()
+        self._stepped = [False] * len(self.segments)
+        self._remaining = [sum(1 for i in idx if i in self._expected) for idx in self.seg_params]
+        self._backward_pending = False
 
     def take_fresh(self, p):
         f = self._fresh.get(id(p), False)
@@ -55,7 +177,7 @@ class FlatAdam:
             h(p)
 
     def zero_grad(self, set_to_none=False):
-        if self.flat_grad.is_cuda:
+        if self.flat_grad.is_cuda and (self.segments is None or self._fired):
             ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
         self.flat_grad.zero_()
         for k in self._fresh:
@@ -67,6 +189,12 @@ class FlatAdam:
     def step(self):
         if self.pre_step_hook is not None:
             self.pre_step_hook()
+        if self.segments is not None:
+            if self.external_trigger or self.early_step or any(self._stepped):
+                self._finish_segments()         # (the segment hook has re-laid-out the weights)
+                ops.bump_param_epoch()
+                return
+            self._fired = set()                 # one launch over the whole buffer, below
         if self.flat_param.is_cuda:
             ops.join_side_stream(self.flat_param.device)     # weight gradients are produced on the side stream
         self.step_count += 1
