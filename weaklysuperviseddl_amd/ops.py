@@ -4,6 +4,8 @@ buffers and orders calls on the current stream.  No CPU fallback: non-device ten
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from ._lib import lib, check, WsdlError
@@ -85,6 +87,7 @@ def _cached_prep(cache, weight, need_dx):
     return wf, wd
 
 
+_PREFETCH_HEAD = int(os.environ.get("WSDL_PREFETCH_HEAD", "12"))    # convolutions of the first re-layout batch after an optimiser step (stem + layer1)
 LAYOUT_EPOCH = [0]     # bumped by options that change what a layout buffer holds / how large it is
 
 
@@ -99,6 +102,12 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
         return
     dev = convs[0].weight.device
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    if _PREFETCH_HEAD > 0 and len(convs) > 2 * _PREFETCH_HEAD:
+        # the forward that follows waits for its FIRST layers' layouts: give those their own (small) amax launch instead of
+        # queueing them behind the amax pass over all 158 MB of weights (105 us before the next step could start)
+        prefetch_weight_layouts(convs[:_PREFETCH_HEAD], use_events, epoch_ahead, pingpong)
+        prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong)
+        return
     side.wait_stream(main)
     with torch.cuda.stream(side):
         amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
