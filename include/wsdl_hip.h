@@ -55,6 +55,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
  *   wgrad_wide     0*  split weight-gradient kernel: a lane stages 8-pixel runs of two x rows (16-byte loads / LDS stores)
  *                      instead of one pixel of sixteen rows (stride 1, OW % 8 == 0); bit-identical
+ *   wgrad_mfma16   1*  fp16x2 weight-gradient kernel on v_mfma_f32_16x16x32_f16 (swizzled 128-byte LDS rows): -6 % on the
+ *                      kernel sweep, +2 % img/s against the 32x32x16 form (0); same accuracy against float64
+ *   conv_mfma16    0*  the same MFMA shape in the forward / input-gradient kernels (K chunk 32): -2..-3.6 % on the layer4
+ *                      shapes, +1.6 % on layer3 3x3 and ASPP d12, -0.5 % on the sweep: off
  *   wgrad_xcd      0*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, nothing on the step
  *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms);

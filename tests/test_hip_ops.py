@@ -98,8 +98,12 @@ def test_conv_fwd_dgrad_wgrad(dev, case, arithmetic):
     assert_close(dw2, 2 * wr.grad, what="wgrad accumulate")
 
 
-MODES = {"fp32": dict(conv_split=0, wgrad_split=0, conv_arith=1), "bf16x3": dict(conv_split=1, wgrad_split=1, conv_arith=0),
-         "fp16x2": dict(conv_split=1, wgrad_split=1, conv_arith=1)}
+MODES = {"fp32": dict(conv_split=0, wgrad_split=0, conv_arith=1, conv_mfma16=0, wgrad_mfma16=1),
+         "bf16x3": dict(conv_split=1, wgrad_split=1, conv_arith=0, conv_mfma16=0, wgrad_mfma16=1),
+         # the two MFMA shapes of the fp16x2 kernels: 32x32x16 everywhere / 16x16x32 everywhere
+         "fp16x2-32": dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=0, wgrad_mfma16=0),
+         "fp16x2-16": dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=1, wgrad_mfma16=1),
+         "fp16x2": dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=0, wgrad_mfma16=1)}     # the default
 
 
 @pytest.mark.parametrize("data", ["unit", "wide"])

@@ -17,6 +17,7 @@
 // dgrad = (1, -dil, +pad, stride) over dY with the [tap][cout][cin] weight layout.
 #include "common.h"
 
+#include <type_traits>
 #include <algorithm>
 #include <cstdint>
 #include <mutex>
@@ -1239,6 +1240,7 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
+int g_conv_mfma16 = 0;    // fp16x2 forward / input-gradient kernels with K chunk 32 on v_mfma_f32_16x16x32_f16
 int g_conv_glds = 0;      // weights of the fp16x2 kernels by LDS-DMA: bit 0 the 256x128 form, bit 1 the 4-wave forms
 int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
@@ -1265,6 +1267,13 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     if (g_conv_arith) {
+        if constexpr (BK == 32) {
+            if (g_conv_mfma16) {
+                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, false, true>), grid, dim3(kThreads), 0, s, p);
+                WSDL_LAUNCH_CHECK();
+                return WSDL_OK;
+            }
+        }
         if (g_conv_glds & 2) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
     } else
@@ -1282,7 +1291,8 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     const bool bk32 = g_t256_bk32 && p.Cin % 32 == 0;
     if (g_conv_arith) {
-        if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
+        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, false, true>), grid, dim3(512), 0, s, p);
+        else if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
         else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
     } else {
@@ -1491,6 +1501,7 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
+int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
 int g_wgrad_xcd = 0;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
 int g_wgrad_wide = 0;        // 8-pixel runs per lane in the x staging of the split weight-gradient kernel (stride 1, OW % 8 == 0)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
@@ -1603,12 +1614,14 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "t256_bk32")) { g_t256_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "conv_glds")) { g_conv_glds = value; return WSDL_OK; }
+    if (!strcmp(name, "conv_mfma16")) { g_conv_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_wide")) { g_wgrad_wide = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_mfma16")) { g_wgrad_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1875,14 +1888,26 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
-                    hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
-                    WSDL_LAUNCH_CHECK();
-                    if (g_wgrad_wide && stride == 1 && OW % 8 == 0)
-                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1, true>), grid, dim3(kThreads), 0, s, p, dys,
-                                           (unsigned)dys_bytes, dy_amax);
-                    else
-                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
-                                           (unsigned)dys_bytes, dy_amax);
+                    const bool wide = g_wgrad_wide && stride == 1 && OW % 8 == 0;
+                    if (g_wgrad_mfma16) {
+                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                        WSDL_LAUNCH_CHECK();
+                        if (wide)
+                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else
+                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<false>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                    } else {
+                        hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                        WSDL_LAUNCH_CHECK();
+                        if (wide)
+                            hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else
+                            hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                    }
                 } else {
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,
                                        static_cast<const float*>(nullptr));
