@@ -203,6 +203,38 @@ def test_scheduling_options_reproduce_the_default_bit_for_bit(dev, opt, val):
         ops.set_option(opt, default)
 
 
+@pytest.mark.parametrize("opts", [dict(conv_mfma16=1), dict(wgrad_mfma16=0), dict(wgrad_tile64=1, wgrad_min_tiles=1),
+                                  dict(wgrad_min_tiles=1)])
+def test_other_mfma_shapes_and_tiles_agree_with_the_default(dev, opts):
+    """Options that change the MFMA shape (16x16x32 <-> 32x32x16: another summation order inside a K chunk) or which
+    shapes the fp16x2 weight-gradient kernel takes (64-row / 64-column tiles): results within a few fp32 roundings of the
+    default's, pass by pass (each is measured against float64 in test_split_arithmetic_is_fp32_accurate)."""
+    from weaklysuperviseddl_amd import ops
+    defaults = dict(conv_mfma16=0, wgrad_mfma16=1, wgrad_tile64=0, wgrad_min_tiles=6)
+    shapes = [(16, 512, 512, 3, 1, 2, 32), (4, 64, 64, 3, 1, 1, 32), (4, 64, 256, 1, 1, 1, 32), (4, 256, 64, 1, 1, 1, 32),
+              (8, 256, 128, 1, 1, 1, 32), (2, 128, 128, 3, 2, 1, 32), (3, 192, 320, 3, 1, 2, 24)]
+    try:
+        for B, Cin, Cout, k, st, d, H in shapes:
+            g = torch.Generator(device=dev).manual_seed(Cin + Cout + H)
+            pad = (k // 2) * d
+            x = torch.randn(B, Cin, H, H, device=dev, generator=g)
+            w = torch.randn(Cout, Cin, k, k, device=dev, generator=g) * 0.05
+            res = []
+            for cfg in (defaults, {**defaults, **opts}):
+                for o, v in cfg.items():
+                    ops.set_option(o, v)
+                wf, wd = ops.prep_weights(w)
+                y = ops.conv2d_fwd(x, wf, w.shape, st, pad, d)
+                dy = torch.randn(y.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+                res.append((y, ops.conv2d_dgrad(dy, wd, w.shape, x.shape, st, pad, d), ops.conv2d_wgrad(x, dy, w.shape, st, pad, d)))
+            for a, b, what in zip(res[0], res[1], ("fwd", "dgrad", "wgrad")):
+                err = ((a - b).abs().max() / a.abs().max()).item()
+                assert err < 2e-6, (opts, what, (B, Cin, Cout, k, st, d, H), err)
+    finally:
+        for o, v in defaults.items():
+            ops.set_option(o, v)
+
+
 def test_weight_layout_sizes(dev):
     """The opaque layout buffers: 4 bytes per weight (fp32 k-major; two fp16 pieces + a 16-byte amax trailer) or 6 (three
     bf16 pieces + trailer), by shape and option."""

@@ -1506,8 +1506,17 @@ int g_wgrad_xcd = 0;         // XCD-aware tile order of the split weight-gradien
 int g_wgrad_wide = 0;        // 8-pixel runs per lane in the x staging of the split weight-gradient kernel (stride 1, OW % 8 == 0)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
+// (that was the bf16x3 kernel; the fp16x2 kernel on 16x16x32 MFMAs wins from ONE N tile on: 1x1 convs of layer2 / layer3.0
+// 76 -> 61, 41 -> 31, 63 -> 43 us.  Its 64-row / 64-column tiles, "wgrad_tile64", take the 64-channel layers of layer1
+// too but lose there to the fp32 kernels - 87 -> 121 us on the 64 -> 64 3x3: few tiles, hundreds of slabs - off.)
+int g_wgrad_min_tiles = 6;     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
+int g_wgrad_tile64 = 0;
+bool wgrad_tile64() { return g_conv_arith && g_wgrad_mfma16 && g_wgrad_tile64; }
 bool wgrad_chunk32(int Cout, int Cin, int N) {
-    return g_wgrad_split && Cout % 128 == 0 && Cin % 128 == 0 && N / 128 >= 6;
+    const int q = wgrad_tile64() ? 64 : 128;
+    if (!g_wgrad_split || Cout % q != 0 || Cin % q != 0) return false;
+    const int bn = Cin % 128 == 0 ? 128 : 64;
+    return N / bn >= ((g_conv_arith && g_wgrad_mfma16) ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
 }
 
 // taps that read at least one in-range input pixel for some output pixel (bit t of the result); the others (dilation
@@ -1622,6 +1631,8 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "wgrad_wide")) { g_wgrad_wide = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { g_wgrad_mfma16 = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_min_tiles")) { g_wgrad_min_tiles = value > 0 ? value : 1; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_tile64")) { g_wgrad_tile64 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1883,7 +1894,8 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 live_mask = live_all;            // dead taps: no workgroup writes their slab columns, the reduce skips them
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
                 const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
-                dim3 grid(p.N / 128, Cout / 128, S);
+                const int kBM = Cout % 128 == 0 ? 128 : 64, kBN = Cin % 128 == 0 ? 128 : 64;     // 64: split16 kernel only
+                dim3 grid(p.N / kBN, Cout / kBM, S);
                 p.xcd_order = ((long long)grid.x * grid.y * grid.z) % 8 == 0 ? g_wgrad_xcd : 0;
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
                 if (g_conv_arith) {
@@ -1892,12 +1904,20 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     if (g_wgrad_mfma16) {
                         hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();
-                        if (wide)
-                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<true>), grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
-                        else
-                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<false>), grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
+#define WSDL_W16(BM_, BN_)                                                                                              \
+    do {                                                                                                                \
+        if (wide)                                                                                                       \
+            hipLaunchKernelGGL((conv_wgrad_split16_kernel<BM_, BN_, true>), grid, dim3(kThreads), 0, s, p, dys,          \
+                               (unsigned)dys_bytes, dy_amax);                                                           \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv_wgrad_split16_kernel<BM_, BN_, false>), grid, dim3(kThreads), 0, s, p, dys,         \
+                               (unsigned)dys_bytes, dy_amax);                                                           \
+    } while (0)
+                        if (kBM == 128 && kBN == 128) WSDL_W16(128, 128);
+                        else if (kBM == 128) WSDL_W16(128, 64);
+                        else if (kBN == 128) WSDL_W16(64, 128);
+                        else WSDL_W16(64, 64);
+#undef WSDL_W16
                     } else {
                         hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();

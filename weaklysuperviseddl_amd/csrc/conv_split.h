@@ -1059,12 +1059,15 @@ __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* _
     }
 }
 
-template <bool WX>
+// Tiles of 128 or 64 rows / columns (Cout % BM == 0, Cin % BN == 0): the 64-channel layers of layer1 run it too.
+template <int BM, int BN, bool WX>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
-    constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
+    static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
+    constexpr int BK = 32, ROW = kW16Row;
     constexpr int WN = 2;
-    constexpr int A_U = BM * ROW / 16 / kThreads;          // 4 units per thread, exact
+    constexpr int TMI = BM / 32, TNI = BN / 32;             // 16 x 16 tiles of a wave (2 x 2 waves)
+    constexpr int A_U = BM * ROW / 16 / kThreads;          // units per thread, exact
     constexpr int B_PER = BN / 8;
     constexpr unsigned kOOB = 0x80000000u;
 
@@ -1107,11 +1110,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 #pragma unroll
     for (int e = 0; e < A_U; ++e) voff_a[e] = (unsigned)(m0 * ROW + (tid + e * kThreads) * 16);
 
-    f32x4 acc[4][4];
+    f32x4 acc[TMI][TNI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra[A_U];
     unsigned rb[B_PER];
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         if constexpr (WX) {
             ld_mask = wx_mask;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < BN / 64; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int off = wx_off + j * 64 * HW + 4 * h;
@@ -1211,7 +1214,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
         if constexpr (WX) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < BN / 64; ++j) {
                 unsigned pc[2][4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1240,8 +1243,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 
     const int l15 = lane & 15, lg = lane >> 4;
     const unsigned fr0 = (unsigned)(l15 * ROW + ((lg ^ (l15 >> 1)) << 4)), fr1 = (unsigned)(l15 * ROW + (((4 + lg) ^ (l15 >> 1)) << 4));
-    const unsigned char* Ab = As + wm * 64 * ROW;
-    const unsigned char* Bb = Bs + wn * 64 * ROW;
+    const unsigned char* Ab = As + wm * (BM / 2) * ROW;
+    const unsigned char* Bb = Bs + wn * (BN / 2) * ROW;
     if (t_dh >= p.H || (p.OH - 1) * p.stride + t_dh < 0 || t_dw >= p.W || (p.OW - 1) * p.stride + t_dw < 0) return;
     int c0 = next_valid(chunk_begin);
     if (c0 < chunk_end) load_tiles(c0);
@@ -1250,21 +1253,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         const int c1 = next_valid(c0 + 1);
         if (c1 < chunk_end) load_tiles(c1);
         lds_barrier();
-        half8 a[4][2], b[4][2];
+        half8 a[TMI][2], b[TNI][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TMI; ++i) {
             a[i][0] = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr0);
             a[i][1] = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr1);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TNI; ++j) {
             b[j][0] = *reinterpret_cast<const half8*>(Bb + j * 16 * ROW + fr0);
             b[j][1] = *reinterpret_cast<const half8*>(Bb + j * 16 * ROW + fr1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TNI; ++j) {
                 f32x4 c = acc[i][j];
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
@@ -1277,13 +1280,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l15;
+        for (int j = 0; j < TNI; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m0 + wm * 64 + i * 16 + lg * 4 + r;
+                const int co = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
                 slab[(long long)co * p.N + n] = acc[i][j][r] * out_scale;
             }
         }

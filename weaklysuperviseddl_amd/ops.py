@@ -154,6 +154,8 @@ def set_option(name, value):
     check(lib().wsdl_set_option(name.encode(), int(value)))
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
+    if name == "wgrad_tile64":
+        WGRAD_TILE64[0] = int(value != 0)
     LAYOUT_EPOCH[0] += 1
     bump_param_epoch()
 
@@ -315,8 +317,14 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     return dx
 
 
+WGRAD_TILE64 = [0]     # mirrors the library's "wgrad_tile64"
+
+
 def _wgrad_split(wshape):
-    return CONV_ARITH[0] == 1 and wshape[0] % 128 == 0 and wshape[1] % 128 == 0
+    """May the library's fp16x2 weight-gradient kernel take this shape (then both operands need amax scalars - a read
+    pass on the main stream for a tensor that carries none, so this must not claim more than the library's own rule)."""
+    q = 64 if WGRAD_TILE64[0] else 128
+    return CONV_ARITH[0] == 1 and wshape[0] % q == 0 and wshape[1] % q == 0
 
 
 def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None):
