@@ -455,6 +455,7 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
 # wgrad kernels overlap the HBM-bound BatchNorm backward / gradient-reduce kernels of the main chain.
 OVERLAP_WGRAD = [True]
 WGRAD_AFTER_DGRAD = [False]     # measured: 21.2 ms/step against 20.9 with the weight gradient enqueued first (profiles/r02_notes.md)
+LAST_WGRAD_ON_MAIN = [os.environ.get("WSDL_LAST_WGRAD_ON_MAIN", "1") != "0"]   # the stem's weight gradient: see _wgrad_into
 _side_streams = {}
 
 
@@ -473,13 +474,15 @@ def join_side_stream(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
-def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None):
-    """d(param) = wgrad(x, dconv) written straight into param.grad (a slice of the flat gradient buffer)."""
+def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, last=False):
+    """d(param) = wgrad(x, dconv) written straight into param.grad (a slice of the flat gradient buffer).
+    ``last``: no input gradient follows (the network's first layer): nothing else is left for the main stream, so the
+    kernel runs there, beside whatever the side stream still has queued, instead of behind it."""
     accumulate = not sink.take_fresh(param)
     split = _wgrad_split(wshape)
     x_amax = x_amax if x_amax is not None else amax_of(x, split)       # resolved on the MAIN stream (may launch a pass)
     dy_amax = amax_of(dconv, split)
-    if OVERLAP_WGRAD[0]:
+    if OVERLAP_WGRAD[0] and not (last and LAST_WGRAD_ON_MAIN[0]):
         main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
         side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
         with torch.cuda.stream(side):
@@ -568,7 +571,7 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
             if sw is not None:
-                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax)
+                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax, last=not ctx.needs_input_grad[0])
             else:
                 dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil, x_amax=ctx.x_amax)
         if not WGRAD_AFTER_DGRAD[0]:
