@@ -188,16 +188,25 @@ def make_optimizer(model, lr=1e-4, early_step=None):
         index = {id(p): i for i, p in enumerate(params)}
         by_param = {index[id(m.weight)]: m for m in convs}
 
-        def relayout(_k, param_indices, use_events):
+        def relayout(k, param_indices, use_events, adam_event=None):
+            if k == 0:
+                adam_event = None        # the first layers' layouts gate the next forward: not behind the other segments' queue
             seg_convs = [by_param[i] for i in param_indices if i in by_param]
             # runs before step() bumps the parameter epoch; in eager mode into the spare buffers (this step's remaining
             # input-gradient kernels still read the current ones), inside a captured graph in place
-            ops.prefetch_weight_layouts(seg_convs, use_events=use_events, epoch_ahead=1, pingpong=use_events)
+            return ops.prefetch_weight_layouts(seg_convs, use_events=use_events, epoch_ahead=1, pingpong=use_events,
+                                               after=adam_event)
 
         opt.post_step_hook = lambda: ops.prefetch_weight_layouts(convs)     # after the single-launch step
-        opt.enable_early_step(relayout)
         if early_step is None:
-            early_step = os.environ.get("WSDL_EARLY_STEP", "0") == "1"
+            early_step = {"0": False, "1": True, "2": "tail"}[os.environ.get("WSDL_EARLY_STEP", "0")]
+        if early_step == "tail":
+            # two segments: [the stem | everything else].  "Everything else" is stepped while the stem's backward (max-pool,
+            # BatchNorm over the 67 MB map, the 7x7 weight gradient: 0.3 ms of small launches) still runs
+            stem = params[0].numel() + sum(p.numel() for p in params[1:3])
+            opt.enable_early_step(relayout, first=(stem + 63) // 64 * 64, growth=1 << 20, cap=1 << 40)
+        else:
+            opt.enable_early_step(relayout)
         opt.early_step = bool(early_step)
     return opt
 

@@ -91,12 +91,25 @@ _PREFETCH_HEAD = int(os.environ.get("WSDL_PREFETCH_HEAD", "12"))    # convolutio
 LAYOUT_EPOCH = [0]     # bumped by options that change what a layout buffer holds / how large it is
 
 
-def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=False):
+_prep_streams = {}
+
+
+def prep_stream(device):
+    """Third stream: re-layouts that follow an early segment step must not sit in the side stream in front of the weight
+    gradients (and the Adam launches) still to come."""
+    st = _prep_streams.get(device)
+    if st is None:
+        st = _prep_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=False, after=None):
     """Lay out next step's weights on the side stream (called right after the optimiser step of these weights): the
     re-layout kernels leave the forward chain; each conv waits on its own event (``use_events=False``: the main stream
     joins the side stream instead - inside a captured graph).
     ``epoch_ahead``: the caller will bump the parameter epoch this many times before the layouts are used (early
-    segment steps run before ``FlatAdam.step`` does).  ``pingpong``: write into the conv's spare pair of buffers and swap -
+    segment steps run before ``FlatAdam.step`` does).  ``after``: an event (the segment's Adam launch) - the re-layouts then
+    run on the prep stream behind it instead of on the side stream.  ``pingpong``: write into the conv's spare pair of buffers and swap -
     input-gradient kernels of the CURRENT step that are still to be enqueued keep reading the pair they were given."""
     if not convs:
         return
@@ -105,10 +118,14 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
     if _PREFETCH_HEAD > 0 and len(convs) > 2 * _PREFETCH_HEAD:
         # the forward that follows waits for its FIRST layers' layouts: give those their own (small) amax launch instead of
         # queueing them behind the amax pass over all 158 MB of weights (105 us before the next step could start)
-        prefetch_weight_layouts(convs[:_PREFETCH_HEAD], use_events, epoch_ahead, pingpong)
-        prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong)
-        return
-    side.wait_stream(main)
+        prefetch_weight_layouts(convs[:_PREFETCH_HEAD], use_events, epoch_ahead, pingpong, after)
+        return prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong, after)
+    if after is not None and use_events:
+        side = prep_stream(dev)
+        side.wait_event(after)
+    else:
+        side.wait_stream(main)
+    ev = None
     with torch.cuda.stream(side):
         amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
         for i, m in enumerate(convs):
@@ -128,6 +145,7 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
             cache["prep_layout"] = LAYOUT_EPOCH[0]
     if not use_events:
         main.wait_stream(side)          # graph capture: no cross-replay events - the step ends with the layouts complete
+    return ev                           # recorded behind the last re-layout (None without events)
 
 
 def workspace(nbytes, device):

@@ -62,8 +62,8 @@ class FlatAdam:
     # ---------------------------------------------------------------------------------- early segment steps
     def enable_early_step(self, segment_hook=None, first=1 << 18, growth=5, cap=12_000_000):
         """Cut the flat buffer into segments and step each as soon as its gradients are complete (module docstring).
-        ``segment_hook(k, param_indices, use_events)`` runs right after segment k's Adam launch (side stream already
-        behind it): the place to re-lay-out that segment's convolution weights."""
+        ``segment_hook(k, param_indices, use_events, adam_event)`` runs right after segment k's Adam launch: the place to
+        re-lay-out that segment's convolution weights (behind ``adam_event``, on a stream of its own)."""
         if not self.flat_param.is_cuda:
             return self
         bounds, target = [0], first
@@ -91,6 +91,7 @@ class FlatAdam:
         self._remaining = None
         self._accumulating = False
         self._adam_event = None
+        self._prep_done = [None] * len(self.segments)     # per segment: event behind its last re-layout
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda q, i=i: self._announce(i))
         self.grad_ready_hooks.append(lambda p: self._announce(self._index[id(p)]))
@@ -135,6 +136,9 @@ class FlatAdam:
         lo, hi = self.segments[k]
         main, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
         side.wait_stream(main)
+        if not self.capture_mode and self._prep_done[k] is not None:
+            side.wait_event(self._prep_done[k])        # last step's re-layouts of THIS segment read the parameters overwritten now
+        ev = None
         with torch.cuda.stream(side):
             if after is not None:
                 after.wait()
@@ -145,11 +149,11 @@ class FlatAdam:
                                self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
                                step_dev=self.step_dev)
             if not self.capture_mode:
-                self._adam_event = torch.cuda.Event()
-                self._adam_event.record(side)
+                ev = self._adam_event = torch.cuda.Event()
+                ev.record(side)
         self._stepped[k] = True
         if self.segment_hook is not None:
-            self.segment_hook(k, self.seg_params[k], not self.capture_mode)
+            self._prep_done[k] = self.segment_hook(k, self.seg_params[k], not self.capture_mode, ev)
 
     def _finish_segments(self):
         dev = self.flat_param.device
