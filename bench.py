@@ -127,7 +127,9 @@ def pmc_traffic(kernel):
     from weaklysuperviseddl_amd import ops
     # the library's timing classes name the arithmetic template argument "AR"; rocprofv3 prints its value
     name = kernel.replace(", AR>", f", {ops.CONV_ARITH[0]}>")
-    k = json.load(open(files[-1])).get("kernels", {}).get(name)
+    kernels = json.load(open(files[-1])).get("kernels", {})
+    # (rocprofv3 also prints the trailing template arguments that the class name leaves at their defaults)
+    k = kernels.get(name) or next((v for kk, v in sorted(kernels.items()) if kk.startswith(name[:-1] + ", ")), None)
     return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
 
 

@@ -36,7 +36,7 @@ def main():
     fetch, write = per_kernel(bf, "FETCH_SIZE"), per_kernel(bw, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
-        if not k.startswith(("conv_", "bn_", "wgrad_", "prep_", "adam", "pairwise", "layercam", "softmax_ce", "bilinear")):
+        if not k.startswith(("conv_", "bn_", "wgrad_", "prep_", "adam", "pairwise", "layercam", "softmax_ce", "bilinear", "dy_split", "multi_amax", "amax_", "maxpool", "gap_")):
             continue
         fk, wk = fetch.get(k, {"launches": 0, "avg_kib": 0.0}), write.get(k, {"launches": 0, "avg_kib": 0.0})
         wide = k.startswith(("adam", "bn_apply", "bn_bwd_apply", "bn_stats"))      # 16 B/lane kernels
