@@ -83,6 +83,21 @@ def smooth_images(B, H, W, seed):
     return (img * 0.5 + 0.5 + 0.01 * torch.randn(B, 3, H, W, generator=g)).clamp(0, 1)
 
 
+class stdout_to_stderr:
+    """Process-group creation prints from C++ ("[Gloo] Rank 0 is connected to ...") on file descriptor 1; stdout carries
+    the one JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def sync_all(world):
     if world > 1:
         dist.barrier()
@@ -274,6 +289,16 @@ def cam_bench(device, iters=5, roofline=True):
     ms = (time.perf_counter() - t0) / iters * 1e3
     out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
+    # stage 1 as generate_pseudo_masks runs it: three of the loader's batches of 8 in flight on three streams
+    nb, lanes = 6, 3
+    gen.generate_batches([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        gen.generate_batches([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes)
+    torch.cuda.synchronize()
+    out["ms_per_img_pipelined"] = round((time.perf_counter() - t0) / iters * 1e3 / (nb * n_img), 4)
+    out["pipelined"] = f"{nb} batches of {n_img}, {lanes} in flight (LayerCAMGenerator.generate_batches, as generate_pseudo_masks)"
     if roofline:
         ops.prof_reset()
         ops.prof_enable(True)
@@ -357,7 +382,8 @@ def spawn_ranks(args, argv):
         except subprocess.TimeoutExpired:
             p.kill()
             rcs.append(-9)
-    sys.stdout.write(out0)
+    for line in out0.splitlines():                # the contract: ONE JSON line on stdout; anything else a rank printed -> stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit(f"bench ranks exited with {rcs}")
@@ -452,7 +478,11 @@ def main():
         ops.OVERLAP_WGRAD[0] = False
     if os.environ.get("WSDL_WGRAD_AFTER_DGRAD"):
         ops.WGRAD_AFTER_DGRAD[0] = True             # A/B: enqueue the input gradient before the weight gradient
-    rank, local, world = init_distributed()
+    if os.environ.get("WSDL_DUMP_AFTER"):            # debugging aid: where is every thread N seconds from now?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["WSDL_DUMP_AFTER"]), repeat=False, file=sys.stderr)
+    with stdout_to_stderr():
+        rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
@@ -470,7 +500,8 @@ def main():
     # WSDL_FORCE_DIST=1 puts the data-parallel machinery (RCCL broadcasts / bucketed all-reduces, control exchange) on a
     # single rank as well: the one-GPU rehearsal of the code path the 8-GPU run takes
     dp_on = world > 1 or (dist.is_available() and dist.is_initialized())
-    reducer = GradBucketReducer(opt, modules=[model]) if dp_on else None   # noqa: F841  (hooks live on the optimizer)
+    with stdout_to_stderr():
+        reducer = GradBucketReducer(opt, modules=[model]) if dp_on else None   # noqa: F841  (hooks live on the optimizer)
 
     if rank == 0:
         log(f"{cfg} on {device}, world={world}, B={B}, {S}x{S}; warm-up {args.warmup} steps")

@@ -159,6 +159,30 @@ def test_generate_pseudo_masks_in_memory(dev, cam_models, tmp_path):
     assert np.array_equal(keep_largest(np.zeros((4, 4), np.uint8)), np.zeros((4, 4), np.uint8))
 
 
+def test_cam_batches_in_flight_equal_batch_by_batch(dev, cam_models):
+    """Stage 1 keeps three of the loader's batches in flight on three streams (LayerCAMGenerator.generate_batches,
+    generate_pseudo_masks(streams=3)): the CAMs and masks are those of the batch-by-batch loop, bit for bit."""
+    from weaklysuperviseddl_amd.TraditionalModel import LayerCAMGenerator, generate_pseudo_masks
+    _ref, mine = cam_models
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.rand(3, 3, 224, 224, generator=g).to(dev) for _ in range(5)]
+    classes = [torch.randint(0, 37, (3,), generator=g).to(dev) for _ in range(5)]
+    gen = LayerCAMGenerator(mine, ["layer3", "layer4"])
+    one = [gen.generate_batch(b, 1.0, c, thresh=0.3) for b, c in zip(batches, classes)]
+    for _ in range(2):                                            # twice: lanes are created, then reused
+        many = gen.generate_batches(batches, 1.0, classes, 0.3, streams=3)
+        torch.cuda.synchronize()
+        for (c1, m1), (c2, m2) in zip(one, many):
+            assert torch.equal(c1, c2) and torch.equal(m1, m2)
+    loader = [(b.cpu(), (c.cpu(), None)) for b, c in zip(batches, classes)]
+    res = {}
+    for k in (1, 3):
+        generate_pseudo_masks(loader, gen, cam_thresh=0.3, write_png=False, streams=k)
+        res[k] = (list(generate_pseudo_masks.last_ids), [m.copy() for m in generate_pseudo_masks.last_masks])
+    assert res[1][0] == res[3][0] == list(range(15))
+    assert all(np.array_equal(a, b) for a, b in zip(res[1][1], res[3][1]))
+
+
 @pytest.fixture(scope="module")
 def seg_models(dev):
     import oracle

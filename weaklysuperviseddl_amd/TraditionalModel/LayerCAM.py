@@ -106,6 +106,38 @@ class LayerCAMGenerator:
         grads = [self.gradients[n].detach() for n in self.target_layer_names]
         return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
 
+    def generate_batches(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3):
+        """Several independent batches in flight: batch j runs on stream j % ``streams`` with a generator of its own over
+        the SAME model.  At B=8 and 224x224 a batch is ~160 launches of 25-100 workgroups - a fraction of the chip, and
+        latency-bound; images are independent (eval-mode BatchNorm), so the batches of a loader can overlap.  Returns
+        the list of ``generate_batch`` results, identical to calling it batch by batch."""
+        if class_idxs is None:
+            class_idxs = [None] * len(batches)
+        if streams <= 1 or len(batches) <= 1 or not batches[0].is_cuda:
+            return [self.generate_batch(b, alpha, c, thresh) for b, c in zip(batches, class_idxs)]
+        dev = batches[0].device
+        lanes = self.__dict__.setdefault("_lanes", [])
+        while len(lanes) < streams:
+            lanes.append((torch.cuda.Stream(device=dev),
+                          LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged)))
+        cur = torch.cuda.current_stream(dev)
+        outs = []
+        for j, (imgs, cls) in enumerate(zip(batches, class_idxs)):
+            st, gen = lanes[j % streams]
+            st.wait_stream(cur)                              # the inputs (and the cached weight layouts) are ready
+            imgs.record_stream(st)
+            if cls is not None:
+                cls = cls.to(dev)
+                cls.record_stream(st)
+            with torch.cuda.stream(st):
+                out = gen.generate_batch(imgs, alpha, cls, thresh)
+            for t in (out if isinstance(out, tuple) else (out,)):
+                t.record_stream(cur)
+            outs.append(out)
+        for st, _gen in lanes[:streams]:
+            cur.wait_stream(st)
+        return outs
+
     def generate(self, images, alpha=1.0, class_idx=None):
         """images (3,H,W) -> (1,outH,outW), as the reference (unsqueeze inside)."""
         if torch.is_tensor(alpha) and not torch.is_tensor(class_idx):     # notebook order (img, class_idx, alpha)

@@ -12,6 +12,8 @@ Mirrors reference TraditionalModel/PsuedoMasks.py: ``keep_largest`` (:15-21) and
   * ``rank`` / ``world``: stage 1 is per-image independent (eval-mode BN), so under data parallelism the loader's
     batches are dealt round-robin to the ranks - batch j belongs to rank j % world - with NO collective
     (SURVEY.md 8e); image ids stay the global ones, so the union over the ranks is the single-process result;
+  * ``streams``: that many of the loader's batches are in flight on the device at once (``LayerCAMGenerator.generate_batches``);
+    the masks are the same bit for bit;
   * ``keep_largest`` stays on the host as in the reference (skimage there; scipy.ndimage here -
     8-connectivity, raster label order, first label wins area ties, empty mask returned unchanged).
 """
@@ -41,7 +43,7 @@ def _to_png_u8(t):
 
 def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_largest_masks=True,
                           run_id="default", out_root="/content", max_images=500, write_png=True,
-                          device="cuda", rank=0, world=1, keep_images=False):
+                          device="cuda", rank=0, world=1, keep_images=False, streams=3):
     mask_dir = os.path.join(out_root, f"pseudo_masks_{run_id}")
     image_dir = os.path.join(out_root, f"images_{run_id}")
     if write_png:
@@ -56,6 +58,31 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
             if dist.is_initialized():
                 dist.barrier()                  # nobody writes before rank 0 has emptied the directories
     masks, ids, images, img_id = [], [], [], 0
+
+    def finish(group):
+        """CAM + threshold for the queued batches (``streams`` of them in flight), then the host part per image."""
+        if not group:
+            return
+        outs = layercam_gen.generate_batches([g[1] for g in group], alpha, [g[2] for g in group], cam_thresh, streams) \
+            if hasattr(layercam_gen, "generate_batches") else \
+            [layercam_gen.generate_batch(g[1], alpha=alpha, class_idx=g[2], thresh=cam_thresh) for g in group]
+        for (imgs, _d, _l, first_id, take), (_cam, m) in zip(group, outs):
+            m_host = m.cpu().numpy()
+            for i in range(take):
+                gid = first_id + i
+                mi = keep_largest(m_host[i]) if keep_largest_masks else m_host[i]
+                masks.append(mi)
+                ids.append(gid)
+                if keep_images:
+                    images.append(imgs[i].detach())
+                if write_png:
+                    mt = torch.from_numpy(mi).float().unsqueeze(0).expand(3, -1, -1)
+                    Image.fromarray(_to_png_u8(mt)).save(os.path.join(mask_dir, f"{gid}.png"))
+                    im = imgs[i].detach().cpu().clone()
+                    im = (im - im.min()) / (im.max() - im.min())
+                    Image.fromarray(_to_png_u8(im)).save(os.path.join(image_dir, f"{gid}.png"))
+
+    group = []
     for j, (imgs, (labels, _)) in enumerate(loader):
         if img_id >= max_images:
             break
@@ -65,21 +92,12 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
             continue
         imgs_d = imgs[:take].to(device, non_blocking=True)
         labels_d = torch.as_tensor(labels[:take]).to(device)
-        _cam, m = layercam_gen.generate_batch(imgs_d, alpha=alpha, class_idx=labels_d, thresh=cam_thresh)
-        m_host = m.cpu().numpy()
-        for i in range(take):
-            mi = keep_largest(m_host[i]) if keep_largest_masks else m_host[i]
-            masks.append(mi)
-            ids.append(img_id)
-            if keep_images:
-                images.append(imgs[i].detach())
-            if write_png:
-                mt = torch.from_numpy(mi).float().unsqueeze(0).expand(3, -1, -1)
-                Image.fromarray(_to_png_u8(mt)).save(os.path.join(mask_dir, f"{img_id}.png"))
-                im = imgs[i].detach().cpu().clone()
-                im = (im - im.min()) / (im.max() - im.min())
-                Image.fromarray(_to_png_u8(im)).save(os.path.join(image_dir, f"{img_id}.png"))
-            img_id += 1
+        group.append((imgs, imgs_d, labels_d, img_id, take))
+        img_id += take
+        if len(group) >= max(1, streams):
+            finish(group)
+            group = []
+    finish(group)
     generate_pseudo_masks.last_masks = masks
     generate_pseudo_masks.last_ids = ids
     generate_pseudo_masks.last_images = images
