@@ -516,7 +516,7 @@ def test_standalone_batchnorm_and_relu_modules(dev):
 
 def test_aux_head_is_lazy_in_eval_mode_only(dev, seg_models):
     """model(x)['out'] is all the reference ever reads; the aux head has no side effect in eval mode, so it is computed on
-    first access there - and eagerly in train mode, where its BatchNorm running statistics move as in torchvision."""
+    first access there - and on every forward in train mode, where its BatchNorm running statistics move as in torchvision."""
     ref, mine = seg_models
     x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(21))
     ref.eval(), mine.eval()
@@ -528,5 +528,9 @@ def test_aux_head_is_lazy_in_eval_mode_only(dev, seg_models):
     mine.train()
     rm0 = mine.aux_classifier[1].running_mean.clone()
     out = mine(x.to(dev))
-    assert not out._lazy and not torch.equal(mine.aux_classifier[1].running_mean, rm0)
+    # computed (on the side stream, beside the main head): only the JOIN is deferred to whoever reads ['aux']
+    aux = out["aux"]
+    assert not out._lazy and tuple(aux.shape) == (2, 21, 64, 64) and torch.isfinite(aux).all()
+    torch.cuda.synchronize()
+    assert not torch.equal(mine.aux_classifier[1].running_mean, rm0)
     mine.load_state_dict({k: v for k, v in ref.state_dict().items()})

@@ -78,6 +78,9 @@ class _Backbone(nn.Module):
         return OrderedDict(out=self.layer4(f3), aux=f3)
 
 
+_AUX_ON_SIDE_STREAM = os.environ.get("WSDL_AUX_SIDE", "1") != "0"
+
+
 class _Outputs(OrderedDict):
     """The result dict of ``forward``.  In eval mode the aux head - which no caller of the reference ever reads
     ("computed every forward, unused by every loss") and which has no side effect there (eval-mode
@@ -142,6 +145,24 @@ class SegmentationModel(nn.Module):
         size = x.shape[-2:]
         feats = self.backbone(x)
         res = _Outputs()
+        if self.aux_classifier is not None and self.training and x.is_cuda and _AUX_ON_SIDE_STREAM and \
+                not torch.cuda.is_current_stream_capturing():
+            # Train mode computes the aux head on every forward, as torchvision does (its BatchNorm statistics move), and
+            # no loss of the reference reads it: it runs on the side stream - idle during forward - beside the main head
+            # instead of after it; whoever does look at ['aux'] joins first.
+            f3 = feats["aux"]
+            main, side = torch.cuda.current_stream(x.device), ops.side_stream(x.device)
+            side.wait_stream(main)
+            f3.record_stream(side)
+            with torch.cuda.stream(side):
+                aux_out = ops.bilinear_resize(self.aux_classifier(f3), size)
+
+            def joined():
+                torch.cuda.current_stream(x.device).wait_stream(side)
+                return aux_out
+            res["out"] = ops.bilinear_resize(self.classifier(feats["out"]), size)
+            res._lazy["aux"] = joined
+            return res
         res["out"] = ops.bilinear_resize(self.classifier(feats["out"]), size)
         if self.aux_classifier is not None:
             f3 = feats["aux"]
