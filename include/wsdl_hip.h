@@ -245,6 +245,19 @@ int wsdl_copy_planes(const float* src, float* dst, int B, int C, int HW, long lo
 
 /* ---- losses --------------------------------------------------------------------------------- */
 size_t wsdl_reduce_workspace(void);
+/* lovasz_softmax(probas, labels, classes, per_image=False, ignore) - the optional loss of train_segmentation_model
+ * (TraditionalModel/SegmentationModel.py:103-105; LossFunctions/Lovasz-Softmax_Loss.py: lovasz_grad :11-23,
+ * lovasz_softmax_flat :164-192, flatten_probas :195-211).  probas (B,C,H,W) class probabilities, labels int64 (B,H,W).
+ * *loss = mean over the classes that occur (classes_all = 0, 'present') or over all C (classes_all = 1, 'all') of
+ * <errors sorted descending, Jaccard-gradient of the sorted foreground>; dprobas (optional, (B,C,H,W)) = d loss / d probas
+ * (the Jaccard gradient is a constant of the sort order, as in the reference).  ignore_label: pixels with that label take
+ * no part (pass a value no label has, e.g. -1, for None).  One stable radix sort (rocPRIM) + one scan + one pass per class;
+ * bitwise reproducible; ties in the errors are ranked by pixel index. */
+size_t wsdl_lovasz_softmax_workspace(int B, int C, int H, int W);
+int wsdl_lovasz_softmax_fwd_bwd(const float* probas, const int64_t* labels, float* loss, float* dprobas, int B, int C,
+                                int H, int W, int classes_all, long long ignore_label, void* ws, size_t ws_bytes,
+                                wsdl_stream_t stream);
+
 /* nn.CrossEntropyLoss() on (B,C,H,W) logits and int64 (B,H,W) labels
  * (TraditionalModel/SegmentationModel.py:90,107; AlternatingDirectionCutLoss.py:789,699): mean over the pixels whose
  * label != ignore_index (PyTorch's default is -100; such pixels get zero loss and zero gradient).  Any other label

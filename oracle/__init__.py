@@ -33,6 +33,9 @@ from .losses import (  # noqa: F401
     ConstrainToBoundaryLossSingle,
     compute_affinities,
     pairwise_affinity_loss,
+    lovasz_grad,
+    lovasz_softmax,
+    lovasz_softmax_flat,
 )
 from .layercam import LayerCAMGenerator, CAMGenerator, layercam_epilogue  # noqa: F401
 from .pseudo_masks import keep_largest, cam_to_mask, generate_pseudo_masks  # noqa: F401

@@ -105,3 +105,56 @@ class ConstrainToBoundaryLossSingle(nn.Module):
     def compute_affinities_single(image, sigma_color=0.1, sigma_space=5, window_size=5):
         a = _affinity_stack(image.unsqueeze(0), window_size, sigma_color, sigma_space)
         return [a[k] for k in range(a.shape[0])]                           # K x (1,H,W)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Lovasz-softmax (reference TraditionalModel/LossFunctions/Lovasz-Softmax_Loss.py; optional loss of
+# train_segmentation_model, SegmentationModel.py:103-105: ``lovasz_softmax(F.softmax(outputs, 1), masks,
+# classes='present', per_image=False, ignore=None)``).  Restated from the algorithm (Berman et al., Alg. 1):
+def lovasz_grad(gt_sorted):
+    """Gradient of the Lovasz extension of the Jaccard loss w.r.t. sorted errors (:11-23): with G = sum(gt),
+    J_k = 1 - (G - cumsum(gt)_k) / (G + cumsum(1 - gt)_k), the k-th entry is J_k - J_{k-1} (J_{-1} = 0)."""
+    gt = gt_sorted.float()
+    total = gt.sum()
+    inter = total - gt.cumsum(0)
+    union = total + (1.0 - gt).cumsum(0)
+    jac = 1.0 - inter / union
+    out = jac.clone()
+    out[1:] = jac[1:] - jac[:-1]
+    return out
+
+
+def lovasz_softmax_flat(probas, labels, classes="present"):
+    """probas (P, C), labels (P,) -> mean over the (present) classes of <sorted |fg - p_c|, lovasz_grad(fg sorted)>
+    (:164-192).  The gradient vector is a constant of the sort order (not differentiated through)."""
+    if probas.numel() == 0:
+        return probas * 0.0
+    C = probas.shape[1]
+    losses = []
+    which = range(C) if classes in ("all", "present") else classes
+    for c in which:
+        fg = (labels == c).float()
+        if classes == "present" and fg.sum() == 0:
+            continue
+        errors = (fg - probas[:, c]).abs()
+        errors_sorted, perm = torch.sort(errors, 0, descending=True)
+        losses.append(torch.dot(errors_sorted, lovasz_grad(fg[perm]).detach()))
+    if not losses:
+        return probas.sum() * 0.0            # the reference's mean([]) = 0
+    return sum(losses) / len(losses)
+
+
+def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
+    """probas (B, C, H, W) class probabilities, labels (B, H, W) (:146-161, flatten_probas :195-211)."""
+    def flat(p, l):
+        Cc = p.shape[1]
+        p = p.permute(0, 2, 3, 1).reshape(-1, Cc)
+        l = l.reshape(-1)
+        if ignore is None:
+            return p, l
+        keep = l != ignore
+        return p[keep], l[keep]
+    if per_image:
+        vals = [lovasz_softmax_flat(*flat(p.unsqueeze(0), l.unsqueeze(0)), classes=classes) for p, l in zip(probas, labels)]
+        return sum(vals) / len(vals)
+    return lovasz_softmax_flat(*flat(probas, labels), classes=classes)

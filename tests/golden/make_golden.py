@@ -228,6 +228,40 @@ print("keep_largest.npz", len(out))
 '''
 
 
+def gen_lovasz():
+    """lovasz_softmax of the reference's own file (LossFunctions/Lovasz-Softmax_Loss.py: torch + numpy only; its
+    ``Variable`` is the identity on modern torch): loss and d loss / d probas for softmax probabilities of seeded logits."""
+    from torch.autograd import Variable
+    try:
+        from itertools import ifilterfalse
+    except ImportError:
+        from itertools import filterfalse as ifilterfalse
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                       # ``classes is 'present'``: SyntaxWarning (SURVEY.md D10)
+        ns = lift(f"{REF}/LossFunctions/Lovasz-Softmax_Loss.py",
+                  {"lovasz_grad", "lovasz_softmax", "lovasz_softmax_flat", "flatten_probas", "mean", "isnan"},
+                  {"Variable": Variable, "ifilterfalse": ifilterfalse})
+    out, meta = {}, []
+    cases = [(2, 2, 16, 16, "present", False, None), (3, 2, 12, 20, "present", False, None), (2, 3, 8, 8, "present", False, None),
+             (2, 3, 8, 8, "all", False, None), (2, 2, 16, 16, "present", True, None), (2, 4, 10, 6, "present", False, 3)]
+    for i, (B, C, H, W, classes, per_image, ignore) in enumerate(cases):
+        g = torch.Generator().manual_seed(500 + i)
+        logits = 1.5 * torch.randn(B, C, H, W, generator=g)
+        labels = torch.randint(0, C, (B, H, W), generator=g)
+        if i == 2:
+            labels[labels == 2] = 0                                # class 2 absent: 'present' skips it
+        probas = F.softmax(logits, dim=1).detach().requires_grad_()
+        loss = ns["lovasz_softmax"](probas, labels, classes=classes, per_image=per_image, ignore=ignore)
+        loss.backward()
+        out[f"lov{i}_probas"], out[f"lov{i}_labels"] = probas.detach().numpy(), labels.numpy()
+        out[f"lov{i}_loss"], out[f"lov{i}_grad"] = np.float64(loss.item()), probas.grad.numpy()
+        meta.append(dict(B=B, C=C, H=H, W=W, classes=classes, per_image=per_image, ignore=ignore))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(f"{HERE}/lovasz.npz", **out)
+    print("lovasz.npz", len(out))
+
+
 def gen_keep_largest():
     py39 = "/opt/conda/bin/python3.9"
     subprocess.run([py39, "-c", _KEEP_LARGEST_PY39, f"{HERE}/keep_largest.npz"], check=True)
@@ -238,4 +272,5 @@ if __name__ == "__main__":
     gen_losses()
     gen_layercam()
     gen_refine_and_metrics()
+    gen_lovasz()
     gen_keep_largest()

@@ -625,3 +625,59 @@ def test_pairwise_loss_with_cached_affinities_is_bit_identical(dev, shape, windo
         l2 = ops.pairwise_affinity_loss(p2, img, window, 0.1, space, softmax, norm, cache=cache)
         l1.sum().backward(), l2.sum().backward()
         assert torch.equal(l1, l2) and torch.equal(p1.grad, p2.grad), (softmax, norm, space)
+
+
+def test_lovasz_softmax_vs_golden_and_oracle(dev, golden):
+    """The device Lovasz-softmax against the vectors produced by the reference's own function bodies (loss and gradient;
+    'present' with an absent class, 'all', per_image, an ignored label) and, at a size with a million pixels, against the
+    oracle: loss to 1e-5; gradient where the sorted errors are distinct (inside a tie the reference's order is whatever
+    torch.sort gave, ours the pixel index - the loss does not depend on it)."""
+    import oracle
+    from weaklysuperviseddl_amd import ops
+    g = golden("lovasz")
+    meta = json.loads(str(g["meta"]))
+    for i, m in enumerate(meta):
+        p = torch.from_numpy(g[f"lov{i}_probas"]).to(dev).requires_grad_()
+        lab = torch.from_numpy(g[f"lov{i}_labels"]).to(dev)
+        loss = ops.lovasz_softmax(p, lab, classes=m["classes"], per_image=m["per_image"], ignore=m["ignore"])
+        loss.backward()
+        assert abs(loss.item() - float(g[f"lov{i}_loss"])) <= 1e-5 * max(1.0, abs(float(g[f"lov{i}_loss"]))), (i, loss.item())
+        ref = torch.from_numpy(g[f"lov{i}_grad"])
+        assert (p.grad.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-9, i
+    gen = torch.Generator().manual_seed(5)
+    logits = torch.randn(4, 2, 512, 512, generator=gen)
+    labels = (torch.rand(4, 512, 512, generator=gen) > 0.6).long()
+    pc = torch.softmax(logits, 1).requires_grad_()
+    lo = oracle.lovasz_softmax(pc, labels)
+    lo.backward()
+    pd = torch.softmax(logits, 1).to(dev).requires_grad_()
+    ld = ops.lovasz_softmax(pd, labels.to(dev))
+    ld.backward()
+    assert abs(ld.item() - lo.item()) <= 1e-5 * lo.item()
+    # rank-dependent gradient: compare where no other pixel of the class has the same error
+    err = (torch.nn.functional.one_hot(labels, 2).permute(0, 3, 1, 2).float() - pc.detach()).abs()
+    for c in range(2):
+        e = err[:, c].reshape(-1)
+        _u, inv, cnt = torch.unique(e, return_inverse=True, return_counts=True)
+        distinct = (cnt[inv] == 1).reshape(err[:, c].shape)
+        a, b = pd.grad[:, c].cpu()[distinct], pc.grad[:, c][distinct]
+        assert distinct.float().mean() > 0.5
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+    # two runs: bit-identical
+    pd2 = torch.softmax(logits, 1).to(dev).requires_grad_()
+    ld2 = ops.lovasz_softmax(pd2, labels.to(dev))
+    ld2.backward()
+    assert ld2.item() == ld.item() and torch.equal(pd2.grad, pd.grad)
+
+
+def test_train_step_with_lovasz_softmax(dev):
+    """loss_fn='lovasz_softmax' of the reference's train_segmentation_model: the step runs, the loss is finite and falls."""
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    import bench
+    torch.manual_seed(0)
+    model = build_segmentation_model().to(dev).train()
+    opt = make_optimizer(model, lr=1e-4)
+    img, masks = bench.synthetic_batch(4, 64, 64, dev, 3)
+    losses = [float(train_step(model, opt, img, masks, loss_fn="lovasz_softmax")) for _ in range(6)]
+    assert all(np.isfinite(losses)) and min(losses[2:]) < losses[0], losses

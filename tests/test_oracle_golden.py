@@ -273,3 +273,17 @@ def test_product_models_are_wired_like_the_oracle():
                 for k, c in m.named_modules() if isinstance(c, wnn.Conv2d)}
     assert geom_mine(build_segmentation_model()) == geom_ref(oracle.build_segmentation_model())
     assert geom_mine(FrozenResNetCAM(37)) == geom_ref(oracle.FrozenResNetCAM(37))
+
+
+def test_lovasz_softmax_loss_and_grad(golden):
+    """The oracle's Lovasz-softmax against the reference's own function bodies (LossFunctions/Lovasz-Softmax_Loss.py):
+    classes='present' (a class without pixels skipped) / 'all', per_image, an ignored label."""
+    g = golden("lovasz")
+    meta = json.loads(str(g["meta"]))
+    assert len(meta) == 6
+    for i, m in enumerate(meta):
+        p = T(g[f"lov{i}_probas"]).requires_grad_()
+        loss = oracle.lovasz_softmax(p, T(g[f"lov{i}_labels"]), classes=m["classes"], per_image=m["per_image"], ignore=m["ignore"])
+        loss.backward()
+        _close(loss.detach(), g[f"lov{i}_loss"], rel=1e-5)
+        _close(p.grad, g[f"lov{i}_grad"], rel=1e-5)

@@ -183,11 +183,17 @@ def build_segmentation_model(num_classes=2, aux_loss=True):
     return SegmentationModel(num_classes=num_classes, aux_loss=aux_loss, aux_classes=21)
 
 
-def train_step(model, optimizer, images, masks, extra_loss=None):
-    """One training iteration; returns the (device) loss tensor, no host synchronisation."""
+def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_entropy"):
+    """One training iteration; returns the (device) loss tensor, no host synchronisation.  ``loss_fn``: 'cross_entropy' or
+    'lovasz_softmax' (reference SegmentationModel.py:65,103-107)."""
     masks = torch.clamp(masks, max=1)
     outputs = model(images)["out"]
-    loss = ops.cross_entropy(outputs, masks.long())
+    if loss_fn == "lovasz_softmax":
+        loss = ops.lovasz_softmax(ops.softmax_channels(outputs), masks.long(), classes="present", per_image=False, ignore=None)
+    elif loss_fn == "cross_entropy":
+        loss = ops.cross_entropy(outputs, masks.long())
+    else:
+        raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
     if extra_loss is not None:
         loss = loss + extra_loss(outputs, images)
     optimizer.zero_grad()

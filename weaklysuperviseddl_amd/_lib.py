@@ -54,6 +54,8 @@ SIGNATURES = {
     "wsdl_copy_planes": (_i, [_vp, _vp, _i, _i, _i, _ll, _ll, _vp]),
     "wsdl_reduce_workspace": (_sz, []),
     "wsdl_softmax_ce_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _ll, _vp, _sz, _vp]),
+    "wsdl_lovasz_softmax_workspace": (_sz, [_i, _i, _i, _i]),
+    "wsdl_lovasz_softmax_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _vp, _sz, _vp]),
     "wsdl_pairwise_affinity_loss_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp, _sz, _vp]),
     "wsdl_pairwise_cache_bytes": (_sz, [_i, _i, _i, _i]),
     "wsdl_pairwise_cache": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -977,6 +977,45 @@ def cross_entropy(logits, labels, ignore_index=-100):
     return _SoftmaxCE.apply(logits, labels, ignore_index)
 
 
+class _LovaszSoftmax(torch.autograd.Function):
+    """lovasz_softmax(probas, labels, classes, per_image=False, ignore) - reference
+    TraditionalModel/LossFunctions/Lovasz-Softmax_Loss.py:146-192; loss and d loss / d probas in one call (a stable
+    radix sort, a scan and one pass per class on the device)."""
+
+    @staticmethod
+    def forward(ctx, probas, labels, classes_all, ignore):
+        probas = _dense(probas, "probas")
+        labels = _req(labels, "labels", torch.int64).contiguous()
+        B, Cc, H, W = probas.shape
+        if tuple(labels.shape) != (B, H, W):
+            raise WsdlError(f"lovasz_softmax: labels {tuple(labels.shape)} do not match probas {tuple(probas.shape)}")
+        loss = torch.empty((), device=probas.device, dtype=torch.float32)
+        dp = torch.empty_like(probas) if probas.requires_grad else None
+        ws = workspace(lib().wsdl_lovasz_softmax_workspace(B, Cc, H, W), probas.device)
+        check(lib().wsdl_lovasz_softmax_fwd_bwd(_p(probas), _p(labels), _p(loss), _p(dp), B, Cc, H, W, int(classes_all),
+                                                int(ignore), _p(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None, None, None
+
+
+def lovasz_softmax(probas, labels, classes="present", per_image=False, ignore=None):
+    """probas (B,C,H,W) class probabilities (or (B,H,W): one sigmoid map), labels (B,H,W)."""
+    if classes not in ("present", "all"):
+        raise WsdlError("lovasz_softmax: classes must be 'present' or 'all' (an explicit class list is not supported)")
+    if probas.dim() == 3:
+        probas = probas.unsqueeze(1)
+    ign = -(1 << 62) if ignore is None else int(ignore)
+    if per_image:
+        vals = [_LovaszSoftmax.apply(probas[b:b + 1], labels[b:b + 1], classes == "all", ign) for b in range(probas.shape[0])]
+        return torch.stack(vals).mean()
+    return _LovaszSoftmax.apply(probas, labels, classes == "all", ign)
+
+
 def pairwise_affinity_loss(preds, image, window=5, sigma_color=0.1, sigma_space=0.0, apply_softmax=True,
                            normalise=0, cache=None):
     """``cache``: ``pairwise_cache(image, window, sigma_color)`` when the image stays fixed over many evaluations."""
