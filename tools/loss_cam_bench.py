@@ -44,6 +44,10 @@ def main():
         lg = preds.clone().requires_grad_()
         us = timeit(lambda: ops.cross_entropy(lg, lab))
         print(f"{'softmax-CE fwd+bwd ' + name:44s} {us:9.1f} {24 * px / us / 1e3:9.1f}  24 B/px (8 logits + 8 int64 label + 8 grad)")
+        pl = torch.softmax(preds, 1).requires_grad_()
+        us = timeit(lambda: ops.lovasz_softmax(pl, lab))
+        print(f"{'lovasz-softmax fwd+bwd ' + name:44s} {us:9.1f} {24 * px / us / 1e3:9.1f}  24 B/px (8 probas + 8 int64 label + 8 grad; "
+              "2 sorts of (key, index) pairs + 2 scans in between)")
     acts = [torch.relu(torch.randn(8, c, 14, 14, device=dev)) for c in (1024, 2048)]
     grads = [torch.randn(8, c, 14, 14, device=dev) * 1e-3 for c in (1024, 2048)]
     nbytes = sum(8 * a.numel() for a in acts) + 8 * 224 * 224 * 5
