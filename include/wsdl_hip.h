@@ -57,14 +57,16 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      instead of one pixel of sixteen rows (stride 1, OW % 8 == 0); bit-identical
  *   wgrad_mfma16   1*  fp16x2 weight-gradient kernel on v_mfma_f32_16x16x32_f16 (swizzled 128-byte LDS rows): -6 % on the
  *                      kernel sweep, +2 % img/s against the 32x32x16 form (0); same accuracy against float64
- *   conv_mfma16    0*  the same MFMA shape in the forward / input-gradient kernels (K chunk 32): -2..-3.6 % on the layer4
- *                      shapes, +1.6 % on layer3 3x3 and ASPP d12, -0.5 % on the sweep: off
+ *   conv_mfma16    1*  the same MFMA shape in the forward / input-gradient kernels (K chunk 32): neutral on the isolated kernel
+ *                      sweep (-2..-3.6 % on the layer4 shapes, +1.6 % on layer3 3x3 and ASPP d12), +2.2 % img/s on the step
+ *                      (784.7 -> 802.1, three same-box pairs) - under the power limit it leaves more to the kernels beside it
  *   wgrad_min_tiles 6* / wgrad_tile64 0*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles
  *                      on (1: the layer2 1x1 kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches);
  *                      64-row / 64-column tiles for the 64-channel layers (slower than the fp32 kernels there)
  *   wgrad_xcd      0*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, nothing on the step
- *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms);
+ *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms; selects the
+ *                      32x32x16 form of those kernels);
  *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      192 channels, n > 1 = from n channels; measured: resident wins at every channel count)

@@ -44,9 +44,9 @@ def errs(a, ref):
 
 MODES = (("fp32", dict(conv_split=0, wgrad_split=0, conv_arith=1, conv_mfma16=0, wgrad_mfma16=1)),
          ("bf16x3", dict(conv_split=1, wgrad_split=1, conv_arith=0, conv_mfma16=0, wgrad_mfma16=1)),
-         ("fp16x2", dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=0, wgrad_mfma16=1)),      # the default
-         # the other MFMA shape of each fp16x2 kernel: forward / dgrad on 16x16x32, wgrad on 32x32x16
-         ("fp16x2-alt", dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=1, wgrad_mfma16=0)))
+         ("fp16x2", dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=1, wgrad_mfma16=1)),      # the default: 16x16x32
+         # the other MFMA shape of the fp16x2 kernels: 32x32x16 everywhere
+         ("fp16x2-alt", dict(conv_split=1, wgrad_split=1, conv_arith=1, conv_mfma16=0, wgrad_mfma16=0)))
 
 
 def main():
@@ -86,8 +86,8 @@ def main():
                 worst["fp16x2-alt"] = max(worst["fp16x2-alt"], ha[1] / f32[1])
     for o, v in MODES[2][1].items():
         ops.set_option(o, v)
-    print("worst split/fp32 rms-error ratio: bf16x3 %.2f, fp16x2 %.2f (default: wgrad on 16x16x32, forward / dgrad on 32x32x16), "
-          "fp16x2 with the other MFMA shape of each kernel %.2f" % (worst["bf16x3"], worst["fp16x2"], worst["fp16x2-alt"]))
+    print("worst split/fp32 rms-error ratio: bf16x3 %.2f, fp16x2 %.2f (default: v_mfma_f32_16x16x32_f16 in all three passes), "
+          "fp16x2 on v_mfma_f32_32x32x16_f16 %.2f" % (worst["bf16x3"], worst["fp16x2"], worst["fp16x2-alt"]))
 
 
 if __name__ == "__main__":

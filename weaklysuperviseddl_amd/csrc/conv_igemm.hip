@@ -1240,7 +1240,7 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
-int g_conv_mfma16 = 0;    // fp16x2 forward / input-gradient kernels with K chunk 32 on v_mfma_f32_16x16x32_f16
+int g_conv_mfma16 = 1;    // fp16x2 forward / input-gradient kernels with K chunk 32 on v_mfma_f32_16x16x32_f16
 int g_conv_glds = 0;      // weights of the fp16x2 kernels by LDS-DMA: bit 0 the 256x128 form, bit 1 the 4-wave forms
 int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
@@ -1268,7 +1268,7 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     if (g_conv_arith) {
         if constexpr (BK == 32) {
-            if (g_conv_mfma16) {
+            if (g_conv_mfma16 && !(g_conv_glds & 2)) {
                 hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, false, true>), grid, dim3(kThreads), 0, s, p);
                 WSDL_LAUNCH_CHECK();
                 return WSDL_OK;
@@ -1291,7 +1291,7 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     const bool bk32 = g_t256_bk32 && p.Cin % 32 == 0;
     if (g_conv_arith) {
-        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, false, true>), grid, dim3(512), 0, s, p);
+        if (bk32 && g_conv_mfma16 && !(g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, false, true>), grid, dim3(512), 0, s, p);
         else if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
         else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
