@@ -47,7 +47,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   conv_split     1*  0 = forward / input-gradient convolutions on the exact-fp32 MFMA kernels everywhere
  *   wgrad_split    1*  0 = weight gradients on the exact-fp32 MFMA kernels everywhere
  *   tile256        1*  256x128 workgroup tiles (512 threads) where they still give >= 256 workgroups
- *   t256_bk32      1*  K chunks of 32 in the 256x128 form
+ *   t256_bk32      0*  K chunks of 32 in the 256x128 form (faster per kernel, 1-2.6 % slower per step: registers / LDS left for
+ *                      the weight-gradient workgroups running beside it)
  *   split_bk32     1*  K chunks of 32 in the small-tile split forms;   bk32  1*  same for the fp32 kernels
  *   ksplit_big     1*  128x128 tiles + 2 K slices for grids of 200..399 tiles with K >= 2048
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
@@ -63,8 +64,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   wgrad_min_tiles 6* / wgrad_tile64 0*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles
  *                      on (1: the layer2 1x1 kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches);
  *                      64-row / 64-column tiles for the 64-channel layers (slower than the fp32 kernels there)
- *   wgrad_xcd      0*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
- *                      -1.4 % on the kernel sweep, nothing on the step
+ *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
+ *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
  *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms; selects the
  *                      32x32x16 form of those kernels);
  *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)

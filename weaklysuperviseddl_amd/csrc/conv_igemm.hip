@@ -1284,7 +1284,9 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
 
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
-int g_t256_bk32 = 1;      // K chunks of 32 in the 256x128 form (half the barriers; +3.5 % measured on the bf16x3 kernel)
+int g_t256_bk32 = 0;      // K chunks of 32 in the 256x128 form: +3.5 % per kernel on the bf16x3 kernel, but with fp16x2 the 16-deep
+                          // form (119 registers, 61 KB of LDS against 169 / 99-111 KB) wins 1-2.6 % on the STEP (818.6 -> 828.2,
+                          // 824 -> 845 img/s on two boxes): it leaves room for the weight-gradient workgroups beside it
 int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
@@ -1502,7 +1504,7 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
 int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
-int g_wgrad_xcd = 0;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
+int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
 int g_wgrad_wide = 0;        // 8-pixel runs per lane in the x staging of the split weight-gradient kernel (stride 1, OW % 8 == 0)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
