@@ -143,8 +143,12 @@ def pmc_traffic(kernel):
     # the library's timing classes name the arithmetic template argument "AR"; rocprofv3 prints its value
     name = kernel.replace(", AR>", f", {ops.CONV_ARITH[0]}>")
     kernels = json.load(open(files[-1])).get("kernels", {})
-    # (rocprofv3 also prints the trailing template arguments that the class name leaves at their defaults)
-    k = kernels.get(name) or next((v for kk, v in sorted(kernels.items()) if kk.startswith(name[:-1] + ", ")), None)
+    # rocprofv3 prints the K chunk the class name calls BK and the trailing template arguments it leaves at their defaults:
+    # of the candidates, the one the profiled run launched most
+    cands = []
+    for nm in ([name.replace(", BK,", f", {bk},") for bk in (16, 32)] if ", BK," in name else [name]):
+        cands += [v for kk, v in kernels.items() if kk == nm or kk.startswith(nm[:-1] + ", ")]
+    k = max(cands, key=lambda v: v.get("launches", 0)) if cands else None
     return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
 
 

@@ -1291,7 +1291,8 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    const bool bk32 = g_t256_bk32 && p.Cin % 32 == 0;
+    // bit 0: forward launches (p.bh > 0), bit 1: input-gradient launches (tap step negated)
+    const bool bk32 = (g_t256_bk32 & (p.bh < 0 ? 2 : 1)) && p.Cin % 32 == 0;
     if (g_conv_arith) {
         if (bk32 && g_conv_mfma16 && !(g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, false, true>), grid, dim3(512), 0, s, p);
         else if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
