@@ -235,6 +235,8 @@ def make_optimizer(model, lr=1e-4, early_step=None):
         else:
             opt.enable_early_step(relayout)
         opt.early_step = bool(early_step)
+        if opt.early_step:
+            opt.register_announce_hooks()
     return opt
 
 

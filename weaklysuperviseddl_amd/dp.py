@@ -134,6 +134,8 @@ class GradBucketReducer:
             bounds = [lo for lo, _hi in optimizer.segments] + [n]
             self._early = bool(optimizer.early_step)
             optimizer.external_trigger = self.active and self._early
+            if optimizer.external_trigger:
+                optimizer.register_announce_hooks()
         else:
             num_buckets = max(1, min(num_buckets, nparams))
             # bucket boundaries on parameter boundaries, roughly equal sizes

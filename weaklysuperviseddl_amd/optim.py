@@ -92,10 +92,18 @@ class FlatAdam:
         self._accumulating = False
         self._adam_event = None
         self._prep_done = [None] * len(self.segments)     # per segment: event behind its last re-layout
+        self._hooked = False
+        return self
+
+    def register_announce_hooks(self):
+        """Gradient announcements (needed only when segments are stepped before ``step()``: 364 Python hook calls per step
+        of the segmentation model cost the host ~2.5 ms of the 16 it needs to enqueue a step)."""
+        if self.segments is None or self._hooked:
+            return
+        self._hooked = True
         for i, p in enumerate(self.params):
             p.register_post_accumulate_grad_hook(lambda q, i=i: self._announce(i))
         self.grad_ready_hooks.append(lambda p: self._announce(self._index[id(p)]))
-        return self
 
     @contextlib.contextmanager
     def accumulate(self):
@@ -177,11 +185,12 @@ class FlatAdam:
         return f
 
     def grad_ready(self, p):
+        self._dirty = True              # the side stream may be writing flat_grad: zero_grad must join before its memset
         for h in self.grad_ready_hooks:
             h(p)
 
     def zero_grad(self, set_to_none=False):
-        if self.flat_grad.is_cuda and (self.segments is None or self._fired):
+        if self.flat_grad.is_cuda and getattr(self, "_dirty", True):
             ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
         self.flat_grad.zero_()
         for k in self._fresh:
@@ -197,6 +206,7 @@ class FlatAdam:
             if self.external_trigger or self.early_step or any(self._stepped):
                 self._finish_segments()         # (the segment hook has re-laid-out the weights)
                 ops.bump_param_epoch()
+                self._dirty = False             # the main stream waits for the Adam launches, which follow every gradient
                 return
             self._fired = set()                 # one launch over the whole buffer, below
         if self.flat_param.is_cuda:
@@ -211,5 +221,6 @@ class FlatAdam:
                                step_dev=self.step_dev)
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
+        self._dirty = False                     # (joined above)
         if self.post_step_hook is not None:
             self.post_step_hook()
