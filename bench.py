@@ -108,9 +108,8 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def host_cores():
-    """CPU share of this process: cgroup quota if there is one, else the affinity mask, capped at 16
-    (the GPU box's share per GPU; torch would otherwise spawn one thread per host core)."""
+def host_cores_available():
+    """CPU share of this process: the affinity mask, cut by the cgroup quota if there is one (no cap of ours)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -118,7 +117,22 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, 16))
+    return max(1, n)
+
+
+CPU_THREAD_CAP = int(os.environ.get("WSDL_CPU_THREADS", "16"))   # this pool gives a one-GPU job 16 host cores
+
+
+def host_cores():
+    """Threads the CPU baselines run on: the cores this process may use (affinity mask / cgroup quota), capped at the
+    pool's per-GPU CPU share (16; WSDL_CPU_THREADS changes it).  The bench line reports the threads used (``cores``), the
+    uncapped count (``cores_available``) and the cap."""
+    return max(1, min(host_cores_available(), CPU_THREAD_CAP))
+
+
+def cpu_info():
+    return {"cores": host_cores(), "cores_available": host_cores_available(), "thread_cap": CPU_THREAD_CAP,
+            "cpu": cpu_model()}
 
 
 def cpu_model():
@@ -187,7 +201,7 @@ def cpu_baseline(B, H, W, extra=None, steps=3):
         opt.step()
 
     dt = _timed(one, 1, steps, f"oracle train step B={B} {H}x{W} on {threads} threads")
-    return {"value": round(B / dt, 4), "unit": "img/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+    return {"value": round(B / dt, 4), "unit": "img/s", **cpu_info(), "kind": "port",
             "sample": f"oracle SegmentationModel fwd+loss+bwd+Adam, B={B} {H}x{W} (the full batch of the workload), 1 warm-up + "
                       f"{steps} timed steps, median; torch CPU {torch.__version__} on {threads} threads"}
 
@@ -222,7 +236,7 @@ def cam_cpu_baselines(n_img=8):
 
     t_loop = _timed(loop, 1, 3, "oracle CAM per-image loop")
     t_bat = _timed(batched, 1, 3, "oracle CAM batched")
-    base = {"unit": "ms/img", "cores": threads, "kind": "port", "cpu": cpu_model()}
+    base = {"unit": "ms/img", **cpu_info(), "kind": "port"}
     return {"per_image_loop": dict(base, value=round(t_loop / n_img * 1e3, 3),
                                    sample=f"oracle FrozenResNetCAM fwd + class-logit bwd (to the image, as the reference) + LayerCAM "
                                           f"+ threshold + keep_largest, {n_img} x 224x224 one image per call, 1 warm-up + 3 timed, median"),
@@ -244,7 +258,7 @@ def ncut_cpu_baseline(B, H, W, steps=2):
         crit(preds, img).backward()
 
     dt = _timed(one, 1, steps, f"oracle NCut fwd+bwd ({B},2,{H},{W})")
-    return {"value": round(dt * 1e3, 2), "unit": "ms/step", "cores": threads, "kind": "port", "cpu": cpu_model(),
+    return {"value": round(dt * 1e3, 2), "unit": "ms/step", **cpu_info(), "kind": "port",
             "sample": f"oracle LocalNormalizedCutLoss(0.1, 5) fwd+bwd, preds ({B},2,{H},{W}), 24-slice formulation "
                       f"(AlternatingDirectionCutLoss.py:87-101), 1 warm-up + {steps} timed, median"}
 
@@ -352,45 +366,90 @@ def ncut_bench(device, B=32, H=256, W=256, reps=20):
 
 
 # ------------------------------------------------------------------------------------------ launching
-def spawn_ranks(args, argv):
-    """``python bench.py --gpus N`` from a bare shell: start N ranks as child processes BEFORE anything here touches
-    the GPU (no re-exec of a process that has initialised HIP), relay rank 0's JSON line, fail if any rank fails."""
+def rank_environments(n, ndev, base_env, port=None):
+    """The environment of each of the ``n`` ranks ``python bench.py --gpus n`` starts on a box with ``ndev`` GPUs (pure:
+    nothing is launched - also the GPU-less dry run of the spawn logic, tests/test_abi_and_host.py).  One rank per GPU
+    over RCCL when there are enough GPUs; with fewer, a rehearsal: ranks share the devices (at most 6 processes per
+    GPU on this pool) and the collectives go over gloo."""
     import socket
-    n = args.gpus
-    ndev = torch.cuda.device_count()              # does not initialise the GPU on this image
-    env = dict(os.environ)
+    env = dict(base_env)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     if "MASTER_PORT" not in env:
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            env["MASTER_PORT"] = str(s.getsockname()[1])
+        if port is None:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+        env["MASTER_PORT"] = str(port)
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
     if ndev < n:
-        # rehearsal: fewer GPUs than ranks - ranks share the devices, the collectives go over gloo
         if n > 6 * max(ndev, 1):
             raise SystemExit(f"--gpus {n}: only {ndev} GPU(s) here and at most 6 processes may share one")
         env.setdefault("WSDL_DIST_BACKEND", "gloo")
+    return [dict(env, RANK=str(r), LOCAL_RANK=str(r)) for r in range(n)]
+
+
+def spawn_ranks(args, argv):
+    """``python bench.py --gpus N`` from a bare shell: start N ranks as child processes BEFORE anything here touches
+    the GPU (no re-exec of a process that has initialised HIP), relay rank 0's JSON line, fail if any rank fails."""
+    n = args.gpus
+    ndev = torch.cuda.device_count()              # does not initialise the GPU on this image
+    envs = rank_environments(n, ndev, os.environ)
+    if ndev < n:
         log(f"{ndev} GPU(s) for {n} ranks: rehearsal over gloo, ranks share the device(s)")
     procs = []
-    for r in range(n):
-        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+    for r, e in enumerate(envs):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
-    rcs = []
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=3000))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
+    rcs = wait_ranks(procs, timeout_s=float(os.environ.get("WSDL_BENCH_TIMEOUT", "3000")))
+    out0 = procs[0].captured
     for line in out0.splitlines():                # the contract: ONE JSON line on stdout; anything else a rank printed -> stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit(f"bench ranks exited with {rcs}")
+
+
+def wait_ranks(procs, timeout_s=3000.0, poll_s=0.2):
+    """Wait for every rank; rank 0's stdout is drained by a thread (``procs[0].captured``).  The FIRST rank that exits
+    non-zero - or the deadline - ends the run: the others would otherwise sit in their collectives until the backend's
+    own timeout (a rank that died before its first all-reduce leaves its peers waiting for it).  Children are killed by
+    their exact PIDs."""
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    if procs[0].stdout is not None:
+        reader.start()
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = bad[0] if bad else -1
+            log(f"rank {failed} exited with {rcs[failed]}: stopping the other ranks" if bad else
+                f"ranks still running after {timeout_s:.0f} s: stopping them")
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10.0
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(poll_s)
+    rcs = [p.wait() for p in procs]
+    if procs[0].stdout is not None:
+        reader.join(timeout=10.0)
+    procs[0].captured = (buf[0] if buf else b"").decode()
+    if failed == -1:
+        rcs = [rc if rc else -9 for rc in rcs]
+    return rcs
 
 
 def build_workload(cfg, B, S, device, rank, graph=False):
@@ -558,7 +617,17 @@ def main():
                  "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
     }
     if dp_on:
-        result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches}
+        plan = reducer.comm_budget()
+        result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches,
+                        "control_exchanges": {"blocking": reducer.control_exchanges_blocking,
+                                              "asynchronous_one_step_behind": reducer.control_exchanges_async},
+                        "bucket_plan": plan,
+                        "exposed_bucket": plan[0] if plan else None,
+                        "note": "bucket_plan: bytes per all-reduce (launch order: last bucket first, from gradient-ready hooks) and "
+                                "the time each needs on xGMI (~153 GB/s per link, one link to each peer): ring_us through one "
+                                "link, direct_us = reduce-scatter + all-gather over all links at once.  Only bucket 0 (the stem + "
+                                "layer1, the last gradients of backward) cannot overlap backward: its time is the expected "
+                                "exposed communication per step; the others have the rest of backward (>= 1 ms each) to hide in"}
 
     if not args.no_roofline:
         # instrumented pass: same steps on every rank (the collectives must match), HIP events around every

@@ -262,6 +262,120 @@ def gen_lovasz():
     print("lovasz.npz", len(out))
 
 
+def gen_bottleneck():
+    """The only network code the reference holds itself: ``Bottleneck`` vendored from an old torchvision in
+    PretrainedBasnetModel/model/resnet_model.py:99-135 (1x1 -> 3x3 with the stride on it, i.e. the v1.5 wiring ->
+    1x1 x4, residual add, ReLU after the add; no dilation argument).  Train-mode forward + backward of three blocks
+    - identity shortcut; projection shortcut at stride 1 (layer1.0's form); projection shortcut at stride 2
+    (layer2.0's form) - pin ``oracle.models.Bottleneck(dilation=1)`` and the HIP ``nn.Bottleneck``: outputs, input
+    gradient, every parameter gradient and the BatchNorm running statistics after the forward."""
+    Block = lift("/root/reference/PretrainedBasnetModel/model/resnet_model.py", {"Bottleneck"})["Bottleneck"]
+    out, meta = {}, []
+    cases = [(64, 16, 1, False, 2, 12, 12), (32, 16, 1, True, 2, 10, 14), (32, 16, 2, True, 3, 12, 10)]
+    for i, (inpl, planes, stride, down, B, H, W) in enumerate(cases):
+        torch.manual_seed(900 + i)
+        ds = None
+        if down:
+            ds = nn.Sequential(nn.Conv2d(inpl, planes * 4, kernel_size=1, stride=stride, bias=False),
+                               nn.BatchNorm2d(planes * 4))
+        blk = Block(inpl, planes, stride, ds)
+        g = torch.Generator().manual_seed(910 + i)
+        for m in blk.modules():
+            if isinstance(m, nn.BatchNorm2d):               # non-trivial affine / running statistics
+                m.weight.data.copy_(torch.rand(m.num_features, generator=g) * 0.5 + 0.75)
+                m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+        for k, v in blk.state_dict().items():
+            out[f"b{i}/state/{k}"] = v.detach().clone().numpy()
+        x = torch.randn(B, inpl, H, W, generator=g).requires_grad_()
+        dy = torch.randn(B, planes * 4, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=g)
+        blk.train()
+        y = blk(x)
+        y.backward(dy)
+        out[f"b{i}/x"], out[f"b{i}/dy"] = x.detach().numpy(), dy.numpy()
+        out[f"b{i}/y"], out[f"b{i}/dx"] = y.detach().numpy(), x.grad.numpy()
+        for k, p in blk.named_parameters():
+            out[f"b{i}/grad/{k}"] = p.grad.numpy()
+        for k, v in blk.state_dict().items():
+            if "running" in k:
+                out[f"b{i}/after/{k}"] = v.detach().clone().numpy()
+        blk.eval()
+        out[f"b{i}/y_eval"] = blk(x.detach()).detach().numpy()
+        meta.append(dict(inplanes=inpl, planes=planes, stride=stride, downsample=down))
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(f"{HERE}/bottleneck.npz", **out)
+    print("bottleneck.npz", len(out))
+
+
+def gen_eval_helpers():
+    """``evaluate_classification`` (ClassificationModel.py:109-150) and ``evaluate_layercam_on_test_set``
+    (LayerCAM.py:84-130) run on stubs: a "model" that returns stored logits and a "generator" that returns stored
+    CAMs - the fixture pins the metric procedure (accuracy / macro-F1 formulas; threshold, trimap binarisation,
+    nearest resize, the 11-image cap), not a network.  ``.cuda()`` in the reference body is made the identity."""
+    import contextlib
+    import io
+    met = lift(f"{REF}/ExtraUtilities.py", {"compute_iou_and_acc"})["compute_iou_and_acc"]
+    ec = lift(f"{REF}/ClassificationModel.py", {"evaluate_classification"})["evaluate_classification"]
+    ev = lift(f"{REF}/LayerCAM.py", {"evaluate_layercam_on_test_set"}, {"compute_iou_and_acc": met})["evaluate_layercam_on_test_set"]
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    nb, bs, nc = 5, 8, 37
+    logits = torch.randn(nb, bs, nc, generator=g)
+    labels = torch.randint(0, nc, (nb, bs), generator=g)
+    logits[torch.arange(nb)[:, None], torch.arange(bs)[None, :], labels] += 2.0 * (torch.rand(nb, bs, generator=g) > 0.4)
+
+    class Stub(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.k = 0
+
+        def forward(self, x):
+            k, self.k = self.k, self.k + 1
+            return logits[k], None
+
+    loader = [(torch.zeros(bs, 1), (labels[k], None)) for k in range(nb)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        acc, f1 = ec(Stub(), loader, torch.device("cpu"), num_classes=nc)
+    out["cls_logits"], out["cls_labels"], out["cls_acc_f1"] = logits.numpy(), labels.numpy(), np.array([acc, f1])
+
+    n = 13                                                   # the reference stops after 11 (i >= 10)
+    cams = smooth_image(n, 56, 56, 78)[:, 0]                 # (n,56,56) in [0,1]
+    tri = torch.randint(1, 4, (n, 1, 1, 56, 56), generator=g)          # trimap values 1..3, foreground = 1
+    tri_small = torch.randint(1, 4, (n, 1, 1, 40, 50), generator=g)    # every third image: another size -> nearest resize
+    lab = torch.randint(0, nc, (n,), generator=g)
+
+    class Gen:
+        def __init__(self):
+            self.k = 0
+
+        def generate(self, img, class_idx=None, alpha=1.0):
+            k, self.k = self.k, self.k + 1
+            return cams[k:k + 1].clone()
+
+    test_loader = [(torch.zeros(1, 3, 56, 56), (lab[k:k + 1], (tri_small if k % 3 == 2 else tri)[k])) for k in range(n)]
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = ev(Gen(), test_loader, alpha=1.0, cam_thresh=0.3)
+    finally:
+        torch.Tensor.cuda = orig
+    out["cam_maps"] = cams.numpy().astype(np.float16).astype(np.float32)      # stored rounded: the stub returns these exact values
+    out["cam_tri"], out["cam_tri_small"], out["cam_labels"] = tri.numpy().astype(np.uint8), tri_small.numpy().astype(np.uint8), lab.numpy()
+    # re-run on the rounded maps so that fixture inputs and outputs correspond exactly
+    cams = torch.from_numpy(out["cam_maps"])
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = ev(Gen(), test_loader, alpha=1.0, cam_thresh=0.3)
+    finally:
+        torch.Tensor.cuda = orig
+    out["cam_iou_acc"] = np.array([res["layercam_fg_iou"], res["layercam_fg_acc"]])
+    np.savez_compressed(f"{HERE}/eval_helpers.npz", **out)
+    print("eval_helpers.npz", len(out), out["cls_acc_f1"], out["cam_iou_acc"])
+
+
 def gen_keep_largest():
     py39 = "/opt/conda/bin/python3.9"
     subprocess.run([py39, "-c", _KEEP_LARGEST_PY39, f"{HERE}/keep_largest.npz"], check=True)
@@ -269,8 +383,7 @@ def gen_keep_largest():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_losses()
-    gen_layercam()
-    gen_refine_and_metrics()
-    gen_lovasz()
-    gen_keep_largest()
+    gens = dict(losses=gen_losses, layercam=gen_layercam, refine=gen_refine_and_metrics, lovasz=gen_lovasz,
+                bottleneck=gen_bottleneck, eval_helpers=gen_eval_helpers, keep_largest=gen_keep_largest)
+    for name in (sys.argv[1:] or list(gens)):        # python make_golden.py [losses layercam ...]: only those
+        gens[name]()

@@ -285,3 +285,64 @@ def test_hipgraph_replay_equals_eager_steps(dev):
     for k in sde:
         assert torch.equal(sde[k], sdg[k]), k                     # running statistics and num_batches_tracked too
     assert len(set(le)) == 6 and all(np.isfinite(le))
+
+
+def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
+    """BASELINE configs[3], one GPU's share, as ONE chain: LayerCAM on (16,3,224,224) -> threshold -> keep_largest ->
+    in-memory hand-off (NEAREST 224 -> 256, ImageNet normalise) -> two training steps at B=16 256 x 256.
+      * the chain's masks (``generate_pseudo_masks``: loader batches of 8, three in flight) equal the stage-by-stage path
+        (one ``generate_batch`` per batch, ``keep_largest`` per image) bit for bit, and the per-image B=1 calls of the
+        reference's loop outside the fp32 band around the threshold;
+      * the two steps are finite and the whole chain is bitwise reproducible (parameters, gradients, losses)."""
+    import bench
+    from weaklysuperviseddl_amd import nn as wnn
+    from weaklysuperviseddl_amd.TraditionalModel import (LayerCAMGenerator, build_segmentation_model, generate_pseudo_masks,
+                                                         keep_largest, stage_handoff, train_step)
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    gen, _, _ = bench.cam_setup(dev, 1)
+    imgs224 = torch.rand(16, 3, 224, 224, generator=torch.Generator().manual_seed(100))       # bench.py's cfg4 inputs
+    labels = torch.arange(16) % 37
+    loader = [(imgs224[:8], (labels[:8], None)), (imgs224[8:], (labels[8:], None))]
+
+    def chain():
+        generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev)
+        masks = [m.copy() for m in generate_pseudo_masks.last_masks]
+        assert generate_pseudo_masks.last_ids == list(range(16))
+        img, m = stage_handoff(imgs224, masks, (256, 256), dev)
+        torch.manual_seed(0)
+        model = build_segmentation_model().to(dev).train()
+        for mod in model.modules():
+            if isinstance(mod, wnn.Dropout):
+                mod.p = 0.0                          # host-seeded masks would differ between the two runs
+        opt = make_optimizer(model, lr=1e-4)
+        losses = [train_step(model, opt, img, m.long()).item() for _ in range(2)]
+        torch.cuda.synchronize()
+        return masks, img, m, losses, opt.flat_param.clone(), opt.flat_grad.clone()
+
+    masks, img, m, losses, p1, g1 = chain()
+    assert tuple(img.shape) == (16, 3, 256, 256) and tuple(m.shape) == (16, 256, 256) and m.dtype == torch.uint8
+    assert set(torch.unique(m).tolist()) <= {0, 255}
+    assert all(np.isfinite(losses)) and torch.isfinite(p1).all() and torch.isfinite(g1).all() and g1.abs().max().item() > 0
+    # stage by stage: one batched CAM + threshold per loader batch, keep_largest per image
+    gen2 = LayerCAMGenerator(gen.model, ["layer3", "layer4"])
+    k = 0
+    for b_imgs, (b_lab, _) in loader:
+        cam, mk = gen2.generate_batch(b_imgs.to(dev), 1.0, b_lab.to(dev), thresh=0.3)
+        mk = mk.cpu().numpy()
+        for i in range(b_imgs.shape[0]):
+            assert np.array_equal(keep_largest(mk[i]), masks[k]), k
+            # the reference's per-image loop (B = 1: other tile / split-K choices): same mask outside the fp32 band
+            cam1 = gen2.generate(b_imgs[i].to(dev), 1.0, class_idx=b_lab[i:i + 1].to(dev))[0]
+            raw1 = ((cam1 >= 0.3) & (cam1 > 0)).cpu().numpy()
+            d = torch.from_numpy(raw1 != (mk[i] != 0))
+            band = 2.0 * (cam1 - cam[i]).abs().max().item() + 1e-6
+            assert band < 1e-3 and ((cam[i].cpu() - 0.3).abs()[d] <= band).all(), (k, int(d.sum()), band)
+            k += 1
+    # the hand-off's masks are the NEAREST resize of the stage-1 masks
+    from weaklysuperviseddl_amd.TraditionalModel.PsuedoMasks import nearest_resize_index
+    idx = nearest_resize_index(256, 224, "cpu")
+    for k in range(16):
+        assert np.array_equal(m[k].cpu().numpy(), masks[k][idx][:, idx] * 255)
+    masks2, img2, m2, losses2, p2, g2 = chain()
+    assert all(np.array_equal(a, b) for a, b in zip(masks, masks2)) and torch.equal(img, img2) and torch.equal(m, m2)
+    assert losses == losses2 and torch.equal(p1, p2) and torch.equal(g1, g2)

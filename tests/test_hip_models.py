@@ -27,20 +27,31 @@ def rms_err(a, b):
     return ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30)).item()
 
 
-def close_mod_relu_flips(a, b, tol=1e-3):
+FLIP_LOG = []        # one record per comparison that needed the sparse-deviation branch (reported by the last test)
+FLIP_CALLS = [0]
+
+
+def close_mod_relu_flips(a, b, tol=1e-3, what=""):
     """Gradient tensors that crossed ReLUs.  A pre-activation within fp32 noise of zero (|v| < ~1e-7; about one in
-    10^7 elements, i.e. a few per cent of the runs of a block and nearly every run of a whole network) gets its
-    mask decided differently by two correct fp32 implementations; the gradient is discontinuous there, so the
-    flip moves a sparse footprint of elements by up to ~1e-2 of the maximum (measured: tools/dbg notes in
-    profiles/r01_notes.md - the fp32-MFMA kernels and the oracle flip just as often as the split kernels).
-    Accept: max-norm within tol, or a sparse deviation (<= 10 % of the elements beyond tol, rms <= 10 tol,
-    max <= 50 tol).  Kernel-level exactness is tested without ReLUs in test_hip_ops.py."""
+    10^7 elements) gets its mask decided differently by two correct fp32 implementations; the gradient is
+    discontinuous there, so a flip moves a sparse footprint of elements (one channel row of a weight gradient, a
+    receptive field of an input gradient).  Accept: max-norm within tol - or a SPARSE deviation: at most
+    max(0.1 % of the elements, 8 elements) beyond tol, rms <= 3 tol, max <= 50 tol.  Every use of the second
+    branch is logged; ``test_zz_relu_flip_fallback_usage`` reports them and bounds how often it happened.
+    Kernel-level exactness is tested without ReLUs in test_hip_ops.py."""
+    FLIP_CALLS[0] += 1
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     e, scale = (a - b).abs(), b.abs().max() + 1e-30
     if (e.max() / scale).item() < tol:
         return True
-    frac = (e > tol * scale).double().mean().item()
-    return frac <= 0.10 and rms_err(a, b) <= 10 * tol and (e.max() / scale).item() <= 50 * tol
+    nbad = int((e > tol * scale).sum().item())
+    rec = dict(what=str(what), numel=a.numel(), nbad=nbad, frac=nbad / a.numel(), rms=rms_err(a, b),
+               max=(e.max() / scale).item())
+    rec["ok"] = bool(nbad <= max(1e-3 * a.numel(), 8) and rec["rms"] <= 3 * tol and rec["max"] <= 50 * tol)
+    FLIP_LOG.append(rec)
+    # a gross deviation fails where it happens; a marginal one is judged (and listed with all the others) by
+    # test_zz_relu_flip_fallback_usage at the end of the module
+    return rec["frac"] <= 0.10 and rec["rms"] <= 10 * tol and rec["max"] <= 50 * tol
 
 
 def randomise_bn(model, seed):
@@ -100,9 +111,11 @@ def test_layercam_end_to_end(dev, cam_models, variant):
     e_ref, e_mine = rel_err(cams_r, cams_64), rel_err(cam_b, cams_64)
     assert e_mine < max(1e-3, 3 * e_ref), (e_mine, e_ref)
     assert rel_err(cam_b, cams_r) < 3e-3
-    want = ((cams_r >= 0.3) & (cams_r > 0)).to(torch.uint8)
-    safe = (cams_r - 0.3).abs() > 4e-3
-    assert torch.equal(mask_b.cpu()[safe], want[safe])
+    # masks: equal to the float64 run's outside the band two fp32 runs may differ by - the MEASURED distance to float64
+    band = 2.0 * max(e_ref, e_mine) * cams_64.abs().max().item() + 1e-6
+    want = ((cams_64 >= 0.3) & (cams_64 > 0)).to(torch.uint8)
+    safe = (cams_64 - 0.3).abs() > band
+    assert torch.equal(mask_b.cpu()[safe], want[safe]) and band < 4e-3, band
     # per-image reference-style calls, hook path and default class (argmax)
     one = gen_h.generate(imgs[1].to(dev), 1.0, class_idx=cls[1:2].to(dev))
     assert tuple(one.shape) == (1, 224, 224) and rel_err(one, cams_r[1:2]) < 3e-3
@@ -116,7 +129,7 @@ def test_layercam_end_to_end(dev, cam_models, variant):
         assert rel_err(gen_h.activations[n], gen_r.activations[n]) < 1e-3
     # layer4's gradient is the fc row / 49: no ReLU crossed.  layer3's crosses layer4's nine ReLU layers.
     assert rel_err(gen_h.gradients["layer4"], gen_r.gradients["layer4"]) < 1e-5
-    assert close_mod_relu_flips(gen_h.gradients["layer3"], gen_r.gradients["layer3"])
+    assert close_mod_relu_flips(gen_h.gradients["layer3"], gen_r.gradients["layer3"], what=f"layercam {variant} layer3 grad")
 
 
 def test_generate_pseudo_masks_in_memory(dev, cam_models, tmp_path):
@@ -142,15 +155,23 @@ def test_generate_pseudo_masks_in_memory(dev, cam_models, tmp_path):
     # CAM value inside the band around the threshold in which two fp32 runs of a 50-layer network may land on either side
     generate_pseudo_masks(loader, gen_m, cam_thresh=0.3, keep_largest_masks=False, write_png=False)
     raw_m = generate_pseudo_masks.last_masks
+    import copy
+    gen_64 = oracle.LayerCAMGenerator(copy.deepcopy(ref).double(), ["layer3", "layer4"])
+    gen_hip = LayerCAMGenerator(mine, ["layer3", "layer4"])
     k = 0
     for imgs_b, (labels_b, _) in loader:
         for i in range(imgs_b.shape[0]):
             cam = gen_r.generate(imgs_b[i], alpha=1.0, class_idx=labels_b[i:i + 1])[0]
-            raw_r = oracle.cam_to_mask(cam, 0.3)
-            diff = torch.from_numpy(raw_m[k] != raw_r)
-            assert ((cam - 0.3).abs()[diff] < 4e-3).all(), (k, int(diff.sum()))
+            cam64 = gen_64.generate(imgs_b[i].double(), alpha=1.0, class_idx=labels_b[i:i + 1])[0]
+            cam_h = gen_hip.generate(imgs_b[i].to(dev), 1.0, class_idx=labels_b[i:i + 1].to(dev))[0].cpu()
+            # the band is what this image's two fp32 runs measure against float64, not a constant
+            band = 2.0 * max((cam.double() - cam64).abs().max().item(), (cam_h.double() - cam64).abs().max().item()) + 1e-6
+            assert band < 4e-3, band
+            raw_64 = oracle.cam_to_mask(cam64, 0.3)
+            diff = torch.from_numpy(raw_m[k] != raw_64)
+            assert ((cam64 - 0.3).abs()[diff] <= band).all(), (k, int(diff.sum()), band)
             # keep_largest can only turn such a flip into a different component when it bridges two: count them
-            assert int(diff.sum()) <= int(((cam - 0.3).abs() < 4e-3).sum())
+            assert int(diff.sum()) <= int(((cam64 - 0.3).abs() <= band).sum())
             k += 1
     from PIL import Image
     m0 = np.array(Image.open(f"{mdir}/0.png"))
@@ -244,10 +265,10 @@ def test_every_block_type_fwd_bwd_train_mode(dev, seg_models):
         dy = torch.randn(yr.shape, generator=g)
         yr.backward(dy), ym.backward(dy.to(dev))
         assert rel_err(ym, yr) < 1e-3, name
-        assert close_mod_relu_flips(xm.grad, xr.grad), (name, rel_err(xm.grad, xr.grad))
+        assert close_mod_relu_flips(xm.grad, xr.grad, what=name + " dx"), (name, rel_err(xm.grad, xr.grad))
         pr = dict(mr.named_parameters())
         for k, p in mm.named_parameters():
-            assert close_mod_relu_flips(p.grad, pr[k].grad), (name, k, rel_err(p.grad, pr[k].grad))
+            assert close_mod_relu_flips(p.grad, pr[k].grad, what=name + " " + k), (name, k, rel_err(p.grad, pr[k].grad))
     # stem: conv7x7 s2 + BN + ReLU + maxpool
     x = torch.randn(4, 3, 64, 64, generator=g)
     ref.zero_grad(), mine.zero_grad()
@@ -437,7 +458,7 @@ def test_train_fc_only(dev, cam_models):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    train_fc_only(mine, loader, device=dev, epochs=1, log=None)
+    train_fc_only(mine, dev, 1, dataloader=loader, log=None)       # the reference's positional order
     assert not mine.training
     assert rel_err(mine.fc.weight, ref.fc.weight) < 2e-3 and rel_err(mine.fc.bias, ref.fc.bias) < 2e-2
     sd_r, sd_m = ref.state_dict(), mine.state_dict()
@@ -534,3 +555,206 @@ def test_aux_head_is_lazy_in_eval_mode_only(dev, seg_models):
     torch.cuda.synchronize()
     assert not torch.equal(mine.aux_classifier[1].running_mean, rm0)
     mine.load_state_dict({k: v for k, v in ref.state_dict().items()})
+
+
+def test_bottleneck_vs_the_references_vendored_block(dev, golden):
+    """HIP ``nn.Bottleneck`` against the fixture made from the reference's own vendored block
+    (PretrainedBasnetModel/model/resnet_model.py:99-135; tests/golden/make_golden.py gen_bottleneck): train-mode forward,
+    input gradient, parameter gradients, running statistics, eval-mode forward - identity shortcut and both
+    projection-shortcut forms, 1e-3 (no comparison through the oracle)."""
+    import json
+    from weaklysuperviseddl_amd import nn as wnn
+    from test_oracle_golden import _bottleneck_from_fixture
+    g = golden("bottleneck")
+    meta = json.loads(str(g["meta"]))
+    for i in range(len(meta)):
+        blk = _bottleneck_from_fixture(g, i, meta, wnn.Bottleneck, lambda ci, co, k, s: wnn.Conv2d(ci, co, k, stride=s),
+                                       wnn.BatchNorm2d, wnn.FusedSequential).to(dev).train()
+        x = T(g[f"b{i}/x"]).to(dev).requires_grad_()
+        y = blk(x)
+        y.backward(T(g[f"b{i}/dy"]).to(dev))
+        assert rel_err(y, T(g[f"b{i}/y"])) < 1e-3, i
+        assert close_mod_relu_flips(x.grad, T(g[f"b{i}/dx"]), what=f"reference Bottleneck {i} dx")
+        for k, p in blk.named_parameters():
+            assert close_mod_relu_flips(p.grad, T(g[f"b{i}/grad/{k}"]), what=f"reference Bottleneck {i} {k}"), (i, k)
+        for k, v in blk.state_dict().items():
+            if "running" in k:
+                assert rel_err(v, T(g[f"b{i}/after/{k}"])) < 1e-4, (i, k)
+        with torch.no_grad():
+            assert rel_err(blk.eval()(x.detach()), T(g[f"b{i}/y_eval"])) < 1e-3, i
+
+
+def test_cfg1_layercam_on_the_stated_batch_of_8(dev, cam_models):
+    """BASELINE configs[0]: ClassificationModel + LayerCAM on 8 synthetic 224 x 224 RGB images - the full stated batch
+    (B changes the tile / split-K choices of the small-grid kernels), class_idx = i mod 37, against the
+    oracle's per-image loop: CAMs judged against a float64 run, masks equal outside the fp32 band around the
+    threshold, every disagreeing pixel checked to lie inside it."""
+    import copy
+    import oracle
+    from weaklysuperviseddl_amd.TraditionalModel import LayerCAMGenerator
+    ref, mine = cam_models
+    imgs = torch.rand(8, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    cls = torch.arange(8) % 37
+    gen_r = oracle.LayerCAMGenerator(ref, ["layer3", "layer4"])
+    gen_64 = oracle.LayerCAMGenerator(copy.deepcopy(ref).double(), ["layer3", "layer4"])
+    cams_r = torch.cat([gen_r.generate(imgs[i], alpha=1.0, class_idx=cls[i:i + 1]) for i in range(8)])
+    cams_64 = torch.cat([gen_64.generate(imgs[i].double(), alpha=1.0, class_idx=cls[i:i + 1]) for i in range(8)])
+    cam_b, mask_b = LayerCAMGenerator(mine, ["layer3", "layer4"]).generate_batch(imgs.to(dev), 1.0, cls.to(dev), thresh=0.3)
+    e_ref, e_mine = rel_err(cams_r, cams_64), rel_err(cam_b, cams_64)
+    print("cfg1 CAM max-norm distance to fp64: HIP %.3e, fp32 oracle %.3e" % (e_mine, e_ref))
+    assert e_mine < max(1e-3, 3 * e_ref), (e_mine, e_ref)
+    # the band: what two fp32 runs may differ by = the measured distance of either to float64 (not a constant)
+    band = 2.0 * max(e_ref, e_mine) * cams_64.abs().max().item() + 1e-6
+    want = ((cams_64 >= 0.3) & (cams_64 > 0)).to(torch.uint8)
+    diff = mask_b.cpu() != want
+    assert ((cams_64 - 0.3).abs()[diff] <= band).all(), (int(diff.sum()), band)
+    print("cfg1 masks: %d of %d pixels differ from the float64 masks, all within %.2e of the threshold" %
+          (int(diff.sum()), diff.numel(), band))
+
+
+def test_train_model_accepts_the_references_positional_call(dev, seg_models):
+    """``train_model(model, optimizer, criterion_ce, num_epochs)`` exactly as the reference calls it
+    (AlternatingDirectionCutLoss.py:793 ``train_model(net, optimizer, criterion_ce, num_epochs=10)``), the loader being
+    the module-level ``train_loader`` (:781) - equal, bit for bit, to the keyword form and to plain ``train_step``s."""
+    from weaklysuperviseddl_amd.TraditionalModel import train_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel import AlternatingDirectionCutLoss as ADC
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    _, mine = seg_models
+    sd0 = {k: v.clone() for k, v in mine.state_dict().items()}
+    g = torch.Generator().manual_seed(31)
+    data = [(torch.randn(2, 3, 64, 64, generator=g), (torch.rand(2, 64, 64, generator=g) > 0.5).long() * 255, ["a", "b"])
+            for _ in range(2)] + [(torch.randn(1, 3, 64, 64, generator=g), torch.zeros(1, 64, 64).long(), ["c"])]   # B=1: skipped
+
+    def run(how):
+        mine.load_state_dict(sd0)
+        mine.train()
+        opt = make_optimizer(mine, lr=1e-3)
+        if how == "reference":
+            ADC.train_loader = data
+            try:
+                tot = train_model(mine, opt, nn.CrossEntropyLoss(), 2)
+            finally:
+                ADC.train_loader = None
+        elif how == "keyword":
+            tot = train_model(mine, opt, None, num_epochs=2, train_loader=data, log=None)
+        else:
+            tot = []
+            for _ in range(2):
+                t = torch.zeros((), device=dev)
+                for x, m, _n in data[:2]:
+                    t += train_step(mine, opt, x.to(dev), m.to(dev))
+                tot.append(t)
+        torch.cuda.synchronize()
+        return [t.item() for t in tot], opt.flat_param.clone(), opt.step_count
+
+    ref_l, ref_p, n = run("reference")
+    assert n == 4 and all(np.isfinite(ref_l))
+    for how in ("keyword", "steps"):
+        l, p, n2 = run(how)
+        assert l == ref_l and torch.equal(p, ref_p) and n2 == 4, how
+    mine.load_state_dict(sd0)
+
+
+@pytest.mark.parametrize("loss_fn", ["cross_entropy", "lovasz_softmax"])
+def test_train_segmentation_model_on_a_pseudo_mask_run(dev, tmp_path, loss_fn):
+    """``train_segmentation_model(loss_fn, run_id, lr, num_epochs, batch_size, val_split)`` (SegmentationModel.py:59-122)
+    on the PNG directories ``generate_pseudo_masks`` writes: returns (model, final_loss); the per-epoch validation runs
+    when a val_loader is given."""
+    from PIL import Image
+    from weaklysuperviseddl_amd.TraditionalModel import train_segmentation_model, SegmentationModel
+    from weaklysuperviseddl_amd.TraditionalModel.PsuedoMasks import _to_png_u8
+    rng = np.random.RandomState(4)
+    for d in ("images_t1", "pseudo_masks_t1"):
+        (tmp_path / d).mkdir()
+    for i in range(5):                                   # batch_size 2 -> batches of 2, 2, 1 (the last one skipped)
+        m = np.zeros((64, 64), np.uint8)
+        m[10 + 4 * i:50, 8:40 + 3 * i] = 1
+        Image.fromarray(_to_png_u8(torch.from_numpy(m).float().unsqueeze(0).expand(3, -1, -1))).save(tmp_path / "pseudo_masks_t1" / f"{i}.png")
+        Image.fromarray(_to_png_u8(torch.from_numpy(rng.rand(3, 64, 64).astype(np.float32)))).save(tmp_path / "images_t1" / f"{i}.png")
+    logs = []
+    val = [(torch.rand(1, 3, 64, 64), (torch.tensor([0]), torch.randint(1, 4, (1, 64, 64))))]
+    torch.manual_seed(0)
+    model, final_loss = train_segmentation_model(loss_fn, "t1", 1e-4, 2, 2, 0.2, out_root=str(tmp_path), device=dev,
+                                                 val_loader=val, seed=3, log=logs.append)
+    assert isinstance(model, SegmentationModel) and np.isfinite(final_loss) and final_loss > 0
+    assert sum("Epoch" in x for x in logs) == 2 and sum("Validation IoU" in x for x in logs) == 2
+    assert "[Run t1] Epoch 2/2" in " ".join(logs)
+    with pytest.raises(ValueError):
+        train_segmentation_model("dice", "t1", out_root=str(tmp_path), device=dev)
+
+
+def test_amax_slot_pools_roll_over_per_stream(dev, cam_models):
+    """amax slots come from one zero-initialised pool per (device, stream).  With a pool of 8 slots
+    every CAM batch rolls its lane's pool over several times while the other lanes are busy: the three-lane results
+    must still be the serial ones bit for bit (a pool shared between streams could have a lane's memset wipe - or
+    pre-date - a slot another lane is publishing into), and a training step stays deterministic."""
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import LayerCAMGenerator
+    _ref, mine = cam_models
+    g = torch.Generator().manual_seed(41)
+    batches = [torch.rand(2, 3, 224, 224, generator=g).to(dev) for _ in range(6)]
+    classes = [torch.randint(0, 37, (2,), generator=g).to(dev) for _ in range(6)]
+    gen = LayerCAMGenerator(mine, ["layer3", "layer4"])
+    serial = [gen.generate_batch(b, 1.0, c, thresh=0.3) for b, c in zip(batches, classes)]
+    torch.cuda.synchronize()
+    old = ops.AMAX_POOL_SLOTS[0]
+    ops.AMAX_POOL_SLOTS[0] = 8
+    try:
+        ops.reset_amax_pool(dev)
+        for _ in range(2):
+            many = gen.generate_batches(batches, 1.0, classes, 0.3, streams=3)
+            torch.cuda.synchronize()
+            for (c1, m1), (c2, m2) in zip(serial, many):
+                assert torch.equal(c1, c2) and torch.equal(m1, m2)
+        pools = [k for k in ops._amax_pools if k[0] == dev]
+        assert len(pools) >= 3                                      # one per lane stream (plus the main stream's)
+    finally:
+        ops.AMAX_POOL_SLOTS[0] = old
+        ops.reset_amax_pool(dev)
+    # a cached amax is dropped when the tensor is modified in place (ADVICE r2 low)
+    x = torch.randn(2, 64, 16, 16, device=dev)
+    a1 = ops.amax_of(x).item()
+    x.mul_(8.0)
+    a2 = ops.amax_of(x).item()
+    assert abs(a2 - 8.0 * a1) <= 1e-6 * a2 and abs(a1 - x.abs().max().item() / 8.0) <= 1e-6 * a1
+
+
+def test_outputs_dict_resolves_lazy_entries_everywhere(dev, seg_models):
+    """the result of ``forward`` behaves like torchvision's OrderedDict for every read access."""
+    _, mine = seg_models
+    x = torch.randn(2, 3, 64, 64, device=dev)
+    mine.eval()
+    with torch.no_grad():
+        out = mine(x)
+        assert "aux" in out and out.get("aux") is not None and tuple(out.get("aux").shape) == (2, 21, 64, 64)
+        assert out.get("nope", 5) == 5
+        out2 = mine(x)
+        c = out2.copy()
+        assert set(c) == {"out", "aux"} and torch.equal(c["aux"], out["aux"])
+        out3 = mine(x)
+        a = out3.pop("aux")
+        assert torch.equal(a, out["aux"]) and "aux" not in out3 and len(out3) == 1
+    mine.train()
+    o = mine(x)                                  # train mode: the aux head runs on the side stream
+    sd = mine.state_dict()                       # ... and state_dict() waits for it before reading its running statistics
+    torch.cuda.synchronize()
+    assert torch.isfinite(sd["aux_classifier.1.running_var"]).all() and tuple(o["aux"].shape) == (2, 21, 64, 64)
+
+
+def test_zz_relu_flip_fallback_usage():
+    """Runs last in this module: how often did a gradient comparison need the ReLU-flip branch, and by how much?
+    Written to gpurun_out/relu_flips.json when that directory exists; every logged comparison must meet the tight
+    sparse-deviation bound (<= max(0.1 % of the elements, 8) beyond 1e-3, rms <= 3e-3, max <= 5e-2)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "relu_flips.json"), "w") as f:
+            json.dump({"comparisons": FLIP_CALLS[0], "fallbacks": FLIP_LOG}, f, indent=1)
+    print("ReLU-flip branch: %d of %d gradient comparisons" % (len(FLIP_LOG), FLIP_CALLS[0]))
+    for r in FLIP_LOG:
+        print("  %-60s numel %8d  beyond tol %6d (%.4f %%)  rms %.2e  max %.2e  %s" %
+              (r["what"], r["numel"], r["nbad"], 100 * r["frac"], r["rms"], r["max"], "ok" if r["ok"] else "TOO LARGE"))
+    assert all(r["ok"] for r in FLIP_LOG), [r for r in FLIP_LOG if not r["ok"]]
+    assert len(FLIP_LOG) <= max(4, 0.02 * FLIP_CALLS[0]), (len(FLIP_LOG), FLIP_CALLS[0])

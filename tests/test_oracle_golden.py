@@ -287,3 +287,79 @@ def test_lovasz_softmax_loss_and_grad(golden):
         loss.backward()
         _close(loss.detach(), g[f"lov{i}_loss"], rel=1e-5)
         _close(p.grad, g[f"lov{i}_grad"], rel=1e-5)
+
+
+def _bottleneck_from_fixture(g, i, meta, make_block, make_conv, make_bn, make_seq):
+    m = meta[i]
+    ds = None
+    if m["downsample"]:
+        ds = make_seq(make_conv(m["inplanes"], m["planes"] * 4, 1, m["stride"]), make_bn(m["planes"] * 4))
+    blk = make_block(m["inplanes"], m["planes"], m["stride"], 1, ds)
+    pre = f"b{i}/state/"
+    blk.load_state_dict({k[len(pre):]: T(g[k]).clone() for k in g.files if k.startswith(pre)})
+    return blk
+
+
+def test_bottleneck_matches_the_references_vendored_block(golden):
+    """The one piece of network code the reference holds itself - ``Bottleneck`` in
+    PretrainedBasnetModel/model/resnet_model.py:99-135 (vendored from torchvision; stride on the 3x3 = the v1.5 wiring
+    torchvision's resnet50 / deeplabv3_resnet50 use, no dilation argument) - pins ``oracle.models.Bottleneck`` at
+    dilation 1: train-mode forward, input gradient, every parameter gradient, the running statistics written by the
+    forward, and the eval-mode forward, for the identity shortcut and both projection-shortcut forms."""
+    g = golden("bottleneck")
+    meta = json.loads(str(g["meta"]))
+    assert [(m["stride"], m["downsample"]) for m in meta] == [(1, False), (1, True), (2, True)]
+    for i in range(len(meta)):
+        blk = _bottleneck_from_fixture(
+            g, i, meta, oracle.models.Bottleneck,
+            lambda ci, co, k, s: nn.Conv2d(ci, co, k, stride=s, bias=False), nn.BatchNorm2d, nn.Sequential).train()
+        x = T(g[f"b{i}/x"]).clone().requires_grad_()
+        y = blk(x)
+        y.backward(T(g[f"b{i}/dy"]))
+        _close(y.detach(), g[f"b{i}/y"], rel=1e-5)
+        _close(x.grad, g[f"b{i}/dx"], rel=1e-5)
+        for k, p in blk.named_parameters():
+            _close(p.grad, g[f"b{i}/grad/{k}"], rel=1e-5)
+        for k, v in blk.state_dict().items():
+            if "running" in k:
+                _close(v, g[f"b{i}/after/{k}"], rel=1e-6)
+        _close(blk.eval()(x.detach()).detach(), g[f"b{i}/y_eval"], rel=1e-5)
+
+
+def test_eval_helpers_follow_the_reference_procedures(golden):
+    """``evaluate_classification`` (ClassificationModel.py:109-150) and ``evaluate_layercam_on_test_set``
+    (LayerCAM.py:84-130) of the PRODUCT against outputs of the reference's own function bodies on stub inputs
+    (tests/golden/make_golden.py gen_eval_helpers).  Both are host-side metric procedures around a model / generator
+    call, so with stubs they run without a GPU: accuracy and macro-F1; threshold, trimap == 1, nearest resize, the
+    11-image cap, IoU / accuracy averaging."""
+    from weaklysuperviseddl_amd.TraditionalModel import evaluate_classification, evaluate_layercam_on_test_set
+    g = golden("eval_helpers")
+    logits, labels = T(g["cls_logits"]), T(g["cls_labels"])
+
+    class Stub(nn.Module):
+        k = 0
+
+        def forward(self, x):
+            self.k += 1
+            return logits[self.k - 1], None
+
+    loader = [(torch.zeros(logits.shape[1], 1), (labels[k], None)) for k in range(logits.shape[0])]
+    acc, f1 = evaluate_classification(Stub(), loader, "cpu", num_classes=37, log=None)
+    assert abs(acc - g["cls_acc_f1"][0]) < 1e-9 and abs(f1 - g["cls_acc_f1"][1]) < 1e-6
+
+    cams, tri, tri_small, lab = T(g["cam_maps"]), T(g["cam_tri"]).long(), T(g["cam_tri_small"]).long(), T(g["cam_labels"])
+
+    class Gen:
+        k = 0
+
+        def generate_batch(self, x, alpha, cls, thresh=None):
+            self.k += 1
+            cam = cams[self.k - 1:self.k].clone()
+            return cam, ((cam >= thresh) & (cam > 0)).to(torch.uint8)       # the fused threshold of wsdl_layercam_epilogue
+
+    n = cams.shape[0]
+    test_loader = [(torch.zeros(1, 3, 56, 56), (lab[k:k + 1], (tri_small if k % 3 == 2 else tri)[k])) for k in range(n)]
+    gen = Gen()
+    res = evaluate_layercam_on_test_set(gen, test_loader, alpha=1.0, cam_thresh=0.3, device="cpu", log=None)
+    assert gen.k == 11                                                     # LayerCAM.py:119-120
+    assert abs(res["layercam_fg_iou"] - g["cam_iou_acc"][0]) < 1e-9 and abs(res["layercam_fg_acc"] - g["cam_iou_acc"][1]) < 1e-9

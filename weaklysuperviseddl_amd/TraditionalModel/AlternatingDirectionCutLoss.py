@@ -116,10 +116,32 @@ def refine_pseudo_masks_batched(model, images, masks, lambda_boundary=0.1, thres
         return (Xn[:, 1] > threshold).float()
 
 
-def train_model(model, optimizer, train_loader, num_epochs=3, device="cuda", log=print, max_steps_per_epoch=None):
-    """CE-only epochs (the reference's ``train_model``; criterion is nn.CrossEntropyLoss()).  ``train_loader``: a
-    DataLoader of (images, masks[, names]) or a callable returning a fresh iterator per epoch (the in-memory
-    dataset's ``batches``).  Returns the per-epoch summed losses (the number the reference prints)."""
+train_loader = None      # the reference's ``train_model`` reads a module-level ``train_loader`` (AlternatingDirectionCutLoss.py:692,781)
+
+
+def train_model(model, optimizer, criterion_ce=None, num_epochs=3, *, train_loader=None, device="cuda", log=print,
+                max_steps_per_epoch=None):
+    """Reference ``train_model(model, optimizer, criterion_ce, num_epochs=3)`` (AlternatingDirectionCutLoss.py:684-707),
+    same positional signature: CE-only epochs over ``train_loader``.
+
+    ``criterion_ce``: the reference passes ``nn.CrossEntropyLoss()`` (:789) - mapped onto the fused HIP
+    softmax-cross-entropy kernel (``SegmentationModel.resolve_criterion``); None means the same; any other callable is
+    applied to ``(outputs, masks)``.  The loader: keyword ``train_loader`` - a DataLoader of (images, masks[, names]) or a
+    callable returning a fresh iterator per epoch (``InMemoryPseudoDataset.batches``) - or, as in the reference, the
+    module-level ``train_loader`` of this module.  For callers of the earlier form ``train_model(model, optimizer, loader,
+    ...)`` an ITERABLE in the third position (a DataLoader, a list of batches) is still taken as the loader.
+    Returns the per-epoch summed losses (the number the reference prints)."""
+    if train_loader is None and not isinstance(criterion_ce, nn.Module) and \
+            (hasattr(criterion_ce, "__iter__") or hasattr(criterion_ce, "__len__")):
+        train_loader, criterion_ce = criterion_ce, None           # earlier call form: an iterable loader in third position
+    if train_loader is None:
+        train_loader = globals().get("train_loader")
+    if train_loader is None:
+        raise ValueError("train_model: no data - pass train_loader=... or set "
+                         "weaklysuperviseddl_amd.TraditionalModel.AlternatingDirectionCutLoss.train_loader "
+                         "(the reference reads a module-level train_loader, AlternatingDirectionCutLoss.py:692)")
+    from .SegmentationModel import resolve_criterion
+    criterion = None if criterion_ce is None else resolve_criterion(criterion_ce)
     model.train()
     totals = []
     for epoch in range(num_epochs):
@@ -131,7 +153,7 @@ def train_model(model, optimizer, train_loader, num_epochs=3, device="cuda", log
             images, masks = batch[0].to(device), batch[1].to(device)
             if images.size(0) == 1:       # SegmentationModel.py:97-98: BN cannot normalise one pooled value
                 continue
-            total += train_step(model, optimizer, images, masks)
+            total += train_step(model, optimizer, images, masks, criterion=criterion)
         totals.append(total)
         if log:
             log(f"Epoch {epoch + 1}/{num_epochs}, Loss: {total.item():.4f}")
@@ -188,8 +210,9 @@ def run_alternating_training(model, optimizer, dataset, num_alternations=10, epo
             t = torch.tensor([steps], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MIN, group=control_group())
             steps = int(t.item())
-        losses = train_model(model, optimizer, lambda: dataset.batches(bs, shuffle=True, generator=gen, limit=steps),
-                             num_epochs=epochs_per_round, device=device, log=log if rank == 0 else None)
+        losses = train_model(model, optimizer, None, epochs_per_round,
+                             train_loader=lambda: dataset.batches(bs, shuffle=True, generator=gen, limit=steps),
+                             device=device, log=log if rank == 0 else None)
         metrics = evaluate(model) if evaluate is not None else None
         if log and rank == 0 and metrics is not None:
             log(f"Iteration {it + 1}: Evaluation -> {metrics}")

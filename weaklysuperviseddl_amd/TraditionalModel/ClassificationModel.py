@@ -35,18 +35,32 @@ class FrozenResNetCAM(nn.Module):
         return logits, [f2, f3, f4]
 
 
-def train_fc_only(model, dataloader, device="cuda", epochs=10, lr=1e-3, log=print):
-    """Stage 0: reference AlternatingDirectionCutLoss.py:116-141 / ClassificationModel.py:70-106.
+def _is_device(x):
+    return isinstance(x, (str, torch.device, int))
+
+
+def train_fc_only(model, device="cuda", epochs=10, num_classes=37, *, dataloader=None, val_loader=None, lr=1e-3, log=print):
+    """Stage 0: reference ``train_fc_only(model, device, epochs=10, num_classes=37)``
+    (ClassificationModel.py:70-106; notebook AlternatingDirectionCutLoss.py:116-141), same positional signature.
 
     Adam(lr=1e-3) on ``fc`` only with ``nn.CrossEntropyLoss``; ``model.train()`` as in the reference, so the frozen
-    trunk's BatchNorm layers normalise with batch statistics and their running statistics keep drifting.
+    trunk's BatchNorm layers normalise with batch statistics and their running statistics keep drifting; the model is
+    left in eval mode (:106).  The reference builds its loaders from the Oxford-IIIT Pet download (:75-78, network): here
+    they are keyword arguments - ``dataloader`` of ``(imgs, (labels, _))`` batches (required), ``val_loader`` (optional:
+    ``evaluate_classification`` after every epoch, :101-104).
     Per-batch host reads of loss / accuracy are replaced by device accumulators read once per epoch."""
     from .. import ops
     from ..optim import FlatAdam
+    if not _is_device(device):
+        raise TypeError("train_fc_only(model, device, epochs=10, num_classes=37, *, dataloader=...): the second argument is "
+                        "the device, as in the reference; the loader is the keyword `dataloader`")
+    if dataloader is None:
+        raise ValueError("train_fc_only: pass dataloader=... (the reference builds it from the Oxford-IIIT Pet download, "
+                         "ClassificationModel.py:75-78, which needs the network)")
     model.to(device)
-    model.train()
     opt = FlatAdam(list(model.fc.parameters()), lr=lr)
     for epoch in range(epochs):
+        model.train()
         tot_loss = torch.zeros((), device=device)
         correct = torch.zeros((), device=device, dtype=torch.long)
         total = 0
@@ -61,6 +75,39 @@ def train_fc_only(model, dataloader, device="cuda", epochs=10, lr=1e-3, log=prin
             correct += (logits.detach().argmax(dim=1) == labels).sum()
             total += imgs.size(0)
         if log:
-            log(f"Epoch {epoch + 1}/{epochs} - Loss: {tot_loss.item() / total:.4f} - Acc: {100 * correct.item() / total:.2f}%")
+            log(f"Epoch {epoch + 1}/{epochs} - Train Loss: {tot_loss.item() / total:.4f} - Train Acc: {100 * correct.item() / total:.2f}%")
+        if val_loader is not None:
+            val_acc, val_f1 = evaluate_classification(model, val_loader, device, num_classes=num_classes, log=None)
+            if log:
+                log(f"           --> Val Acc: {val_acc:.2f}% - Val F1: {val_f1:.4f}")
     model.eval()
     return model
+
+
+@torch.no_grad()
+def evaluate_classification(model, dataloader, device="cuda", num_classes=37, *, log=print):
+    """Reference ``evaluate_classification(model, dataloader, device, num_classes=37)`` (ClassificationModel.py:109-150):
+    accuracy (per cent) and macro-F1 over the loader's ``(imgs, (labels, _))`` batches, the reference's formulas
+    (precision / recall / F1 with +1e-8 in every denominator, F1 averaged over all ``num_classes`` classes whether
+    present or not).  The per-class true/false positive counts come from one confusion-matrix ``bincount`` per batch on
+    the device instead of 3 x 37 masked sums, and nothing is read back before the end."""
+    model.eval()
+    model.to(device)
+    conf = torch.zeros(num_classes * num_classes, device=device, dtype=torch.long)
+    for imgs, (labels, _) in dataloader:
+        imgs, labels = imgs.to(device), torch.as_tensor(labels).to(device).long().view(-1)
+        logits, _ = model(imgs)
+        preds = logits.argmax(dim=1)
+        conf += torch.bincount(labels * num_classes + preds, minlength=num_classes * num_classes)
+    conf = conf.view(num_classes, num_classes).double()          # [true, predicted]
+    tp = conf.diag()
+    fp = conf.sum(0) - tp
+    fn = conf.sum(1) - tp
+    precision = tp / (tp + fp + 1e-8)
+    recall = tp / (tp + fn + 1e-8)
+    f1 = 2 * precision * recall / (precision + recall + 1e-8)
+    macro_f1 = f1.float().mean().item()
+    acc = 100.0 * tp.sum().item() / max(conf.sum().item(), 1.0)
+    if log:
+        log(f"Evaluation - Accuracy: {acc:.2f}% - F1 Score (macro): {macro_f1:.4f}")
+    return acc, macro_f1

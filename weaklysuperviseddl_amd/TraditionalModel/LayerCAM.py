@@ -120,6 +120,7 @@ class LayerCAMGenerator:
         while len(lanes) < streams:
             lanes.append((torch.cuda.Stream(device=dev),
                           LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged)))
+            ops.register_lane_stream(lanes[-1][0])
         cur = torch.cuda.current_stream(dev)
         outs = []
         for j, (imgs, cls) in enumerate(zip(batches, class_idxs)):
@@ -146,6 +147,42 @@ class LayerCAMGenerator:
         return self.generate_batch(x, float(alpha), class_idx)
 
     __call__ = generate
+
+
+@torch.no_grad()
+def evaluate_layercam_on_test_set(layercam_gen, test_loader, alpha=1.0, cam_thresh=0.3, *, device="cuda", max_images=11,
+                                  log=print):
+    """Reference ``evaluate_layercam_on_test_set(layercam_gen, test_loader, alpha=1.0, cam_thresh=0.3)``
+    (LayerCAM.py:84-130): IoU / pixel accuracy of the thresholded LayerCAM foreground mask against the ground-truth
+    trimap (foreground = class 1), one image - the first of each batch - per batch, over the first 11 batches (the
+    reference breaks after ``i >= 10``, :119-120), nearest resize of the prediction when sizes differ.  Returns
+    ``{"layercam_fg_iou", "layercam_fg_acc"}``.  The threshold is fused into the CAM epilogue kernel; the metric is
+    the host-side ``compute_iou_and_acc`` of the reference."""
+    from .ExtraUtilities import compute_iou_and_acc
+    ious, accs = [], []
+    for i, (img, (label, true_mask)) in enumerate(test_loader):
+        x = img[0].to(device)
+        tm = (true_mask[0].to(device) == 1).long()
+        tm = tm.reshape(tm.shape[-2:])
+        lab = label[0]
+        cls = torch.as_tensor([int(lab.item() if torch.is_tensor(lab) else lab)], device=device)
+        _cam, mask = layercam_gen.generate_batch(x.unsqueeze(0), float(alpha), cls, thresh=cam_thresh)
+        pred = mask[0].long()
+        if pred.shape != tm.shape:
+            # F.interpolate(mode='nearest'): source index = floor(dst * in / out)
+            ih = torch.arange(tm.shape[0], device=device) * pred.shape[0] // tm.shape[0]
+            iw = torch.arange(tm.shape[1], device=device) * pred.shape[1] // tm.shape[1]
+            pred = pred[ih][:, iw]
+        iou, acc = compute_iou_and_acc(pred, tm)
+        ious.append(iou)
+        accs.append(acc)
+        if max_images is not None and i >= max_images - 1:
+            break
+    out = {"layercam_fg_iou": sum(ious) / len(ious), "layercam_fg_acc": sum(accs) / len(accs)}
+    if log:
+        log("\n Evaluation of CAMs on test set:")
+        log(f" - LayerCam FG: Avg IoU: {out['layercam_fg_iou']:.4f} | Acc: {out['layercam_fg_acc']:.4f}")
+    return out
 
 
 class CAMGenerator:

@@ -127,6 +127,46 @@ class _Outputs(OrderedDict):
     def __len__(self):
         return super().__len__() + len(self._lazy)
 
+    # every read access of the dict API resolves the lazy entries first: ``out.get('aux')`` must not answer None for a
+    # key ``'aux' in out`` reports (torchvision returns a plain OrderedDict)
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def pop(self, key, *default):
+        self._resolve(key)
+        return super().pop(key, *default)
+
+    def popitem(self, last=True):
+        self._all()
+        return super().popitem(last)
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        super().__setitem__(key, default)
+        return default
+
+    def __setitem__(self, key, value):
+        if getattr(self, "_lazy", None):
+            self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+    def __delitem__(self, key):
+        if self._lazy.pop(key, None) is None:
+            super().__delitem__(key)
+
+    def copy(self):
+        self._all()
+        return OrderedDict(super().items())
+
+    def __eq__(self, other):
+        self._all()
+        return super().__eq__(other)
+
+    def __repr__(self):
+        self._all()
+        return super().__repr__()
+
 
 class SegmentationModel(nn.Module):
     def __init__(self, num_classes=2, aux_loss=True, aux_classes=21):
@@ -141,8 +181,31 @@ class SegmentationModel(nn.Module):
             if isinstance(m, wnn.Conv2d) and m.bias is not None:
                 m.reset_parameters()
 
+    # The train-mode aux head runs on the side stream (forward below) and writes its BatchNorm running statistics there.
+    # A training step joins that stream before Adam; a train-mode forward WITHOUT a step (BatchNorm recalibration, a
+    # loss-only validation pass) does not - so every place that reads those buffers on another stream joins first.
+    def _join_aux(self):
+        ev = self.__dict__.get("_aux_event")
+        if ev is not None:
+            self.__dict__["_aux_event"] = None
+            if not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream().wait_event(ev)      # the event sits right behind the aux head: not the whole side stream
+
+    def train(self, mode=True):
+        self._join_aux()
+        return super().train(mode)
+
+    def state_dict(self, *args, **kwargs):
+        self._join_aux()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._join_aux()
+        return super().load_state_dict(*args, **kwargs)
+
     def forward(self, x):
         size = x.shape[-2:]
+        self._join_aux()              # a previous forward's aux head may still be writing the statistics read / written now
         feats = self.backbone(x)
         res = _Outputs()
         if self.aux_classifier is not None and self.training and x.is_cuda and _AUX_ON_SIDE_STREAM and \
@@ -156,6 +219,9 @@ class SegmentationModel(nn.Module):
             f3.record_stream(side)
             with torch.cuda.stream(side):
                 aux_out = ops.bilinear_resize(self.aux_classifier(f3), size)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            self.__dict__["_aux_event"] = ev
 
             def joined():
                 torch.cuda.current_stream(x.device).wait_stream(side)
@@ -183,12 +249,33 @@ def build_segmentation_model(num_classes=2, aux_loss=True):
     return SegmentationModel(num_classes=num_classes, aux_loss=aux_loss, aux_classes=21)
 
 
-def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_entropy"):
+def resolve_criterion(criterion):
+    """What a reference-style ``criterion`` object means on the HIP path.  ``nn.CrossEntropyLoss()`` (the only criterion
+    the reference constructs: SegmentationModel.py:90, AlternatingDirectionCutLoss.py:789) maps onto the fused
+    softmax-cross-entropy kernel with its ``ignore_index``; options the kernel does not implement raise instead of being
+    dropped silently.  Any other callable is applied to ``(outputs, masks)`` as it is."""
+    if criterion is None:
+        return lambda o, m: ops.cross_entropy(o, m.long())
+    if isinstance(criterion, nn.CrossEntropyLoss):
+        if criterion.weight is not None or criterion.reduction != "mean" or getattr(criterion, "label_smoothing", 0.0) != 0.0:
+            raise ValueError("train_step: nn.CrossEntropyLoss with class weights, a reduction other than 'mean' or label "
+                             "smoothing is not implemented by wsdl_softmax_ce_fwd_bwd (the reference uses the defaults)")
+        ign = int(criterion.ignore_index)
+        return lambda o, m: ops.cross_entropy(o, m.long(), ign)
+    if callable(criterion):
+        return criterion
+    raise TypeError(f"criterion: expected nn.CrossEntropyLoss, a callable or None, got {type(criterion).__name__}")
+
+
+def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_entropy", criterion=None):
     """One training iteration; returns the (device) loss tensor, no host synchronisation.  ``loss_fn``: 'cross_entropy' or
-    'lovasz_softmax' (reference SegmentationModel.py:65,103-107)."""
+    'lovasz_softmax' (reference SegmentationModel.py:65,103-107); ``criterion``: a reference-style loss object instead
+    (``resolve_criterion``)."""
     masks = torch.clamp(masks, max=1)
     outputs = model(images)["out"]
-    if loss_fn == "lovasz_softmax":
+    if criterion is not None:
+        loss = resolve_criterion(criterion)(outputs, masks)
+    elif loss_fn == "lovasz_softmax":
         loss = ops.lovasz_softmax(ops.softmax_channels(outputs), masks.long(), classes="present", per_image=False, ignore=None)
     elif loss_fn == "cross_entropy":
         loss = ops.cross_entropy(outputs, masks.long())
@@ -270,3 +357,51 @@ def evaluate_model(model, loader, device="cuda", binarize="notebook"):
         ious.append(iou)
         accs.append(acc)
     return sum(ious) / len(ious), sum(accs) / len(accs)
+
+
+def train_segmentation_model(loss_fn, run_id, lr=1e-4, num_epochs=10, batch_size=4, val_split=0.2, *, out_root="/content",
+                             device="cuda", val_loader=None, num_workers=0, seed=None, log=print, model=None):
+    """Reference ``train_segmentation_model(loss_fn, run_id, lr=1e-4, num_epochs=10, batch_size=4, val_split=0.2)``
+    (TraditionalModel/SegmentationModel.py:59-122), same positional signature, returns ``(model, final_loss)``.
+
+    Trains DeepLabV3-ResNet50 (``build_segmentation_model``) with Adam(lr) on the pseudo masks of run ``run_id`` -
+    ``{out_root}/images_{run_id}`` / ``{out_root}/pseudo_masks_{run_id}``, what ``generate_pseudo_masks`` wrote - with
+    ``loss_fn`` 'cross_entropy' or 'lovasz_softmax'; batches of one image are skipped (:97-98), masks clamped to {0,1} (:100).
+
+    Where the reference's text cannot run, the working notebook decides: the reference builds the
+    pseudo-mask dataset (:73-77) and then trains on ``load_split_data()`` (:80-83), whose items are not (image, mask)
+    pairs; AlternatingDirectionCutLoss.py:775-781 trains on ``PseudoSegmentationDataset`` - so does this.  ``val_split`` is
+    accepted and, as in the reference (which never reads it), unused; the per-epoch validation of :118-119 runs when a
+    ``val_loader`` of ``(img, (label, trimap))`` items is given (the reference takes it from the Oxford-IIIT Pet download,
+    which needs the network).  Keyword-only extras: the directories' root (the reference hard-codes /content), the
+    device, an existing model to continue from."""
+    from torch.utils.data import DataLoader
+    from .SegmentationDataset import PseudoSegmentationDataset
+    if loss_fn not in ("cross_entropy", "lovasz_softmax"):
+        raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
+    import os as _os
+    image_dir = _os.path.join(out_root, f"images_{run_id}")
+    mask_dir = _os.path.join(out_root, f"pseudo_masks_{run_id}")
+    full_dataset = PseudoSegmentationDataset(img_dir=image_dir, mask_dir=mask_dir, transform=True)
+    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    train_loader = DataLoader(full_dataset, batch_size=batch_size, shuffle=True, num_workers=num_workers, generator=gen)
+    if model is None:
+        model = build_segmentation_model(num_classes=2)
+    model = model.to(device)
+    optimizer = make_optimizer(model, lr=lr)
+    final_loss = 0.0
+    for epoch in range(num_epochs):
+        model.train()
+        total = torch.zeros((), device=device)
+        for images, masks in train_loader:
+            if images.size(0) == 1:
+                continue
+            total += train_step(model, optimizer, images.to(device), masks.to(device), loss_fn=loss_fn)
+        final_loss = total.item()                       # one host read per epoch (the reference: one per step)
+        if log:
+            log(f"[Run {run_id}] Epoch {epoch + 1}/{num_epochs}, Loss: {final_loss:.4f}")
+        if val_loader is not None:
+            avg_iou, avg_acc = evaluate_model(model, val_loader, device=device, binarize="modular")
+            if log:
+                log(f"[Run {run_id}] Validation IoU: {avg_iou:.4f}, Accuracy: {avg_acc:.4f}")
+    return model, final_loss

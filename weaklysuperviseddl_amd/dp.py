@@ -22,7 +22,15 @@ than one process):
     bitmap over a host-side (gloo) control group in every ``wait()``; bucket ranges, the set of parameters cut
     out of their bucket and the "late" list are all derived from the agreed bitmap, never from local firing;
   * a parameter counts once per step (a second firing - a weight used twice - does not launch its bucket early);
-    a gradient that arrives after its bucket has left raises unless it is inside ``no_sync()``;
+    a gradient that arrives after its bucket has left is an error unless it is inside ``no_sync()`` - recorded by the
+    hook, carried as a flag in the control exchange and raised by EVERY rank from ``wait()`` (a hook raising on one
+    rank alone would leave its peers inside the next collective);
+  * the control exchange is off the step's critical path once the firing set has settled: after ``STEADY_AFTER``
+    consecutive steps with one and the same agreed set, ``wait()`` stops blocking on it - each step's bitmap goes out
+    asynchronously and is looked at one step later (it completed long ago), the step itself assumes the settled set.
+    A rank whose firing deviates in that mode keeps to the settled collective sequence (a gradient for a cut-out
+    parameter is held back, not applied unreduced); every rank sees the deviation in the same ``wait()`` one step later,
+    all return to the blocking exchange together, and the held-back gradient joins that step's reduction;
   * per-replica BatchNorm statistics are the design: ``average_bn_buffers`` averages the running
     statistics over the ranks, for the moment a state_dict is saved; dropout seeds differ per rank
     (``ops.DROPOUT_SEED_OFFSET``).
@@ -106,6 +114,8 @@ def average_bn_buffers(modules, group=None):
         return
     world = dist.get_world_size(group)
     for m in modules:
+        if hasattr(m, "_join_aux"):
+            m._join_aux()               # the train-mode aux head writes its running statistics on the side stream
         for b in m.buffers():
             if b.is_floating_point():
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group)
@@ -115,7 +125,7 @@ def average_bn_buffers(modules, group=None):
 
 
 class GradBucketReducer:
-    def __init__(self, optimizer, process_group=None, num_buckets=4, modules=(), sync_state=True):
+    def __init__(self, optimizer, process_group=None, num_buckets=4, modules=(), sync_state=True, steady_after=None):
         self.opt = optimizer
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -167,9 +177,20 @@ class GradBucketReducer:
         self._remaining = list(self.bucket_size)
         self._accumulating = False
         self._hooks = {}
+        if steady_after is not None:
+            self.STEADY_AFTER = int(steady_after)      # 0: always the blocking exchange (a late gradient is reduced in its own step)
+        self._error = None                 # first hook error of this step (raised by every rank from wait())
+        self._steady = False               # True: the control exchange is asynchronous, one step behind (module docstring)
+        self._steady_set = None
+        self._stable_steps = 0
+        self._last_agreed = None
+        self._ctl_work = self._ctl_buf = None
+        self._held = {}                    # steady mode: gradients of cut-out parameters that fired here, held back one step
+        self.control_exchanges_blocking = 0
+        self.control_exchanges_async = 0
         if self.active:
             self._control = control_group(process_group)
-            self._bitmap = torch.zeros(nparams, dtype=torch.uint8)
+            self._bitmap = torch.zeros(nparams + 1, dtype=torch.uint8)          # last byte: error flag
             if sync_state:
                 sync_initial_state(optimizer, modules, process_group)
             self._index = {id(p): i for i, p in enumerate(optimizer.params)}
@@ -201,18 +222,21 @@ class GradBucketReducer:
             # of a step counts; the other source's echo is dropped.
             if self._accumulating:
                 return
+            # errors are RECORDED here and raised from wait() on every rank together (the flag travels in the control
+            # exchange): an exception out of one rank's autograd hook would leave the peers inside the next collective
             if i in self._fired:
-                if self._fired[i] == src and self._launched[b] and i not in self._excluded:
-                    raise RuntimeError(
-                        f"GradBucketReducer: a second gradient for parameter {i} {tuple(_p.shape)} arrived after its "
-                        "bucket's all-reduce had been launched (a second backward before step()?).  Wrap all but the "
-                        "last backward in reducer.no_sync().")
+                if self._fired[i] == src and self._launched[b] and i not in self._excluded and self._error is None:
+                    self._error = (f"a second gradient for parameter {i} {tuple(_p.shape)} arrived after its bucket's "
+                                   "all-reduce had been launched (a second backward before step()?).  Wrap all but the "
+                                   "last backward in reducer.no_sync().")
                 return
             self._fired[i] = src
             if i in self._excluded:            # reduced on its own at the join (not part of the bucket's collective)
                 return
             if self._launched[b]:
-                raise RuntimeError("GradBucketReducer: gradient for an already reduced bucket (see no_sync())")
+                if self._error is None:
+                    self._error = f"gradient for parameter {i} of an already reduced bucket (see no_sync())"
+                return
             self._remaining[b] -= 1
             self._launch_ready(early=True)
         self._hooks[i] = hook
@@ -254,21 +278,73 @@ class GradBucketReducer:
             return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    STEADY_AFTER = 3       # consecutive steps with one agreed firing set before the control exchange goes asynchronous
+
+    def _local_bitmap(self):
+        bm = self._bitmap
+        bm.zero_()
+        idx = list(self._fired) + list(self._held)
+        if idx:
+            bm[idx] = 1
+        if self._error is not None:
+            bm[-1] = 1
+        return bm
+
+    def _raise_together(self, flagged):
+        if flagged:
+            mine = self._error
+            self._error = None
+            raise RuntimeError("GradBucketReducer: " + (mine or "another rank reported a gradient-ordering error in this "
+                                                        "step (see its message); every rank stops here together"))
+
     def _agree(self):
         """MAX over the ranks of the local firing bitmap (host-side control group): the one source of truth for what
-        this step reduces beyond the buckets and for next step's ranges."""
-        self._bitmap.zero_()
-        if self._fired:
-            self._bitmap[list(self._fired)] = 1
-        dist.all_reduce(self._bitmap, op=dist.ReduceOp.MAX, group=self._control)
-        return set(torch.nonzero(self._bitmap).flatten().tolist())
+        this step reduces beyond the buckets and for next step's ranges.  Blocking; also carries the error flag."""
+        bm = self._local_bitmap()
+        dist.all_reduce(bm, op=dist.ReduceOp.MAX, group=self._control)
+        self.control_exchanges_blocking += 1
+        self._raise_together(bool(bm[-1]))
+        return set(torch.nonzero(bm[:-1]).flatten().tolist())
+
+    def _join_side(self):
+        opt = self.opt
+        if opt.flat_grad.is_cuda:
+            from . import ops
+            ops.join_side_stream(opt.flat_grad.device)
 
     def wait(self):
         """Launch any bucket whose hooks did not all fire, reduce late gradients of excluded parameters, join, and
         learn which parameters to leave out next step - all from the bitmap every rank agrees on."""
         opt = self.opt
         if self.active:
-            fired = self._agree()
+            if self._steady and self._ctl_work is not None:
+                # last step's exchange: launched a whole step ago, so this does not block in practice
+                self._ctl_work.wait()
+                prev, self._ctl_work = self._ctl_buf, None
+                self._raise_together(bool(prev[-1]))
+                if set(torch.nonzero(prev[:-1]).flatten().tolist()) != self._steady_set:
+                    self._steady, self._stable_steps, self._last_agreed = False, 0, None     # every rank sees this in the same wait()
+            if self._steady:
+                fired = self._steady_set
+                extra = sorted(i for i in self._fired if i in self._excluded)
+                if extra:
+                    self._join_side()                       # their weight gradients were written on the side stream
+                    for i in extra:
+                        off, n = opt.offsets[i], opt.params[i].numel()
+                        g = opt.flat_grad[off:off + n]
+                        self._held[i] = self._held[i] + g if i in self._held else g.clone()
+                        g.zero_()                           # not applied unreduced: it joins the reduction one step later
+                self._ctl_buf = self._local_bitmap().clone()
+                self._ctl_work = dist.all_reduce(self._ctl_buf, op=dist.ReduceOp.MAX, group=self._control, async_op=True)
+                self.control_exchanges_async += 1
+            else:
+                if self._held:
+                    self._join_side()
+                    for i, g in self._held.items():         # held back in steady mode: part of THIS step's reduction
+                        off, n = opt.offsets[i], opt.params[i].numel()
+                        opt.flat_grad[off:off + n] += g
+                fired = self._agree()
+                self._held = {}
             self._launch_ready(early=False)
             late = sorted(self._excluded & fired)
             if late and self._early:
@@ -277,35 +353,56 @@ class GradBucketReducer:
                     "one; their segments have already been stepped with the unreduced values.  Set optimizer.early_step "
                     "= False and build the reducer on an optimiser without segments for models whose set of trained "
                     "parameters changes from step to step.")
-            if late and opt.flat_grad.is_cuda:
-                from . import ops
-                ops.join_side_stream(opt.flat_grad.device)      # their weight gradients were written on the side stream
+            if late:
+                self._join_side()                           # their weight gradients were written on the side stream
             for i in late:
                 off, n = opt.offsets[i], opt.params[i].numel()
                 self._all_reduce(opt.flat_grad[off:off + n])
             if not self._early:
                 for w in self._pending:
                     w.wait()
-                if opt.flat_grad.is_cuda:
-                    from . import ops
-                    ops.join_side_stream(opt.flat_grad.device)      # the collectives were enqueued from the side stream
+                self._join_side()                           # the collectives were enqueued from the side stream
             # (early segment steps: every collective has been waited for on the side stream by the Adam launch behind it; the main
             # stream only waits for those launches - FlatAdam._finish_segments - not for the re-layouts queued after them)
-            # next step: per bucket, drop the unused parameters before the first / after the last used one
-            self._excluded = set()
-            for b in range(len(self.bucket_size)):
-                idx = [i for i, bb in enumerate(self.bucket_of) if bb == b]
-                used = [i for i in idx if i in fired]
-                if not used:
-                    self._excluded.update(idx)
-                    self._range[b] = (self.bounds[b], self.bounds[b])
-                    self._remaining[b] = 0
-                    continue
-                first, last = used[0], used[-1]
-                self._excluded.update(i for i in idx if i < first or i > last)
-                self._range[b] = (opt.offsets[first], opt.offsets[last] + opt.params[last].numel())
-                self._remaining[b] = last - first + 1       # unused parameters INSIDE the range are still waited for
+            if not self._steady:
+                # next step: per bucket, drop the unused parameters before the first / after the last used one
+                self._excluded = set()
+                for b in range(len(self.bucket_size)):
+                    idx = [i for i, bb in enumerate(self.bucket_of) if bb == b]
+                    used = [i for i in idx if i in fired]
+                    if not used:
+                        self._excluded.update(idx)
+                        self._range[b] = (self.bounds[b], self.bounds[b])
+                        self._remaining[b] = 0
+                        continue
+                    first, last = used[0], used[-1]
+                    self._excluded.update(i for i in idx if i < first or i > last)
+                    self._range[b] = (opt.offsets[first], opt.offsets[last] + opt.params[last].numel())
+                    self._remaining[b] = last - first + 1       # unused parameters INSIDE the range are still waited for
+                self._stable_steps = self._stable_steps + 1 if fired == self._last_agreed else 1
+                self._last_agreed = fired
+                if self._stable_steps >= self.STEADY_AFTER and self.STEADY_AFTER > 0:
+                    self._steady, self._steady_set = True, fired
+            else:
+                for b in range(len(self.bucket_size)):          # same ranges as last step: only re-arm the counters
+                    lo, hi = self._range[b]
+                    idx = [i for i, bb in enumerate(self.bucket_of) if bb == b and i not in self._excluded]
+                    self._remaining[b] = (idx[-1] - idx[0] + 1) if (idx and hi > lo) else 0
         self._pending = []
         self._fired = {}
         self._launched = [False] * len(self.bucket_size)
         self.last_early_launches, self.early_launches = self.early_launches, 0
+
+    def comm_budget(self, link_gbs=153.0):
+        """Per bucket: bytes and the time its all-reduce needs on the node's xGMI mesh (each GPU has one link of
+        ~``link_gbs`` GB/s to each of the other world-1): ``ring_us`` = 2 (N-1)/N x bytes through ONE link,
+        ``direct_us`` = reduce-scatter + all-gather over all N-1 links at once = 2 x bytes / N per link.  The bucket left
+        exposed at the end of backward is the first (smallest) one; every other bucket overlaps the remaining backward."""
+        n = max(self.world, 1)
+        out = []
+        for b, (lo, hi) in enumerate(self._range):
+            nbytes = 4 * (hi - lo)
+            out.append({"bucket": b, "bytes": nbytes,
+                        "ring_us": round(2 * (n - 1) / n * nbytes / (link_gbs * 1e3), 1) if n > 1 else 0.0,
+                        "direct_us": round(2 * nbytes / n / (link_gbs * 1e3), 1) if n > 1 else 0.0})
+        return out

@@ -74,7 +74,11 @@ class GraphedTrainStep:
     def __call__(self, images, masks):
         """One training iteration on (images, masks); returns the (device) loss, like ``train_step``."""
         self.calls += 1
-        key = (tuple(images.shape), tuple(masks.shape), images.device, self.model.training)
+        # the Adam launch takes lr / betas / eps / grad_scale as kernel ARGUMENTS, frozen into the captured node: a scheduler,
+        # a manual decay or a data-parallel reducer changing one of them must trigger a new capture, not be ignored
+        opt = self.opt
+        key = (tuple(images.shape), tuple(masks.shape), images.device, self.model.training,
+               float(opt.lr), tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale))
         if self.calls <= self.warmup or not self.model.training:
             return self._eager(images, masks)
         if self.graph is None or key != self.key:

@@ -185,26 +185,55 @@ def set_option(name, value):
 # Tensors that arrive without one (the network input, concatenations, dropout outputs, views) get a read pass
 # (``wsdl_amax``) the first time a split convolution consumes them.
 _amax_pools = {}
+AMAX_POOL_SLOTS = [4096]      # slots per pool (tests shrink it to force roll-overs)
 
 
 def amax_slot(device):
-    """A zero-initialised one-element fp32 view (slots are handed out once; a pool of 4096 is one memset)."""
-    pool = _amax_pools.get(device)
+    """A zero-initialised one-element fp32 view (slots are handed out once; a pool of 4096 is one memset).
+
+    One pool per (device, STREAM), like ``workspace()``: the pool's memset is ordered on the stream that allocates it,
+    and a slot's first use - the producing kernel's atomicMax into the zeroed slot - is enqueued on that same stream,
+    so a roll-over on one stream (a CAM lane, the side stream's aux head) can neither wipe nor pre-date a slot another
+    stream is publishing into.  Consumers on other streams read a slot only behind the stream join that orders them
+    after its producer (the weight-gradient kernels on the side stream: ``side.wait_stream(main)``)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    pool = _amax_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
-        buf = torch.zeros(4096, device=device, dtype=torch.float32)
+        buf = torch.zeros(AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32)
         if not torch.cuda.is_current_stream_capturing():
-            buf.record_stream(side_stream(device))    # read by weight-gradient kernels on the side stream
+            # slots are read by kernels on the other streams of this library (weight gradients on the side stream, the
+            # main stream joining a CAM lane): keep the caching allocator from recycling a retired pool under them
+            for st in [_side_streams.get(device)] + [lane for lane in _lane_streams.get(device, [])]:
+                if st is not None:
+                    buf.record_stream(st)
+            buf.record_stream(torch.cuda.default_stream(device))
         pool = [buf, 0]
-        _amax_pools[device] = pool
+        _amax_pools[key] = pool
     i = pool[1]
     pool[1] += 1
     return pool[0][i:i + 1]
 
 
+_lane_streams = {}     # device -> extra streams of this library that may read amax slots (LayerCAM lanes)
+
+
+def register_lane_stream(stream):
+    _lane_streams.setdefault(stream.device, []).append(stream)
+
+
+def _publish_amax(t, slot):
+    """Attach a producer-published amax scalar to the tensor it bounds, with the tensor's version: a later in-place
+    modification (``t.mul_()``, ``buf.copy_()``) makes ``amax_of`` measure again instead of trusting a stale bound."""
+    t._wsdl_amax = slot
+    t._wsdl_amax_version = t._version
+
+
 def reset_amax_pool(device):
-    """Forget the current slot pool: the next request allocates (and zeroes) a new one - graph.py brackets a capture
-    with it so that the captured step's slots are re-zeroed by every replay."""
-    _amax_pools.pop(device if isinstance(device, torch.device) else torch.device(device), None)
+    """Forget the current slot pools of ``device``: the next request allocates (and zeroes) a new one - graph.py brackets a
+    capture with it so that the captured step's slots are re-zeroed by every replay."""
+    device = device if isinstance(device, torch.device) else torch.device(device)
+    for key in [k for k in _amax_pools if k[0] == device]:
+        _amax_pools.pop(key, None)
 
 
 def _split_kc(kc, taps):
@@ -218,6 +247,8 @@ def amax_of(t, needed=True):
     if not needed:
         return None
     a = getattr(t, "_wsdl_amax", None)
+    if a is not None and getattr(t, "_wsdl_amax_version", t._version) != t._version:
+        a = None                 # modified in place since the bound was taken (copy_ into a reused buffer, mul_): measure again
     if a is None:
         tt, bs = _planes(t, "amax input") if t.dim() == 4 else (_dense(t, "amax input"), 0)
         a = amax_slot(t.device)
@@ -226,6 +257,7 @@ def amax_of(t, needed=True):
         check(lib().wsdl_amax(_p(tt), B, per, bs if tt.dim() == 4 else per, _p(a), 0, _stream()))    # the slot is zeroed
         try:
             t._wsdl_amax = a
+            t._wsdl_amax_version = t._version
         except AttributeError:
             pass
     return a
@@ -315,7 +347,7 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
                                 _p(scale), _p(shift), _p(residual), int(relu), x_bs, y_bs, res_bs, _p(x_amax), _p(y_amax),
                                 _p(ws), ws.numel() if ws is not None else 0, _stream()))
     if y_amax is not None:
-        out._wsdl_amax = y_amax
+        _publish_amax(out, y_amax)
     return out
 
 
@@ -404,7 +436,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
                                   _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
                                   int(relu), y_bs, _p(y_amax), _p(ws), ws.numel(), _stream()))
     if y_amax is not None:
-        out._wsdl_amax = y_amax
+        _publish_amax(out, y_amax)
     return out, mean, invstd
 
 
@@ -437,7 +469,7 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, mode, int(acc), dy_bs, y_bs,
                                   _p(dx_amax), _p(ws), ws.numel(), _stream()))
     if dx_amax is not None:
-        dx._wsdl_amax = dx_amax
+        _publish_amax(dx, dx_amax)
     dx._wsdl_fresh = True
     if dres is not None:
         dres._wsdl_fresh = True
@@ -464,7 +496,7 @@ def affine_act_bwd(dy, y, scale, relu, want_dconv=True, want_dres=False):
     check(lib().wsdl_affine_act_bwd(_p(dy), _p(_dense(y) if relu else None), _p(scale), _p(dconv), _p(dres), B, Cc,
                                     H * W, int(relu), _p(amax), _stream()))
     if amax is not None:
-        dconv._wsdl_amax = amax
+        _publish_amax(dconv, amax)
     return dconv, dres
 
 
@@ -545,7 +577,7 @@ class _ConvBNAct(torch.autograd.Function):
         if passthrough:
             xv = x.view_as(x)
             if x_amax is not None:
-                xv._wsdl_amax = x_amax
+                _publish_amax(xv, x_amax)
             return y, xv
         return y
 
@@ -716,8 +748,8 @@ class _MaxPool3x3s2(torch.autograd.Function):
         check(lib().wsdl_maxpool3x3s2_fwd(_p(x), _p(y), _p(am), B * Cc, H, W, _stream()))
         ctx.save_for_backward(am)
         ctx.xshape = tuple(x.shape)
-        if getattr(x, "_wsdl_amax", None) is not None:
-            y._wsdl_amax = x._wsdl_amax          # max over windows of x: the input's bound holds (x >= 0 after ReLU or not)
+        if getattr(x, "_wsdl_amax", None) is not None and getattr(x, "_wsdl_amax_version", x._version) == x._version:
+            _publish_amax(y, x._wsdl_amax)       # max over windows of x: the input's bound holds (x >= 0 after ReLU or not)
         return y
 
     @staticmethod
