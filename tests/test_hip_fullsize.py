@@ -336,7 +336,7 @@ def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
             raw1 = ((cam1 >= 0.3) & (cam1 > 0)).cpu().numpy()
             d = torch.from_numpy(raw1 != (mk[i] != 0))
             band = 2.0 * (cam1 - cam[i]).abs().max().item() + 1e-6
-            assert band < 1e-3 and ((cam[i].cpu() - 0.3).abs()[d] <= band).all(), (k, int(d.sum()), band)
+            assert band < 4e-3 and ((cam[i].cpu() - 0.3).abs()[d] <= band).all(), (k, int(d.sum()), band)
             k += 1
     # the hand-off's masks are the NEAREST resize of the stage-1 masks
     from weaklysuperviseddl_amd.TraditionalModel.PsuedoMasks import nearest_resize_index

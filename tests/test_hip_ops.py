@@ -173,7 +173,8 @@ def test_split_arithmetic_max_norm_per_channel_and_per_block(dev, data):
                   outlier read operands 2^20 below the tensor maximum, i.e. with 2^-19 relative representation error -
                   the documented floor.  Asserted: every region <= 2^-17 (7.6e-6, two orders inside north_star's 1e-3) and
                   the figure is printed beside the fp32 kernels';
-      wide      - channel magnitudes spanning seven decades (the rms test's data): same bound."""
+      wide      - channel magnitudes spanning seven decades (the rms test's data): as unit (the small channels contribute
+                  nothing visible to any output region, the large ones keep their 22 bits)."""
     from weaklysuperviseddl_amd import ops
     g = torch.Generator().manual_seed(78)
     worst = {}
@@ -208,11 +209,9 @@ def test_split_arithmetic_max_norm_per_channel_and_per_block(dev, data):
     for (Cin, k, name, mode), (ch, blk) in worst.items():
         if mode == "fp16x2":
             f_ch, f_blk = worst[(Cin, k, name, "fp32")]
-            bound_ch, bound_blk = (4 * f_ch + 1e-7, 4 * f_blk + 1e-7) if data == "unit" else (2.0 ** -17, 2.0 ** -17)
-            if data == "wide":
-                # a channel (block) whose own maximum is tiny is compared with its own maximum: exact to 2^-39 of the
-                # TENSOR maximum means relative to the region up to (tensor max / region max) x 2^-39
-                bound_ch = bound_blk = 1e-3
+            # measured (GPUTEST r3): unit / wide 0.5-0.9 x the fp32 kernels' figure in every region; outlier20 worst block
+            # 1.2e-6 - 1.5e-6 against 5e-7 - 8e-7 (the 2^-19 floor of operands 2^20 below the tensor maximum, averaged over K)
+            bound_ch, bound_blk = (2.0 ** -17, 2.0 ** -17) if data == "outlier20" else (4 * f_ch + 1e-7, 4 * f_blk + 1e-7)
             assert ch <= bound_ch and blk <= bound_blk, (data, Cin, k, name, ch, blk, f_ch, f_blk)
 
 
