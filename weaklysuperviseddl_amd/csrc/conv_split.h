@@ -366,10 +366,15 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e) {
             const float x0 = __builtin_bit_cast(float, rb[2 * e]), x1 = __builtin_bit_cast(float, rb[2 * e + 1]);
+#ifdef WSDL_EXP_NOSPLIT      // timing-only build: the activations as if they arrived pre-split (no VALU between load and LDS store)
+            pc[0][e] = rb[2 * e] & 0x3fff3fffu;
+            pc[NP - 1][e] = rb[2 * e + 1] & 0x3fff3fffu;
+#else
             if constexpr (AR == 0)
                 split3(x0, x1, pc[0][e], pc[1][e], pc[2][e]);
             else
                 split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
+#endif
         }
         unsigned char* rowp = &Bs[buf][pl * ROW];
         if constexpr (MF) {
@@ -465,14 +470,24 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             }
         }
     };
+#ifdef WSDL_EXP_NOSTAGE          // timing-only build: both LDS images filled once (real data), the loop is barrier + ds_read + MFMA
+    if (nq > 1) store_tiles(1);
+    __syncthreads();
+#endif
     for (int q = 0; q < nq; ++q) {
         const int cur = q & 1;
+#ifndef WSDL_EXP_NOSTAGE
         if (q + 1 < nq) {
             store_tiles(cur ^ 1);                        // the registers hold chunk q + 1
             if constexpr (GL) dma_weights(cur ^ 1);
         }
         if (q + 2 < nq) load_next();
+#endif
+#ifdef WSDL_EXP_NOMFMA           // timing-only build: staging, barriers and one LDS read per chunk, no matrix work
+        acc[0][0][0] += (float)As[cur][(tid * 16) % (BM * ROW)] + (float)Bs[cur][(tid * 16) % (BN * ROW)];
+#else
         mfma_chunk(cur);
+#endif
         if constexpr (GL) {
             if (q + 2 < nq) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
