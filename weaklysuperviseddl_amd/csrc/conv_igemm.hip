@@ -536,6 +536,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
 __global__ void conv_splitk_reduce_kernel(ConvP p) {
     const long long total = (long long)p.Cout * p.P;
     const int OHOW = p.OH * p.OW;
+    float vmax = 0.f;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int co = (int)(idx / p.P), pix = (int)(idx - (long long)co * p.P);
@@ -550,12 +551,15 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
         if (p.accumulate) v += *y;
         if (p.relu) v = fmaxf(v, 0.f);
         *y = v;
+        vmax = fmaxf(vmax, fabsf(v));
     }
+    if (p.y_amax) publish_amax(vmax, p.y_amax);      // (uniform branch; every thread of the workgroup reaches it)
 }
 
 // 16-byte form of the above for OH*OW % 4 == 0 (and 4-float-aligned batch strides): four pixels per thread
 __global__ void conv_splitk_reduce_vec4_kernel(ConvP p) {
     const int OHOW = p.OH * p.OW;
+    float vmax = 0.f;
     const long long total = (long long)p.Cout * p.P, total4 = total / 4;
     const float4* slab4 = reinterpret_cast<const float4*>(p.slab);
     for (long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x; i4 < total4;
@@ -579,7 +583,9 @@ __global__ void conv_splitk_reduce_vec4_kernel(ConvP p) {
         if (p.accumulate) { const float4 o = *y; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *y = v;
+        vmax = amax4(vmax, v);
     }
+    if (p.y_amax) publish_amax(vmax, p.y_amax);      // the split-K path's amax: no separate read pass over the output
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1337,6 +1343,7 @@ int launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
 // give 25 pixel tiles): returns the number of K slices (1 = no split).  Only the fast path supports it.
 int g_ksplit_big = 1;   // 128x128 tiles + 2 K slices for grids of 200..399 such tiles with K >= 2048 (instead of 128x64
                         // tiles): aux 3x3 505 -> 435 us, layer3 3x3 139 -> 128 us; shorter K loses to the slab reduce
+int g_ksplit_target = 512, g_ksplit_max = 8, g_ksplit_min_chunks = 4;   // small grids: workgroups aimed at, most K slices, fewest 32-deep chunks per slice
 int igemm_ksplit(int P, int Cout, int Cin, int T, int dil) {
     if (Cin % 32 != 0 || Cout % 4 != 0 || Cout <= 64) return 1;
     const long long blocks = (long long)wsdl::cdiv(P, 64) * wsdl::cdiv(Cout, 128);       // 128x64 tile
@@ -1346,9 +1353,9 @@ int igemm_ksplit(int P, int Cout, int Cin, int T, int dil) {
         if (b128 >= 200 && b128 < g_tile_threshold && nq >= 64) return 2;
     }
     if (blocks >= 160 || nq < 8) return 1;
-    long long s = 320 / blocks;
-    if (s > nq / 4) s = nq / 4;
-    if (s > 8) s = 8;
+    long long s = g_ksplit_target / blocks;
+    if (s > nq / g_ksplit_min_chunks) s = nq / g_ksplit_min_chunks;
+    if (s > g_ksplit_max) s = g_ksplit_max;
     return s < 2 ? 1 : (int)s;
 }
 
@@ -1382,8 +1389,10 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         wsdl::set_error("conv: the fp16x2 split kernels need the activation tensor's amax (x_amax / dy_amax is null)");
         return WSDL_EINVAL;
     }
+    // who publishes max|y|: the split kernel's epilogue (no split-K), the split-K reduce kernel (any arithmetic), else one
+    // read pass over the output (fp32 kernels without split-K)
     float* amax_after = nullptr;
-    if (p.y_amax && !(split && p.ksplit == 1)) {
+    if (p.y_amax && !(split && p.ksplit == 1) && p.ksplit == 1) {
         amax_after = p.y_amax;
         p.y_amax = nullptr;
     }
@@ -1627,6 +1636,9 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "conv_glds")) { g_conv_glds = value; return WSDL_OK; }
     if (!strcmp(name, "conv_mfma16")) { g_conv_mfma16 = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
+    if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
+    if (!strcmp(name, "ksplit_min_chunks")) { g_ksplit_min_chunks = value > 0 ? value : 1; return WSDL_OK; }
     if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
