@@ -145,25 +145,55 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch (fetch + write) of `kernel` from the committed rocprofv3 --pmc passes of this command
-    (profiles/r*_pmc_traffic.json: FETCH_SIZE x 2 - gfx950 counts half of a coalesced read, calibrated on a
-    known-size copy in our access widths - plus WRITE_SIZE).  PMC passes cannot run inside bench.py itself."""
+def _pmc_file():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, {}
+    d = json.load(open(files[-1]))
+    return files[-1], d
+
+
+def pmc_traffic(kernel, with_source=False):
+    """HBM bytes per launch (fetch + write) of `kernel` from the committed rocprofv3 --pmc passes of this command
+    (profiles/r*_pmc_traffic.json: FETCH_SIZE x 2 - gfx950 counts half of a coalesced read, calibrated on a
+    known-size copy in our access widths - plus WRITE_SIZE).  PMC passes cannot run inside bench.py itself: the figure
+    is a LOOKUP, and `with_source` returns (bytes, "file (collected date)") so that the line says where it comes from."""
+    path, d = _pmc_file()
+    if path is None:
+        return (None, None) if with_source else None
     from weaklysuperviseddl_amd import ops
     # the library's timing classes name the arithmetic template argument "AR"; rocprofv3 prints its value
     name = kernel.replace(", AR>", f", {ops.CONV_ARITH[0]}>")
-    kernels = json.load(open(files[-1])).get("kernels", {})
+    kernels = d.get("kernels", {})
     # rocprofv3 prints the K chunk the class name calls BK and the trailing template arguments it leaves at their defaults:
     # of the candidates, the one the profiled run launched most
     cands = []
     for nm in ([name.replace(", BK,", f", {bk},") for bk in (16, 32)] if ", BK," in name else [name]):
-        cands += [v for kk, v in kernels.items() if kk == nm or kk.startswith(nm[:-1] + ", ")]
+        cands += [v for kk, v in kernels.items() if kk == nm or kk.startswith(nm[:-1] + ", ") or
+                  (not nm.endswith(">") and kk.startswith(nm + "<"))]
     k = max(cands, key=lambda v: v.get("launches", 0)) if cands else None
-    return None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    val = None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
+    if with_source:
+        src = f"{os.path.relpath(path, ROOT)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected {d.get('collected', 'in an earlier round')})"
+        return val, src
+    return val
+
+
+def mfma_busy_3x3():
+    """Cycle-weighted MFMA-busy fraction of the 3x3 convolutions (north_star: ">= 40 % MFMA util on the 3x3 convs") from
+    the committed per-shape counter runs, profiles/r*_mfma_busy_3x3.txt (tools/mfma_busy_3x3.sh: one rocprofv3 --pmc
+    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE run per SURVEY 8a shape and pass) - a lookup, like `traffic`."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy_3x3.txt")))
+    if not files:
+        return None
+    out = {"source": os.path.relpath(files[-1], ROOT)}
+    for line in open(files[-1]):
+        if line.startswith("3x3 convolutions"):
+            parts = line.split()
+            out[parts[2]] = float(parts[-1])
+    return out if len(out) > 1 else None
 
 
 # ------------------------------------------------------------------------------------------ CPU baselines (oracle)
@@ -337,7 +367,10 @@ def cam_bench(device, iters=5, roofline=True):
                            "conv_kernels_frac": round(nprod * conv_tf / BF16_MFMA_PEAK_TFLOPS, 4),
                            "mfma_products_per_fp32_product": nprod,
                            "conv_kernel_ms_per_batch": round(kms / iters, 4),
-                           "gflop_per_img": CAM_GFLOP_PER_IMG, "traffic": None,
+                           "gflop_per_img": CAM_GFLOP_PER_IMG,
+                           "traffic": pmc_traffic("conv_igemm_split_kernel<128, 64, 2, 32, 256, AR>"),
+                           "traffic_layercam_partial_kernel": pmc_traffic("layercam_partial_kernel"),
+                           "traffic_source": pmc_traffic("layercam_partial_kernel", with_source=True)[1],
                            "note": "needed-only FLOPs (forward 12.4 + backward to layer3's output 5.9 GFLOP/img) x the 16-bit MFMA "
                                    "products per fp32 product / wall time of the whole leg, against the dense 16-bit MFMA peak; "
                                    "conv_kernels_* = executed FLOPs of the instrumented conv launches / their HIP-event time"}
@@ -361,8 +394,11 @@ def ncut_bench(device, B=32, H=256, W=256, reps=20):
     px = B * H * W
     return {"us_fwd_bwd": round(us, 2), "shape": [B, 2, H, W],
             "roofline": {"bound": "hbm", "achieved": round(28 * px / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(28 * px / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "note": "28 B/px algorithmic (20 read + 8 gradient write, C=2), fused forward + backward launch"}}
+                         "frac": round(28 * px / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("pairwise_kernel"),
+                         "traffic_source": pmc_traffic("pairwise_kernel", with_source=True)[1],
+                         "note": "28 B/px algorithmic (20 read + 8 gradient write, C=2), fused forward + backward launch; not bound by "
+                                 "HBM nor by its exponentials (the cached-affinity form takes 88 us, staging the tile + halo is "
+                                 "more than half: profiles/r03_notes.md)"}}
 
 
 # ------------------------------------------------------------------------------------------ launching
@@ -677,6 +713,8 @@ def main():
                                   "achieved_fp32_equivalent": round(ach, 3), "achieved_nominal": round(nom, 3),
                                   "mfma_products_per_fp32_product": (nprod if split else 1),
                                   "traffic": pmc_traffic(top["kernel"]),
+                                  "traffic_source": pmc_traffic(top["kernel"], with_source=True)[1],
+                                  "mfma_busy_3x3": mfma_busy_3x3(),
                                   "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
                                   "launches": top["launches"], "avg_launch_us": top["avg_us"],
                                   "flop_per_launch_avg": top["executed"] / top["launches"],

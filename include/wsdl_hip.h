@@ -54,26 +54,23 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
  *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
- *   wgrad_wide     0*  split weight-gradient kernel: a lane stages 8-pixel runs of two x rows (16-byte loads / LDS stores)
- *                      instead of one pixel of sixteen rows (stride 1, OW % 8 == 0); bit-identical
  *   wgrad_mfma16   1*  fp16x2 weight-gradient kernel on v_mfma_f32_16x16x32_f16 (swizzled 128-byte LDS rows): -6 % on the
  *                      kernel sweep, +2 % img/s against the 32x32x16 form (0); same accuracy against float64
  *   conv_mfma16    1*  the same MFMA shape in the forward / input-gradient kernels (K chunk 32): neutral on the isolated kernel
  *                      sweep (-2..-3.6 % on the layer4 shapes, +1.6 % on layer3 3x3 and ASPP d12), +2.2 % img/s on the step
  *                      (784.7 -> 802.1, three same-box pairs) - under the power limit it leaves more to the kernels beside it
- *   wgrad_min_tiles 6* / wgrad_tile64 0*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles
- *                      on (1: the layer2 1x1 kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches);
- *                      64-row / 64-column tiles for the 64-channel layers (slower than the fp32 kernels there)
+ *   wgrad_min_tiles 6*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles on (1: the layer2 1x1
+ *                      kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches)
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
- *   conv_glds      0*  weights of the fp16x2 kernels copied to LDS by LDS-DMA (bit 0: 256x128 form, bit 1: 4-wave forms; selects the
- *                      32x32x16 form of those kernels);
- *                      bit-identical results, measured 2-3 % slower than the register-staged copy (profiles/r02_notes.md)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      192 channels, n > 1 = from n channels; measured: resident wins at every channel count)
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
- *   occupancy_cap  0*  pad the conv kernels' LDS request so that a CU holds at most ceil(blocks/256) workgroups
+ *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,
+ *                      most K slices, fewest 32-deep chunks per slice
+ * (Options measured slower and removed in round 3: conv_glds - weights by LDS-DMA; wgrad_wide - 8-pixel-run staging of x;
+ *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.)
  * (* = default). */
 int wsdl_set_option(const char* name, int value);
 
@@ -104,6 +101,16 @@ int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* to
                       double* total_work_executed /* work minus the skipped all-padding K-chunks */,
                       double* total_bytes /* algorithmic HBM bytes: every operand read once, result written once */);
 int wsdl_prof_reset(void);
+
+/* ---- profiler ranges (roctx) ----------------------------------------------------------------
+ * Named host-side ranges for `rocprofv3 --marker-trace`: wsdl_range_enable(1) loads librocprofiler-sdk-roctx.so (dlopen; the
+ * library does not link against it) and from then on wsdl_range_push / _pop forward to roctxRangePushA / roctxRangePop, and
+ * every launch of an instrumented kernel class (the classes above) sits inside a range carrying the class name.  Disabled
+ * (the default) all three cost one branch.  Returns 0, or WSDL_EINVAL when the roctx library cannot be loaded.
+ * The reference has no tracing of any kind: this is the build's addition. */
+int wsdl_range_enable(int on);
+int wsdl_range_push(const char* name);
+int wsdl_range_pop(void);
 
 /* ---- convolution: implicit GEMM on the matrix cores -------------------------------------------
  * Arithmetic paths, all at fp32-level accuracy (tools/conv_accuracy.py, tests/test_hip_ops.py measure them against fp64):

@@ -240,14 +240,14 @@ def test_fp16x2_scales_cover_extreme_magnitudes(dev):
     assert not torch.isfinite(ops.conv2d_fwd(bad, wf, w.shape, 1, 1, 1)).all()   # an inf input is not silently dropped
 
 
-@pytest.mark.parametrize("opt,val", [("wgrad_wide", 1), ("wgrad_xcd", 1), ("wgrad_xcd", 2), ("xcd_map", 0)])
+@pytest.mark.parametrize("opt,val", [("wgrad_xcd", 1), ("wgrad_xcd", 2), ("xcd_map", 0)])
 def test_scheduling_options_reproduce_the_default_bit_for_bit(dev, opt, val):
-    """Options that change how operands travel (8-pixel-run staging, XCD-aware tile orders) and not what is computed: forward, input gradient and weight gradient equal the default's bit for bit, on shapes that
+    """Options that change how operands travel (XCD-aware tile orders) and not what is computed: forward, input gradient and weight gradient equal the default's bit for bit, on shapes that
     reach the 256x128 and the 4-wave forms, a dilated 3x3 with masked row ends, a strided conv and a ragged one."""
     from weaklysuperviseddl_amd import ops
     shapes = [(16, 512, 512, 3, 1, 2, 32), (4, 256, 256, 3, 1, 4, 16), (2, 128, 128, 3, 2, 1, 32), (16, 256, 1024, 1, 1, 1, 32),
               (3, 48, 80, 3, 1, 1, 17), (2, 128, 256, 3, 1, 36, 24)]
-    default = {"wgrad_wide": 0, "wgrad_xcd": 0, "xcd_map": 1}[opt]          # (wgrad_xcd: compared against the launch order)
+    default = {"wgrad_xcd": 0, "xcd_map": 1}[opt]          # (wgrad_xcd: compared against the launch order)
     try:
         for B, Cin, Cout, k, st, d, H in shapes:
             g = torch.Generator(device=dev).manual_seed(Cin + Cout + H)
@@ -267,15 +267,14 @@ def test_scheduling_options_reproduce_the_default_bit_for_bit(dev, opt, val):
         ops.set_option(opt, default)
 
 
-@pytest.mark.parametrize("opts", [dict(conv_mfma16=0), dict(wgrad_mfma16=0), dict(wgrad_tile64=1, wgrad_min_tiles=1),
-                                  dict(wgrad_min_tiles=1), dict(conv_glds=3, t256_bk32=1), dict(t256_bk32=1),
+@pytest.mark.parametrize("opts", [dict(conv_mfma16=0), dict(wgrad_mfma16=0), dict(wgrad_min_tiles=1), dict(t256_bk32=1),
                                   dict(conv_mfma16=0, t256_bk32=1)])
 def test_other_mfma_shapes_and_tiles_agree_with_the_default(dev, opts):
     """Options that change the MFMA shape (16x16x32 <-> 32x32x16: another summation order inside a K chunk) or which
-    shapes the fp16x2 weight-gradient kernel takes (64-row / 64-column tiles): results within a few fp32 roundings of the
+    shapes the fp16x2 weight-gradient kernel takes (from one 128-wide N tile on): results within a few fp32 roundings of the
     default's, pass by pass (each is measured against float64 in test_split_arithmetic_is_fp32_accurate)."""
     from weaklysuperviseddl_amd import ops
-    defaults = dict(conv_mfma16=1, wgrad_mfma16=1, wgrad_tile64=0, wgrad_min_tiles=6, conv_glds=0, t256_bk32=0)
+    defaults = dict(conv_mfma16=1, wgrad_mfma16=1, wgrad_min_tiles=6, t256_bk32=0)
     shapes = [(16, 512, 512, 3, 1, 2, 32), (4, 64, 64, 3, 1, 1, 32), (4, 64, 256, 1, 1, 1, 32), (4, 256, 64, 1, 1, 1, 32),
               (8, 256, 128, 1, 1, 1, 32), (2, 128, 128, 3, 2, 1, 32), (3, 192, 320, 3, 1, 2, 24)]
     try:

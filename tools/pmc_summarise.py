@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/<round>_pmc_traffic.json.
 
-    python tools/pmc_summarise.py <calib_fetch_dir> <calib_write_dir> <bench_fetch_dir> <bench_write_dir> <out.json>
+    python tools/pmc_summarise.py <calib_fetch_dir> <calib_write_dir> <bench_fetch_dir> <bench_write_dir> <out.json> [<fetch_dir> <write_dir> ...]
+(further fetch / write directory pairs - the CAM leg, the loss kernels - are merged in; a kernel seen in several runs keeps the
+figures of the run that launched it most)
 Counter unit: KiB (rocprofv3 derives FETCH_SIZE = TCC_EA0_RDREQ*64 B / 1024).  The calibration launches have known
 byte counts, giving a bytes-per-counted-byte factor for our 4 B/lane and 16 B/lane access patterns."""
 import collections
@@ -25,6 +27,7 @@ def per_kernel(d, counter):
 
 def main():
     cf, cw, bf, bw, out = sys.argv[1:6]
+    extra = sys.argv[6:]
     GiB = 1 << 30
     calf, calw = per_kernel(cf, "FETCH_SIZE"), per_kernel(cw, "WRITE_SIZE")
     factors = {
@@ -34,6 +37,11 @@ def main():
         "write_16B_per_lane": 0.75 * GiB / (calw["adam_kernel"]["avg_kib"] * 1024),
     }
     fetch, write = per_kernel(bf, "FETCH_SIZE"), per_kernel(bw, "WRITE_SIZE")
+    for i in range(0, len(extra) - 1, 2):
+        for dst, src in ((fetch, per_kernel(extra[i], "FETCH_SIZE")), (write, per_kernel(extra[i + 1], "WRITE_SIZE"))):
+            for k, v in src.items():
+                if k not in dst or v["launches"] > dst[k]["launches"]:
+                    dst[k] = v
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith(("conv_", "bn_", "wgrad_", "prep_", "adam", "pairwise", "layercam", "softmax_ce", "bilinear", "dy_split", "multi_amax", "amax_", "maxpool", "gap_")):
@@ -45,7 +53,10 @@ def main():
         kernels[k] = {"launches": fk["launches"] or wk["launches"],
                       "fetch_bytes_per_launch": fk["avg_kib"] * 1024 * ff, "write_bytes_per_launch": wk["avg_kib"] * 1024 * wf,
                       "raw_fetch_kib": fk["avg_kib"], "raw_write_kib": wk["avg_kib"]}
+    import datetime
     json.dump({"unit_note": "bytes = counter(KiB) * 1024 * calibration factor of the access width",
+               "collected": datetime.date.today().isoformat(),
+               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/refresh_profiles.sh)",
                "calibration_factors": factors, "kernels": kernels}, open(out, "w"), indent=1)
     print(json.dumps(factors, indent=1))
     for k, v in kernels.items():

@@ -24,7 +24,16 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/cal_f -- python3 $R/tools/p
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/cal_w -- python3 $R/tools/pmc_calibrate.py > /dev/null 2>&1 || exit 1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/b_f -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 > /dev/null 2>&1 || exit 1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/b_w -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 > /dev/null 2>&1 || exit 1
-python3 $R/tools/pmc_summarise.py $O/cal_f $O/cal_w $O/b_f $O/b_w $O/pmc_traffic.json > $O/pmc_traffic.txt 2>&1 || exit 1
+# the CAM leg (small-grid conv forms, layercam_* kernels) and the loss kernels (pairwise_kernel, softmax_ce_kernel ...)
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/c_f -- python3 $R/bench.py --cam-only > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/c_w -- python3 $R/bench.py --cam-only > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/l_f -- python3 $R/tools/loss_cam_bench.py > /dev/null 2>&1 || exit 1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/l_w -- python3 $R/tools/loss_cam_bench.py > /dev/null 2>&1 || exit 1
+python3 $R/tools/pmc_summarise.py $O/cal_f $O/cal_w $O/b_f $O/b_w $O/pmc_traffic.json $O/l_f $O/l_w $O/c_f $O/c_w > $O/pmc_traffic.txt 2>&1 || exit 1
+
+step "roctx ranges: marker + kernel trace of two steps and one CAM batch (WSDL_ROCTX=1)"
+WSDL_ROCTX=1 rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $O/markers -- python3 $R/bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/markers_bench.txt 2>&1 || exit 1
+cp $(ls $O/markers/*/*marker_api_stats.csv 2>/dev/null | head -1) $O/roctx_marker_stats.csv 2>/dev/null || true
 
 step "PMC: MFMA busy cycles of the whole step"
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/b_m -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 --serial > /dev/null 2>&1 || exit 1

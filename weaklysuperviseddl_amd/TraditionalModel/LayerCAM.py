@@ -101,10 +101,12 @@ class LayerCAMGenerator:
         self.gradients.clear()
         if class_idx is not None:
             class_idx = class_idx.to(images.device).view(-1)
-        (self._capture_staged if self.staged else self._capture_hooks)(images, class_idx)
+        with ops.prof_range("layercam/forward+class-logit backward"):
+            (self._capture_staged if self.staged else self._capture_hooks)(images, class_idx)
         acts = [self.activations[n].detach() for n in self.target_layer_names]
         grads = [self.gradients[n].detach() for n in self.target_layer_names]
-        return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
+        with ops.prof_range("layercam/epilogue"):
+            return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
 
     def generate_batches(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3):
         """Several independent batches in flight: batch j runs on stream j % ``streams`` with a generator of its own over

@@ -272,20 +272,24 @@ def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_
     'lovasz_softmax' (reference SegmentationModel.py:65,103-107); ``criterion``: a reference-style loss object instead
     (``resolve_criterion``)."""
     masks = torch.clamp(masks, max=1)
-    outputs = model(images)["out"]
-    if criterion is not None:
-        loss = resolve_criterion(criterion)(outputs, masks)
-    elif loss_fn == "lovasz_softmax":
-        loss = ops.lovasz_softmax(ops.softmax_channels(outputs), masks.long(), classes="present", per_image=False, ignore=None)
-    elif loss_fn == "cross_entropy":
-        loss = ops.cross_entropy(outputs, masks.long())
-    else:
-        raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
-    if extra_loss is not None:
-        loss = loss + extra_loss(outputs, images)
-    optimizer.zero_grad()
-    loss.backward()
-    optimizer.step()
+    with ops.prof_range("train_step/forward"):
+        outputs = model(images)["out"]
+    with ops.prof_range("train_step/loss"):
+        if criterion is not None:
+            loss = resolve_criterion(criterion)(outputs, masks)
+        elif loss_fn == "lovasz_softmax":
+            loss = ops.lovasz_softmax(ops.softmax_channels(outputs), masks.long(), classes="present", per_image=False, ignore=None)
+        elif loss_fn == "cross_entropy":
+            loss = ops.cross_entropy(outputs, masks.long())
+        else:
+            raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
+        if extra_loss is not None:
+            loss = loss + extra_loss(outputs, images)
+    with ops.prof_range("train_step/backward"):
+        optimizer.zero_grad()
+        loss.backward()
+    with ops.prof_range("train_step/optimizer"):
+        optimizer.step()
     return loss.detach()
 
 

@@ -25,6 +25,9 @@ SIGNATURES = {
     "wsdl_prof_collect": (_i, [_i, C.POINTER(_ll)] + [C.POINTER(C.c_double)] * 4),
     "wsdl_prof_reset": (_i, []),
     "wsdl_prof_class_name": (C.c_char_p, [_i]),
+    "wsdl_range_enable": (_i, [_i]),
+    "wsdl_range_push": (_i, [C.c_char_p]),
+    "wsdl_range_pop": (_i, []),
     "wsdl_conv2d_weight_layout_bytes": (_sz, [_i, _i, _i, _i, _i, C.POINTER(_i)]),
     "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),

@@ -1,6 +1,8 @@
 // common.hip - error channel, version, and the per-kernel-class event timing used by bench.py.
 #include "common.h"
 
+#include <dlfcn.h>
+
 #include <mutex>
 #include <vector>
 
@@ -26,8 +28,25 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_free_events;
 
 bool prof_enabled() { return g_prof_on; }
 
+// roctx, loaded on demand (the library carries no link-time dependency on the profiler SDK)
+static bool g_ranges_on = false;
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static bool load_roctx() {
+    if (g_roctx_push && g_roctx_pop) return true;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+        if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+            g_roctx_push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (g_roctx_push && g_roctx_pop) return true;
+        }
+    }
+    return false;
+}
+
 ProfScope::ProfScope(int c, hipStream_t st, double work, double work_executed, double bytes)
     : cls(c), s(st), slot(nullptr) {
+    if (g_ranges_on) g_roctx_push(wsdl_prof_class_name(c));
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
@@ -48,6 +67,7 @@ ProfScope::ProfScope(int c, hipStream_t st, double work, double work_executed, d
 }
 
 ProfScope::~ProfScope() {
+    if (g_ranges_on) g_roctx_pop();
     if (!slot) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     size_t idx = reinterpret_cast<size_t>(slot) - 1;
@@ -75,6 +95,23 @@ const char* wsdl_prof_class_name(int cls) {
         "conv_wgrad_split16_kernel<128, 128, false>", "conv_igemm_split_kernel<256, 128, 4, BK, 512, AR>"};
     // (BK: 16 or 32 by the "t256_bk32" option - the profiler's name has the number; the split weight-gradient class: the default fp16x2 kernel's name; "wgrad_mfma16" = 0 / bf16x3 launch conv_wgrad_split32_kernel)
     return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
+}
+
+int wsdl_range_enable(int on) {
+    if (on && !wsdl::load_roctx()) {
+        wsdl::set_error("range_enable: librocprofiler-sdk-roctx.so / libroctx64.so could not be loaded");
+        return WSDL_EINVAL;
+    }
+    wsdl::g_ranges_on = on != 0;
+    return WSDL_OK;
+}
+int wsdl_range_push(const char* name) {
+    if (wsdl::g_ranges_on && name) wsdl::g_roctx_push(name);
+    return WSDL_OK;
+}
+int wsdl_range_pop(void) {
+    if (wsdl::g_ranges_on) wsdl::g_roctx_pop();
+    return WSDL_OK;
 }
 
 int wsdl_prof_enable(int on) {

@@ -1200,22 +1200,8 @@ double wgrad_executed_fraction(int P, int OH, int ow0, int own, int H, int W, in
     return all ? (double)done / (double)all : 1.0;
 }
 
-// Workgroup placement: the dispatcher may stack up to `natural occupancy` blocks on one CU while other CUs
-// sit idle, so a 512-block grid (2 per CU on average) can finish at the pace of a CU holding 3-5 blocks.
-// Padding the LDS request caps the blocks a CU can hold at ceil(blocks / 256): placement becomes even.
-int g_occ_cap = 0;     // measured: no gain - the dispatcher already places blocks evenly (profiles/r01_notes.md)
 int g_tile_threshold = 400;   // blocks below which the half-size pixel tile is used
 constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
-
-size_t occupancy_pad(long long blocks, size_t static_lds) {
-    if (!g_occ_cap) return 0;
-    const long long per_cu = (blocks + kNumCU - 1) / kNumCU;
-    if (per_cu >= 5) return 0;
-    // largest request such that exactly per_cu blocks fit: floor(LDS / per_cu), but more than LDS / (per_cu + 1)
-    size_t want = (size_t)kLdsPerCU / (size_t)per_cu - 4096;   // leave slack: exactly LDS/per_cu did not co-reside
-    want -= want % 1024;
-    return want > static_lds ? want - static_lds : 0;
-}
 
 int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 32
 int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
@@ -1229,9 +1215,7 @@ int launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_fast_kernel<BM, BN, WM, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCU - (int)static_lds - 2048);
     });
-    size_t pad = occupancy_pad((long long)grid.x * grid.y, static_lds);
-    if (pad > (size_t)kLdsPerCU - static_lds - 2048) pad = (size_t)kLdsPerCU - static_lds - 2048;
-    hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), pad, s, p);
+    hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -1247,7 +1231,6 @@ bool split_eligible(int rows, int kc, int T) {
 }
 
 int g_conv_mfma16 = 1;    // fp16x2 forward / input-gradient kernels with K chunk 32 on v_mfma_f32_16x16x32_f16
-int g_conv_glds = 0;      // weights of the fp16x2 kernels by LDS-DMA: bit 0 the 256x128 form, bit 1 the 4-wave forms
 int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
@@ -1274,14 +1257,13 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     if (g_conv_arith) {
         if constexpr (BK == 32) {
-            if (g_conv_mfma16 && !(g_conv_glds & 2)) {
-                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, false, true>), grid, dim3(kThreads), 0, s, p);
+            if (g_conv_mfma16) {
+                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
                 WSDL_LAUNCH_CHECK();
                 return WSDL_OK;
             }
         }
-        if (g_conv_glds & 2) hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
     } else
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 0>), grid, dim3(kThreads), 0, s, p);
     WSDL_LAUNCH_CHECK();
@@ -1300,8 +1282,7 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     // bit 0: forward launches (p.bh > 0), bit 1: input-gradient launches (tap step negated)
     const bool bk32 = (g_t256_bk32 & (p.bh < 0 ? 2 : 1)) && p.Cin % 32 == 0;
     if (g_conv_arith) {
-        if (bk32 && g_conv_mfma16 && !(g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, false, true>), grid, dim3(512), 0, s, p);
-        else if (bk32 && (g_conv_glds & 1)) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
+        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
         else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
     } else {
@@ -1515,20 +1496,15 @@ int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-ch
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
 int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
 int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
-int g_wgrad_wide = 0;        // 8-pixel runs per lane in the x staging of the split weight-gradient kernel (stride 1, OW % 8 == 0)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
 // (that was the bf16x3 kernel; the fp16x2 kernel on 16x16x32 MFMAs wins from ONE N tile on: 1x1 convs of layer2 / layer3.0
-// 76 -> 61, 41 -> 31, 63 -> 43 us.  Its 64-row / 64-column tiles, "wgrad_tile64", take the 64-channel layers of layer1
-// too but lose there to the fp32 kernels - 87 -> 121 us on the 64 -> 64 3x3: few tiles, hundreds of slabs - off.)
+// 76 -> 61, 41 -> 31, 63 -> 43 us.  64-row / 64-column tiles for the 64-channel layers of layer1 lost to the fp32 kernels there -
+// 87 -> 121 us on the 64 -> 64 3x3: few tiles, hundreds of slabs - and were removed in round 3.)
 int g_wgrad_min_tiles = 6;     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
-int g_wgrad_tile64 = 0;
-bool wgrad_tile64() { return g_conv_arith && g_wgrad_mfma16 && g_wgrad_tile64; }
 bool wgrad_chunk32(int Cout, int Cin, int N) {
-    const int q = wgrad_tile64() ? 64 : 128;
-    if (!g_wgrad_split || Cout % q != 0 || Cin % q != 0) return false;
-    const int bn = Cin % 128 == 0 ? 128 : 64;
-    return N / bn >= ((g_conv_arith && g_wgrad_mfma16) ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
+    if (!g_wgrad_split || Cout % 128 != 0 || Cin % 128 != 0) return false;
+    return N / 128 >= ((g_conv_arith && g_wgrad_mfma16) ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
 }
 
 // taps that read at least one in-range input pixel for some output pixel (bit t of the result); the others (dilation
@@ -1624,7 +1600,6 @@ extern "C" {
 
 int wsdl_set_option(const char* name, int value) {
     WSDL_REQUIRE(name, "set_option: null name");
-    if (!strcmp(name, "occupancy_cap")) { g_occ_cap = value; return WSDL_OK; }
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
@@ -1634,7 +1609,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
     if (!strcmp(name, "t256_bk32")) { g_t256_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
-    if (!strcmp(name, "conv_glds")) { g_conv_glds = value; return WSDL_OK; }
     if (!strcmp(name, "conv_mfma16")) { g_conv_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
@@ -1643,11 +1617,9 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
-    if (!strcmp(name, "wgrad_wide")) { g_wgrad_wide = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_mfma16")) { g_wgrad_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_min_tiles")) { g_wgrad_min_tiles = value > 0 ? value : 1; return WSDL_OK; }
-    if (!strcmp(name, "wgrad_tile64")) { g_wgrad_tile64 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
     wsdl::set_error("set_option: unknown option %s", name);
@@ -1909,39 +1881,21 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 live_mask = live_all;            // dead taps: no workgroup writes their slab columns, the reduce skips them
                 unsigned char* dys = static_cast<unsigned char*>(ws) + dys_off;
                 const long long total = 2ll * wsdl::cdiv(p.P, 32) * Cout;
-                const int kBM = Cout % 128 == 0 ? 128 : 64, kBN = Cin % 128 == 0 ? 128 : 64;     // 64: split16 kernel only
-                dim3 grid(p.N / kBN, Cout / kBM, S);
+                dim3 grid(p.N / 128, Cout / 128, S);
                 p.xcd_order = ((long long)grid.x * grid.y * grid.z) % 8 == 0 ? g_wgrad_xcd : 0;
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
-                    const bool wide = g_wgrad_wide && stride == 1 && OW % 8 == 0;
                     if (g_wgrad_mfma16) {
                         hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();
-#define WSDL_W16(BM_, BN_)                                                                                              \
-    do {                                                                                                                \
-        if (wide)                                                                                                       \
-            hipLaunchKernelGGL((conv_wgrad_split16_kernel<BM_, BN_, true>), grid, dim3(kThreads), 0, s, p, dys,          \
-                               (unsigned)dys_bytes, dy_amax);                                                           \
-        else                                                                                                            \
-            hipLaunchKernelGGL((conv_wgrad_split16_kernel<BM_, BN_, false>), grid, dim3(kThreads), 0, s, p, dys,         \
-                               (unsigned)dys_bytes, dy_amax);                                                           \
-    } while (0)
-                        if (kBM == 128 && kBN == 128) WSDL_W16(128, 128);
-                        else if (kBM == 128) WSDL_W16(128, 64);
-                        else if (kBN == 128) WSDL_W16(64, 128);
-                        else WSDL_W16(64, 64);
-#undef WSDL_W16
+                        hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
+                                           (unsigned)dys_bytes, dy_amax);
                     } else {
                         hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();
-                        if (wide)
-                            hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1, true>), grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
-                        else
-                            hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
+                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
+                                           (unsigned)dys_bytes, dy_amax);
                     }
                 } else {
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,

@@ -105,19 +105,6 @@ __device__ __forceinline__ f32x16 split_products(const F (&a)[SplitArith<AR>::NP
     return c;
 }
 
-// One LDS-DMA wave-instruction: lane i copies 16 bytes from its own buffer offset to LDS byte `lds_addr` + 16 i
-// (lds_addr wave-uniform).  Inline assembly so that the compiler, which would drain vmcnt(0) before any later ds_read
-// that might alias the DMA's destination, keeps the copy in flight behind the MFMAs; the caller counts it in its own
-// s_waitcnt vmcnt.  M0 (the destination base) is compiler-reserved: saved and restored inside the statement.
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
-                 : "memory");
-}
-
 constexpr int split_k16_bytes(int AR) { return AR ? 64 : 96; }     // one row's 16 k values: NP pieces x 16 x 2 bytes
 // the layout buffers end in a 16-byte trailer holding the tensor's amax (AR = 1)
 __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_total, long long rows) {
@@ -133,21 +120,17 @@ __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_t
 // py row groups x 8/py pixel groups.  Each XCD then streams 1/py of the weights and py/8 of the activations instead of
 // all the weights and 1/8 of the activations; the host picks py per launch from the two operands' byte counts.
 //
-// GL (weights by LDS-DMA): the pre-split weights need no arithmetic on their way to LDS, so `buffer_load_dwordx4 ... lds`
-// copies them without passing through VGPRs or ds_write_b128 (13 cycles per wave-instruction on the VGPR->LDS path).
-// One wave-instruction fills 1 KiB of consecutive LDS bytes, lane by lane; the padded row image is kept by giving
-// every lane the SOURCE address of the 16-byte unit that belongs at its destination (the pad unit re-reads its
-// neighbour).  The DMA of chunk q+1 is issued after the barrier that retired the buffer's last readers and is waited
-// for with a counted vmcnt (the activation loads of chunk q+2 stay in flight) before the barrier that publishes it.
+// (Weights by LDS-DMA - `buffer_load_dwordx4 ... lds` - were a template option in round 2: bit-identical, 2-3 % slower; round 3
+// measured why: that path feeds a CU ~30 GB/s, the tile needs more.  Removed; profiles/r02_notes.md, r03_notes.md.)
 //
 // MF (fp16x2, K chunk 32): v_mfma_f32_16x16x32_f16 instead of 32x32x16 - one MFMA spans the chunk's 32 k values; the chip
 // holds a higher clock on this shape under the power limit (weight gradient: -8 % per launch, see conv_wgrad_split16_kernel).
 // LDS rows become 128 bytes, unit u = 4 piece + (k / 8) of 16 bytes stored at unit u ^ (row & 7): conflict-free for the
 // operand reads (lane l: row l & 15, k-group l >> 4 - checked against the b128 lane groups) and for the activations'
 // stores (8 consecutive pixel rows, one unit).
-template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool GL = false, bool MF = false>
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
-    static_assert(!MF || (AR == 1 && BK == 32 && !GL), "16x16x32 form: fp16x2, K chunk 32, register staging");
+    static_assert(!MF || (AR == 1 && BK == 32), "16x16x32 form: fp16x2, K chunk 32");
     using Ar = SplitArith<AR>;
     using frag = typename Ar::frag;
     constexpr int NP = Ar::NP;
@@ -162,10 +145,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     constexpr int A_UPS = BM * UPR;                      // 16-byte units of one k16 slab of the row tile
     constexpr int A_U = (KS * A_UPS + NT - 1) / NT;      // units per thread per chunk
     constexpr bool A_EXACT = A_U * NT == KS * A_UPS;
-    constexpr int RU = ROW / 16;                         // 16-byte units per LDS row, the last one padding
-    constexpr int G_TU = BM * RU;                        // units of the padded A image (a multiple of 64)
-    constexpr int G_U = (G_TU + NT - 1) / NT;            // LDS-DMA instructions per thread per chunk
-    static_assert(!GL || G_TU % 64 == 0, "whole wave-instructions");
     constexpr int B_STEP = NT / BN;                      // threads sharing one pixel
     constexpr int B_PER = BK / B_STEP;                   // consecutive k (input channels) per thread
     static_assert(B_PER == 4 || B_PER == 8 || B_PER == 16 || B_PER == 32, "B tile");
@@ -279,20 +258,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             lds_a[e] = (unsigned)(row * ROW + ks * K16B + part * 16);
     }
 
-    // LDS-DMA form: unit u of the padded image = (row, 16-byte slot of the row); slot RU-1 is the padding
-    unsigned voff_g[GL ? G_U : 1];
-    if constexpr (GL) {
-#pragma unroll
-        for (int e = 0; e < G_U; ++e) {
-            const int u = tid + e * NT;
-            const int row = u / RU;
-            int part = u - row * RU;
-            part = part == RU - 1 ? RU - 2 : part;
-            const int ks = part / UPR, pp = part - ks * UPR;
-            voff_g[e] = (m0 + row < p.Cout && u < G_TU) ? (unsigned)(ks * p.Cout * K16B + ((m0 + row) * UPR + pp) * 16) : kOOB;
-        }
-    }
-
     constexpr int TS = MF ? 16 : 32;                     // side of an MFMA output tile
     constexpr int TMI = BM / WM / TS, TNI = BN / WN / TS;  // tiles of a wave
     constexpr int RT = TS * TS / 64;                     // accumulator registers per tile
@@ -305,7 +270,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[GL ? 1 : A_U];
+    u32x4 ra[A_U];
     unsigned rb[B_PER];
     int ld_vi = q0 / cpt, ld_c = q0 - (q0 / cpt) * cpt, ld_tap = 0;
     unsigned voff_b = kOOB;
@@ -323,45 +288,21 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             ++ld_vi;
             set_tap(ld_vi);
         }
-        if constexpr (!GL) {
-            const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
-            const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
+        const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
+        const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
 #pragma unroll
-            for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
-        }
+        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
         const unsigned soff_b = (unsigned)(ld_c * BK * HW) * 4u;
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
             rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, soff_b + (unsigned)(e * HW) * 4u, 0);
         ++ld_c;
     };
-    // LDS-DMA of the weight chunk `wq` (its own cursor: it runs one chunk behind the activation loads)
-    int wq_vi = q0 / cpt, wq_c = q0 - (q0 / cpt) * cpt;
-    const int wave_base = __builtin_amdgcn_readfirstlane(wid) * 1024;
-    const unsigned as_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)&As[0][0];
-    const unsigned long long wt_addr = reinterpret_cast<unsigned long long>(p.wt);
-    const i32x4 rw_words = {(int)(unsigned)wt_addr, (int)(unsigned)(wt_addr >> 32), wbytes, 0x00020000};
-    auto dma_weights = [&](int buf) {
-        if (wq_c == cpt) {
-            wq_c = 0;
-            ++wq_vi;
-        }
-        const int tap = __builtin_amdgcn_readfirstlane(vtaps[wq_vi]);
-        const int c16 = (tap * p.Cin + wq_c * BK) / 16;
-        const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
-#pragma unroll
-        for (int e = 0; e < G_U; ++e)
-            if ((e + 1) * NT <= G_TU || wave_base + e * NT * 16 < G_TU * 16)
-                lds_dma16(rw_words, voff_g[e], soff_a, as_base + (unsigned)(buf * (BM * ROW) + e * NT * 16 + wave_base));
-        ++wq_c;
-    };
     // this thread's k run [kr*B_PER, kr*B_PER + B_PER) inside the chunk -> (k-step, offset inside the 16)
     auto store_tiles = [&](int buf) {
-        if constexpr (!GL) {
 #pragma unroll
-            for (int e = 0; e < A_U; ++e)
-                if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
-        }
+        for (int e = 0; e < A_U; ++e)
+            if (A_EXACT || tid + e * NT < KS * A_UPS) *reinterpret_cast<u32x4*>(&As[buf][lds_a[e]]) = ra[e];
         unsigned pc[NP][B_PER / 2];
 #pragma unroll
         for (int e = 0; e < B_PER / 2; ++e) {
@@ -404,18 +345,11 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     };
 
     if (nq > 0) {
-        if constexpr (GL) dma_weights(0);
         load_next();
         store_tiles(0);
         if (nq > 1) load_next();
-        if constexpr (GL) {
-            // the DMA is older than the second chunk's activation loads: leave those in flight
-            if (nq > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
     }
-    if constexpr (GL) lds_barrier();
-    else __syncthreads();
+    __syncthreads();
     // lane -> (column of the output tile, row group): D[row][col] of v_mfma_f32_32x32x16 / 16x16x32
     const int l31 = MF ? (lane & 15) : (lane & 31), lh = MF ? (lane >> 4) : (lane >> 5);
     auto acc_row = [&](int r) { return MF ? lh * 4 + r : (r & 3) + 8 * (r >> 2) + 4 * lh; };
@@ -479,7 +413,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #ifndef WSDL_EXP_NOSTAGE
         if (q + 1 < nq) {
             store_tiles(cur ^ 1);                        // the registers hold chunk q + 1
-            if constexpr (GL) dma_weights(cur ^ 1);
         }
         if (q + 2 < nq) load_next();
 #endif
@@ -488,10 +421,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #else
         mfma_chunk(cur);
 #endif
-        if constexpr (GL) {
-            if (q + 2 < nq) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B_PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         lds_barrier();
     }
 
@@ -740,12 +669,10 @@ __global__ void dy_split_kernel(const float* __restrict__ dy, unsigned char* __r
 // wave per SIMD, operand reads exposed after every barrier - already runs at half the MFMA rate).
 // `dy_amax` / p.x_amax: the scales of the two operands (AR = 1); the slab receives acc / (s_dy * s_x).
 //
-// WX (stride 1, OW % 8 == 0): a lane owns 8 CONSECUTIVE pixels of two x rows instead of one pixel of sixteen: two
-// 16-byte loads per row (an 8-pixel run of one output row maps to 8 consecutive input pixels; the run may start before
-// / end after the input row - those elements are masked to the padding's zeros), no neighbour exchange, and one
-// ds_write_b128 per (row, piece) instead of eight ds_write_b32: 4 loads + 4 LDS stores per chunk where the one-pixel
-// form issues 16 + 32.  Same LDS image, same MFMA order: bit-identical results.
-template <int BM, int BN, int AR, bool WX = false>
+// (An 8-pixel-run staging of x - two 16-byte loads and one ds_write_b128 per (row, piece) instead of 16 dword loads, 16 DPP
+// exchanges and 32 ds_write_b32 - was an option in round 2: bit-identical, 2.5 % slower on the sweep, 8-13 % on the dilated
+// ASPP shapes.  Removed in round 3.)
+template <int BM, int BN, int AR>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
     static_assert(BM == 128 && BN == 128, "tile");
@@ -838,31 +765,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
 
     const bool row_chunks = (p.OW % BK) == 0;
     unsigned nvb = kOOB;
-    // WX: run = the lane's 8-pixel run of the chunk; its two rows are wx_row and wx_row + 64, with the low two bits of
-    // the row index swapped so that the 8 lanes of a ds_write_b128 group hold rows R and R + 2 (row stride 144 bytes:
-    // rows one apart would share banks)
-    const int wx_run = tid & 3, wx_g = tid >> 2;
-    const int wx_row = (wx_g & ~3) | ((wx_g & 1) << 1) | ((wx_g >> 1) & 1);
-    int wx_off = 0;                    // element offset of the run's first input pixel (may be negative / past the row)
-    unsigned wx_mask = 0;              // bit e: pixel e of the run reads a real input pixel
     auto decode = [&](int c) {
         nvb = kOOB;
-        if constexpr (WX) {
-            wx_mask = 0;
-            const int pix0 = c * BK + 8 * wx_run;
-            if (pix0 < W_P) {
-                const int pb = pix0 / OHOW, rr = pix0 - pb * OHOW;
-                const int oh = rr / p.OW, ow0 = rr - oh * p.OW;
-                const int ih = oh + t_dh, iw0 = ow0 + t_dw;
-                if (ih >= 0 && ih < p.H && iw0 + 7 >= 0 && iw0 < p.W) {
-                    const int lo = iw0 < 0 ? -iw0 : 0, hi = p.W - iw0 < 8 ? p.W - iw0 : 8;     // valid elements [lo, hi)
-                    wx_mask = (0xffu >> (8 - hi)) & (0xffu << lo);
-                    wx_off = (int)((long long)pb * p.x_bs) + (ci0 + wx_row) * HW + ih * p.W + iw0;
-                    nvb = 0;
-                }
-            }
-            return;
-        }
         if (row_chunks) {
             const int first = c * BK;
             const int grow = first / p.OW, ow = first - grow * p.OW + px;
@@ -888,33 +792,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
         }
         return c;
     };
-    unsigned ld_mask = 0;              // wx_mask of the chunk whose x values sit in rb
     auto load_tiles = [&](int c) {
         const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
-        if constexpr (WX) {
-            ld_mask = wx_mask;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    // the four pixels [4h, 4h + 4) of row j: one 16-byte load wherever the quad lies inside the tensor
-                    const int off = wx_off + j * 64 * HW + 4 * h;
-                    const unsigned m4 = (wx_mask >> (4 * h)) & 15u;
-                    u32x4 q = {0u, 0u, 0u, 0u};
-                    if (off >= 0 && (unsigned)off * 4u + 16u <= p.x_bytes) {
-                        q = __builtin_amdgcn_raw_buffer_load_b128(rx, m4 ? (unsigned)off * 4u : kOOB, 0, 0);
-                    } else if (m4) {               // the tensor's first / last row: element by element
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            q[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, ((m4 >> e) & 1u) ? (unsigned)(off + e) * 4u : kOOB, 0, 0);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[j * 8 + 4 * h + e] = q[e];
-                }
-            return;
-        }
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
             rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
@@ -922,30 +803,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
     const bool even = (px & 1) == 0;
     const int pair = px >> 1;
     const unsigned st_b = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair >> 3) * K16B + (pair & 7) * 4);
-    const unsigned st_wx = (unsigned)(wx_row * ROW + (wx_run >> 1) * K16B + (wx_run & 1) * 16);
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
-        if constexpr (WX) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                unsigned pc[NP][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // values past the row's ends are whatever lies there in memory: the padding's zeros instead
-                    const float x0 = ((ld_mask >> (2 * e)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e]) : 0.f;
-                    const float x1 = ((ld_mask >> (2 * e + 1)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e + 1]) : 0.f;
-                    if constexpr (AR == 0)
-                        split3(x0, x1, pc[0][e], pc[1][e], pc[2][e]);
-                    else
-                        split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
-                }
-                unsigned char* d = Bs + st_wx + j * 64 * ROW;
-#pragma unroll
-                for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(d + c * 32) = u32x4{pc[c][0], pc[c][1], pc[c][2], pc[c][3]};
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < B_PER / 2; ++i) {
             const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];
@@ -1021,7 +881,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
 // unit (u ^ ((row >> 1) & 7)): the ds_read_b128 of a 16x16x32 operand (lane l: row l & 15, k-group l >> 4) then takes 16
 // distinct 16-byte slots of the 256-byte bank row in every one of its four lane groups (checked slot by slot against
 // the b128 lane groups of the LDS table); the plain padded rows of the 32x32x16 kernel are 2-way conflicted for it.
-// dY is pre-split into the same rows (dy_split16_kernel), x is staged as in the kernel above (narrow / WX).
+// dY is pre-split into the same rows (dy_split16_kernel), x is staged as in the kernel above.
 constexpr int kW16Row = 128;
 
 __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* __restrict__ out, int B, int Cout,
@@ -1074,11 +934,10 @@ __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* _
     }
 }
 
-// Tiles of 128 or 64 rows / columns (Cout % BM == 0, Cin % BN == 0): the 64-channel layers of layer1 run it too.
-template <int BM, int BN, bool WX>
+template <int BM, int BN>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
-    static_assert((BM == 64 || BM == 128) && (BN == 64 || BN == 128), "tile");
+    static_assert(BM == 128 && BN == 128, "tile");
     constexpr int BK = 32, ROW = kW16Row;
     constexpr int WN = 2;
     constexpr int TMI = BM / 32, TNI = BN / 32;             // 16 x 16 tiles of a wave (2 x 2 waves)
@@ -1139,28 +998,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 
     const bool row_chunks = (p.OW % BK) == 0;
     unsigned nvb = kOOB;
-    const int wx_run = tid & 3, wx_g = tid >> 2;
-    const int wx_row = (wx_g & ~3) | ((wx_g & 1) << 1) | ((wx_g >> 1) & 1);
-    int wx_off = 0;
-    unsigned wx_mask = 0;
     auto decode = [&](int c) {
         nvb = kOOB;
-        if constexpr (WX) {
-            wx_mask = 0;
-            const int pix0 = c * BK + 8 * wx_run;
-            if (pix0 < W_P) {
-                const int pb = pix0 / OHOW, rr = pix0 - pb * OHOW;
-                const int oh = rr / p.OW, ow0 = rr - oh * p.OW;
-                const int ih = oh + t_dh, iw0 = ow0 + t_dw;
-                if (ih >= 0 && ih < p.H && iw0 + 7 >= 0 && iw0 < p.W) {
-                    const int lo = iw0 < 0 ? -iw0 : 0, hi = p.W - iw0 < 8 ? p.W - iw0 : 8;
-                    wx_mask = (0xffu >> (8 - hi)) & (0xffu << lo);
-                    wx_off = (int)((long long)pb * p.x_bs) + (ci0 + wx_row) * HW + ih * p.W + iw0;
-                    nvb = 0;
-                }
-            }
-            return;
-        }
         if (row_chunks) {
             const int first = c * BK;
             const int grow = first / p.OW, ow = first - grow * p.OW + px;
@@ -1186,32 +1025,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         }
         return c;
     };
-    unsigned ld_mask = 0;
     auto load_tiles = [&](int c) {
         const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
-        if constexpr (WX) {
-            ld_mask = wx_mask;
-#pragma unroll
-            for (int j = 0; j < BN / 64; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int off = wx_off + j * 64 * HW + 4 * h;
-                    const unsigned m4 = (wx_mask >> (4 * h)) & 15u;
-                    u32x4 q = {0u, 0u, 0u, 0u};
-                    if (off >= 0 && (unsigned)off * 4u + 16u <= p.x_bytes) {
-                        q = __builtin_amdgcn_raw_buffer_load_b128(rx, m4 ? (unsigned)off * 4u : kOOB, 0, 0);
-                    } else if (m4) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            q[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, ((m4 >> e) & 1u) ? (unsigned)(off + e) * 4u : kOOB, 0, 0);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rb[j * 8 + 4 * h + e] = q[e];
-                }
-            return;
-        }
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
             rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
@@ -1221,27 +1038,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     // narrow form: rows 2 hw + (odd lane) + 16 i share (row >> 1) & 7 = hw & 7
     const unsigned st_row = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair & 3) * 4);
     const unsigned st_u0 = (unsigned)((((pair >> 2)) ^ (hw & 7)) << 4), st_u1 = (unsigned)(((4 + (pair >> 2)) ^ (hw & 7)) << 4);
-    // wide form: the run IS a 16-byte unit
-    const int wx_sw = (wx_row >> 1) & 7;
-    const unsigned stw0 = (unsigned)(wx_row * ROW + ((wx_run ^ wx_sw) << 4)), stw1 = (unsigned)(wx_row * ROW + (((4 + wx_run) ^ wx_sw) << 4));
     auto store_tiles = [&]() {
 #pragma unroll
         for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
-        if constexpr (WX) {
-#pragma unroll
-            for (int j = 0; j < BN / 64; ++j) {
-                unsigned pc[2][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = ((ld_mask >> (2 * e)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e]) : 0.f;
-                    const float x1 = ((ld_mask >> (2 * e + 1)) & 1u) ? __builtin_bit_cast(float, rb[j * 8 + 2 * e + 1]) : 0.f;
-                    split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
-                }
-                *reinterpret_cast<u32x4*>(Bs + stw0 + j * 64 * ROW) = u32x4{pc[0][0], pc[0][1], pc[0][2], pc[0][3]};
-                *reinterpret_cast<u32x4*>(Bs + stw1 + j * 64 * ROW) = u32x4{pc[1][0], pc[1][1], pc[1][2], pc[1][3]};
-            }
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < B_PER / 2; ++i) {
             const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];

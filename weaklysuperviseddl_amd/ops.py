@@ -172,8 +172,6 @@ def set_option(name, value):
     check(lib().wsdl_set_option(name.encode(), int(value)))
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
-    if name == "wgrad_tile64":
-        WGRAD_TILE64[0] = int(value != 0)
     LAYOUT_EPOCH[0] += 1
     bump_param_epoch()
 
@@ -367,14 +365,10 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     return dx
 
 
-WGRAD_TILE64 = [0]     # mirrors the library's "wgrad_tile64"
-
-
 def _wgrad_split(wshape):
     """May the library's fp16x2 weight-gradient kernel take this shape (then both operands need amax scalars - a read
     pass on the main stream for a tensor that carries none, so this must not claim more than the library's own rule)."""
-    q = 64 if WGRAD_TILE64[0] else 128
-    return CONV_ARITH[0] == 1 and wshape[0] % q == 0 and wshape[1] % q == 0
+    return CONV_ARITH[0] == 1 and wshape[0] % 128 == 0 and wshape[1] % 128 == 0
 
 
 def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None):
@@ -1167,6 +1161,40 @@ class _KLDivBatchMean(torch.autograd.Function):
 
 def kl_div_batchmean(xn, s):
     return _KLDivBatchMean.apply(xn, s)
+
+
+# ---- profiler ranges (roctx): WSDL_ROCTX=1 in the environment (or ranges_enable(True)) brackets the phases of a training step
+# and of a CAM batch, and every instrumented kernel class, with named ranges for `rocprofv3 --marker-trace`
+RANGES = [False]
+
+
+def ranges_enable(on=True):
+    check(lib().wsdl_range_enable(int(bool(on))))
+    RANGES[0] = bool(on)
+
+
+class prof_range:
+    """``with ops.prof_range("backward"): ...`` - a named roctx range when ranges are enabled, nothing otherwise."""
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if RANGES[0]:
+            lib().wsdl_range_push(self.name.encode())
+
+    def __exit__(self, *exc):
+        if RANGES[0]:
+            lib().wsdl_range_pop()
+        return False
+
+
+if os.environ.get("WSDL_ROCTX") == "1":
+    try:
+        ranges_enable(True)
+    except Exception:           # the profiler SDK is not there: run without ranges
+        RANGES[0] = False
 
 
 def prof_enable(on):
