@@ -414,12 +414,16 @@ def test_bn_fold_and_affine_bwd(dev):
     sc, sh = ops.bn_fold(gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), 1e-5)
     assert_close(sc, gamma / torch.sqrt(rv + 1e-5), rel=1e-6)
     assert_close(sh, beta - rm * gamma / torch.sqrt(rv + 1e-5), rel=1e-5)
-    y = torch.randn(2, C, 5, 5, generator=g)
-    dy = torch.randn(2, C, 5, 5, generator=g)
-    dconv, dres = ops.affine_act_bwd(dy.to(dev), y.to(dev), sc, True, True, True)
-    m = (y > 0).float()
-    assert_close(dres, dy * m, rel=1e-6)
-    assert_close(dconv, dy * m * sc.cpu().view(1, -1, 1, 1), rel=1e-6)
+    for hw in ((5, 5), (14, 14), (6, 10), (64, 48)):         # plane-per-workgroup form; flat float4 form (HW % 4 == 0, small); large planes
+        y = torch.randn(3, C, *hw, generator=g)
+        dy = torch.randn(3, C, *hw, generator=g)
+        dconv, dres = ops.affine_act_bwd(dy.to(dev), y.to(dev), sc, True, True, True)
+        m = (y > 0).float()
+        assert_close(dres, dy * m, rel=1e-6)
+        assert_close(dconv, dy * m * sc.cpu().view(1, -1, 1, 1), rel=1e-6)
+        assert abs(dconv._wsdl_amax.item() - dconv.abs().max().item()) <= 1e-6 * dconv.abs().max().item()
+        d2, _ = ops.affine_act_bwd(dy.to(dev), y.to(dev), None, True, True, False)      # plain ReLU backward
+        assert_close(d2, dy * m, rel=1e-6)
 
 
 @pytest.mark.parametrize("hw", [(16, 16), (15, 17), (7, 7), (112, 112)])

@@ -20,6 +20,8 @@ What runs where:
 ``generate_batch`` does B images at once (eval-mode BN makes images independent), removing the
 reference's per-image host round trips (``torch.cuda.empty_cache()`` LayerCAM.py:79).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -108,38 +110,80 @@ class LayerCAMGenerator:
         with ops.prof_range("layercam/epilogue"):
             return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
 
-    def generate_batches(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3):
+    def generate_batches(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3, graphs=None):
         """Several independent batches in flight: batch j runs on stream j % ``streams`` with a generator of its own over
-        the SAME model.  At B=8 and 224x224 a batch is ~160 launches of 25-100 workgroups - a fraction of the chip, and
+        the SAME model.  At B=8 and 224x224 a batch is ~130 launches of 25-100 workgroups - a fraction of the chip, and
         latency-bound; images are independent (eval-mode BatchNorm), so the batches of a loader can overlap.  Returns
-        the list of ``generate_batch`` results, identical to calling it batch by batch."""
+        the list of ``generate_batch`` results, identical to calling it batch by batch.
+
+        ``graphs`` (default: on for the staged path, WSDL_CAM_GRAPH=0 turns it off): each lane captures its batch once
+        per (shape, arguments) into a hipGraph and replays it.  Issuing a batch eagerly costs the host ~2.8 ms (Python,
+        ctypes and autograd around ~130 launches) - as long as the GPU needs for it - so three eager lanes were bound by
+        the one host thread; a replay is one host call, and the lanes really overlap on the device.  Same kernels, same
+        order: the results are those of the eager path bit for bit."""
         if class_idxs is None:
             class_idxs = [None] * len(batches)
         if streams <= 1 or len(batches) <= 1 or not batches[0].is_cuda:
             return [self.generate_batch(b, alpha, c, thresh) for b, c in zip(batches, class_idxs)]
+        if graphs is None:
+            graphs = self.staged and os.environ.get("WSDL_CAM_GRAPH", "1") != "0"
         dev = batches[0].device
         lanes = self.__dict__.setdefault("_lanes", [])
         while len(lanes) < streams:
-            lanes.append((torch.cuda.Stream(device=dev),
-                          LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged)))
-            ops.register_lane_stream(lanes[-1][0])
+            lanes.append({"stream": torch.cuda.Stream(device=dev), "graph": None, "key": None, "warm": False,
+                          "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged)})
+            ops.register_lane_stream(lanes[-1]["stream"])
         cur = torch.cuda.current_stream(dev)
         outs = []
         for j, (imgs, cls) in enumerate(zip(batches, class_idxs)):
-            st, gen = lanes[j % streams]
+            lane = lanes[j % streams]
+            st, gen = lane["stream"], lane["gen"]
             st.wait_stream(cur)                              # the inputs (and the cached weight layouts) are ready
             imgs.record_stream(st)
             if cls is not None:
-                cls = cls.to(dev)
+                cls = cls.to(dev).view(-1)
                 cls.record_stream(st)
             with torch.cuda.stream(st):
-                out = gen.generate_batch(imgs, alpha, cls, thresh)
+                out = self._lane_batch(lane, imgs, alpha, cls, thresh) if graphs else gen.generate_batch(imgs, alpha, cls, thresh)
             for t in (out if isinstance(out, tuple) else (out,)):
                 t.record_stream(cur)
             outs.append(out)
-        for st, _gen in lanes[:streams]:
-            cur.wait_stream(st)
+        for lane in lanes[:streams]:
+            cur.wait_stream(lane["stream"])
         return outs
+
+    @staticmethod
+    def _lane_batch(lane, imgs, alpha, cls, thresh):
+        """One batch on a lane through its hipGraph (current stream = the lane's): eager once (allocator, weight-layout
+        caches and lazy library state settle), then capture, then replay with the inputs copied into the captured
+        buffers; the outputs are cloned out of the graph's memory before the next replay overwrites them."""
+        gen = lane["gen"]
+        key = (tuple(imgs.shape), cls is not None, float(alpha), thresh)
+        if not lane["warm"]:
+            lane["warm"] = True
+            return gen.generate_batch(imgs, alpha, cls, thresh)
+        if lane["graph"] is None or lane["key"] != key:
+            dev = imgs.device
+            st = torch.cuda.current_stream(dev)
+            lane["s_imgs"] = imgs.clone()
+            lane["s_cls"] = cls.clone() if cls is not None else None
+            st.synchronize()
+            ops.reset_amax_pool(dev)                # the first slot request inside the capture allocates + zeroes a pool there
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, stream=st):
+                    lane["out"] = gen.generate_batch(lane["s_imgs"], alpha, lane["s_cls"], thresh)
+            finally:
+                ops.reset_amax_pool(dev)            # eager code must not hand out the graph's slots
+            lane["graph"], lane["key"] = g, key
+            lane["ws"] = ops._ws_cache.get((dev, st.cuda_stream))      # the captured launches keep pointing into this buffer
+        else:
+            lane["s_imgs"].copy_(imgs)
+            if cls is not None:
+                lane["s_cls"].copy_(cls)
+        lane["graph"].replay()
+        out = lane["out"]
+        return tuple(t.clone() for t in out) if isinstance(out, tuple) else out.clone()
 
     def generate(self, images, alpha=1.0, class_idx=None):
         """images (3,H,W) -> (1,outH,outW), as the reference (unsqueeze inside)."""
