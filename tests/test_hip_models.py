@@ -701,13 +701,19 @@ def test_amax_slot_pools_roll_over_per_stream(dev, cam_models):
     ops.AMAX_POOL_SLOTS[0] = 8
     try:
         ops.reset_amax_pool(dev)
-        for _ in range(2):
-            many = gen.generate_batches(batches, 1.0, classes, 0.3, streams=3)
+        for _ in range(2):                                          # eager lanes: the pools live on the lanes' streams
+            many = gen.generate_batches(batches, 1.0, classes, 0.3, streams=3, graphs=False)
             torch.cuda.synchronize()
             for (c1, m1), (c2, m2) in zip(serial, many):
                 assert torch.equal(c1, c2) and torch.equal(m1, m2)
         pools = [k for k in ops._amax_pools if k[0] == dev]
         assert len(pools) >= 3                                      # one per lane stream (plus the main stream's)
+        for _ in range(3):                                          # hipGraph lanes: pools allocated (and re-zeroed) inside the graphs
+            many = gen.generate_batches(batches, 1.0, classes, 0.3, streams=3, graphs=True)
+            torch.cuda.synchronize()
+            for (c1, m1), (c2, m2) in zip(serial, many):
+                assert torch.equal(c1, c2) and torch.equal(m1, m2)
+        assert all(lane["graph"] is not None for lane in gen._lanes[:3])
     finally:
         ops.AMAX_POOL_SLOTS[0] = old
         ops.reset_amax_pool(dev)
