@@ -323,7 +323,7 @@ def conv_class_totals(ops):
     return ms, work, exe, exe_split
 
 
-def cam_bench(device, iters=20, roofline=True):
+def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), roofline=True):
     from weaklysuperviseddl_amd import ops
     gen, imgs, cls = cam_setup(device)
     n_img = imgs.shape[0]

@@ -32,8 +32,11 @@ _ORDER = ["layer0", "layer1", "layer2", "layer3", "layer4"]
 
 class LayerCAMGenerator:
     def __init__(self, model, target_layer_names=("layer3", "layer4"), variant="modular", out_hw=(224, 224),
-                 staged=None):
+                 staged=None, auto_graph=True):
         self.model = model.eval()
+        # staged path only: a repeated call (same shapes, same model state) replays a hipGraph of the batch (_lane_batch)
+        self.auto_graph = bool(auto_graph) and os.environ.get("WSDL_CAM_GRAPH", "1") != "0" and \
+            os.environ.get("WSDL_CAM_SELF_GRAPH", "1") != "0"
         self.target_layer_names = list(target_layer_names)
         self.variant = variant
         self.out_hw = tuple(out_hw)
@@ -97,8 +100,37 @@ class LayerCAMGenerator:
         return logits
 
     # -- public API ---------------------------------------------------------------------------------
+    def _state_key(self):
+        """What a captured batch depends on besides its inputs: THIS model's parameters and statistics (a replay reads the
+        weight layouts and folded BatchNorm constants of capture time); any change re-captures.  Per-model indicators, not
+        the library's global epochs (another model's optimiser step must not invalidate this graph): tensor versions (torch-side
+        writes), the step counts of the optimisers that own parameters of the model (FlatAdam writes through raw pointers)
+        and the BatchNorm modules' train-mode forward counters (running statistics written by the kernels)."""
+        from .. import nn as wnn
+        m = self.model
+        versions = sum(t._version for t in m.parameters()) + sum(t._version for t in m.buffers())
+        sinks = {id(k): k.step_count for k in (getattr(p, "_wsdl_grad_sink", None) for p in m.parameters()) if k is not None}
+        bn_steps = sum(b._pending_steps for b in m.modules() if isinstance(b, wnn.BatchNorm2d))
+        return (ops.LAYOUT_EPOCH[0], m.training, versions, tuple(sorted(sinks.items())), bn_steps)
+
     def generate_batch(self, images, alpha=1.0, class_idx=None, thresh=None):
-        """images (B,3,H,W), class_idx LongTensor (B,) or None -> cam (B,outH,outW) [, uint8 mask]."""
+        """images (B,3,H,W), class_idx LongTensor (B,) or None -> cam (B,outH,outW) [, uint8 mask].
+        Staged path on the device: the second call with the same shapes captures the batch (~130 launches that cost the host
+        as long to issue as the GPU needs to run them) into a hipGraph, later calls replay it - same kernels, same results."""
+        if self.auto_graph and self.staged and images.is_cuda and not torch.cuda.is_current_stream_capturing():
+            lane = self.__dict__.get("_self_lane")
+            if lane is None:
+                lane = self.__dict__["_self_lane"] = {
+                    "graph": None, "key": None, "cap_stream": self._get_lanes(1, images.device)[0]["stream"],
+                    "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, True, auto_graph=False)}
+            if class_idx is not None:
+                class_idx = class_idx.to(images.device).view(-1)
+            out = self._lane_batch(lane, images, float(alpha), class_idx, thresh, self._state_key())
+            self.activations, self.gradients = lane["gen"].activations, lane["gen"].gradients
+            return out
+        return self._generate_batch_eager(images, alpha, class_idx, thresh)
+
+    def _generate_batch_eager(self, images, alpha=1.0, class_idx=None, thresh=None):
         self.activations.clear()
         self.gradients.clear()
         if class_idx is not None:
@@ -128,13 +160,10 @@ class LayerCAMGenerator:
         if graphs is None:
             graphs = self.staged and os.environ.get("WSDL_CAM_GRAPH", "1") != "0"
         dev = batches[0].device
-        lanes = self.__dict__.setdefault("_lanes", [])
-        while len(lanes) < streams:
-            lanes.append({"stream": torch.cuda.Stream(device=dev), "graph": None, "key": None, "warm": False,
-                          "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged)})
-            ops.register_lane_stream(lanes[-1]["stream"])
+        lanes = self._get_lanes(streams, dev)
         cur = torch.cuda.current_stream(dev)
         outs = []
+        state = self._state_key() if graphs else None
         for j, (imgs, cls) in enumerate(zip(batches, class_idxs)):
             lane = lanes[j % streams]
             st, gen = lane["stream"], lane["gen"]
@@ -144,7 +173,7 @@ class LayerCAMGenerator:
                 cls = cls.to(dev).view(-1)
                 cls.record_stream(st)
             with torch.cuda.stream(st):
-                out = self._lane_batch(lane, imgs, alpha, cls, thresh) if graphs else gen.generate_batch(imgs, alpha, cls, thresh)
+                out = self._lane_batch(lane, imgs, float(alpha), cls, thresh, state) if graphs else gen.generate_batch(imgs, alpha, cls, thresh)
             for t in (out if isinstance(out, tuple) else (out,)):
                 t.record_stream(cur)
             outs.append(out)
@@ -152,31 +181,47 @@ class LayerCAMGenerator:
             cur.wait_stream(lane["stream"])
         return outs
 
+    def _get_lanes(self, n, dev):
+        """The generator's lanes (stream + a plain generator over the same model each), created on demand.  The process
+        should not hold more streams than it has hardware queues (4 by default on ROCm): with a fifth stream in use two lanes
+        shared a queue and three batches in flight took 0.27 ms/img instead of 0.185 - so the one-batch graph of
+        ``generate_batch`` is captured on lane 0's stream instead of on a stream of its own."""
+        lanes = self.__dict__.setdefault("_lanes", [])
+        while len(lanes) < n:
+            lanes.append({"stream": torch.cuda.Stream(device=dev), "graph": None, "key": None,
+                          "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged,
+                                                   auto_graph=False)})
+            ops.register_lane_stream(lanes[-1]["stream"])
+        return lanes
+
     @staticmethod
-    def _lane_batch(lane, imgs, alpha, cls, thresh):
+    def _lane_batch(lane, imgs, alpha, cls, thresh, state=None):
         """One batch on a lane through its hipGraph (current stream = the lane's): eager once (allocator, weight-layout
         caches and lazy library state settle), then capture, then replay with the inputs copied into the captured
         buffers; the outputs are cloned out of the graph's memory before the next replay overwrites them."""
         gen = lane["gen"]
-        key = (tuple(imgs.shape), cls is not None, float(alpha), thresh)
-        if not lane["warm"]:
-            lane["warm"] = True
-            return gen.generate_batch(imgs, alpha, cls, thresh)
+        key = (tuple(imgs.shape), cls is not None, float(alpha), thresh, state)
+        warm = lane.setdefault("warm_shapes", set())
+        if key[:2] not in warm:                     # a shape's first batch runs eagerly (lazy library state, allocator)
+            warm.add(key[:2])
+            return gen._generate_batch_eager(imgs, alpha, cls, thresh)
         if lane["graph"] is None or lane["key"] != key:
             dev = imgs.device
             st = torch.cuda.current_stream(dev)
+            # capture needs a non-default stream; a lane already is one, the caller's own stream may be the default stream
+            cap = st if st != torch.cuda.default_stream(dev) else lane["cap_stream"]
             lane["s_imgs"] = imgs.clone()
             lane["s_cls"] = cls.clone() if cls is not None else None
             st.synchronize()
             ops.reset_amax_pool(dev)                # the first slot request inside the capture allocates + zeroes a pool there
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, stream=st):
-                    lane["out"] = gen.generate_batch(lane["s_imgs"], alpha, lane["s_cls"], thresh)
+                with torch.cuda.graph(g, stream=cap):
+                    lane["out"] = gen._generate_batch_eager(lane["s_imgs"], alpha, lane["s_cls"], thresh)
             finally:
                 ops.reset_amax_pool(dev)            # eager code must not hand out the graph's slots
             lane["graph"], lane["key"] = g, key
-            lane["ws"] = ops._ws_cache.get((dev, st.cuda_stream))      # the captured launches keep pointing into this buffer
+            lane["ws"] = ops._ws_cache.get((dev, cap.cuda_stream))     # the captured launches keep pointing into this buffer
         else:
             lane["s_imgs"].copy_(imgs)
             if cls is not None:
