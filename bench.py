@@ -338,7 +338,7 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
     out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
     # stage 1 as generate_pseudo_masks runs it: three of the loader's batches of 8 in flight on three streams
-    nb, lanes = 6, 3
+    nb, lanes = int(os.environ.get("WSDL_CAM_NB", "6")), int(os.environ.get("WSDL_CAM_LANES", "3"))
     gen.generate_batches([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -1615,6 +1615,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_min_chunks")) { g_ksplit_min_chunks = value > 0 ? value : 1; return WSDL_OK; }
     if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
+    if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }

@@ -7,6 +7,7 @@
 #include <cstdint>
 
 int wsdl::g_bn_resident = 1;
+int wsdl::g_bn_wide_c = 512;      // channel counts up to which the resident kernels run 1024 threads x 4 float4 ("bn_wide_c" option, 0 = never)
 
 namespace {
 // i / d for the (b, hw) decompositions of the BatchNorm kernels: the plane sizes of the networks are powers of two, and
@@ -258,13 +259,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // the statistics, and applies the normalisation (forward) / the input gradient (backward) from registers - the
 // second pass over x (forward) and over x, dy and the ReLU mask (backward) of the two-kernel form never happens.
 // Same arithmetic: double sums, fixed reduction tree (bitwise reproducible).  grid = C.
-template <int NT>
+template <int NT, int V = 16>
 __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
     long long y_bs, int relu, float* __restrict__ amax) {
-    constexpr int V = 16;                         // float4 per thread
+    // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
+    // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -323,14 +325,13 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     if (amax) publish_amax(vmax, amax);
 }
 
-template <int NT>
+template <int NT, int V = 16>
 __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ y,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
     float* __restrict__ amax, const float* __restrict__ beta) {
-    constexpr int V = 16;
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -402,6 +403,9 @@ static int resident_threads(int C, long long n, int HW) {
     // g_bn_resident: 0 off, 1 = from 192 channels (fewer workgroups than that leave most CUs idle), n > 1 = from n channels
     const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 192;
     if (!wsdl::g_bn_resident || C < min_c || (HW & 3) != 0) return 0;
+    // 256 / 512 channels = one or two workgroups per CU: with four waves each a CU moved 7-11 GB/s (17.6 / 22.3 us for the
+    // 16.8 MB tensors of the 256-channel layers: 1.9 / 2.3 TB/s); sixteen waves of a quarter of the work each do better
+    if (n <= 1024 * 16 && C <= wsdl::g_bn_wide_c) return 1024;
     if (n <= 256 * 64) return 256;
     if (n <= 512 * 64) return 512;
     return 0;
@@ -686,7 +690,11 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
-        if (nt == 256)
+        if (nt == 1024)
+            hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
+                               y_amax);
+        else if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
                                y_amax);
@@ -726,7 +734,11 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
-        if (nt == 256)
+        if (nt == 1024)
+            hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                               dx_amax, beta);
+        else if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
                                dx_amax, beta);
