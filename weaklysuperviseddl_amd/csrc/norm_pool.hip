@@ -403,9 +403,11 @@ static int resident_threads(int C, long long n, int HW) {
     // g_bn_resident: 0 off, 1 = from 192 channels (fewer workgroups than that leave most CUs idle), n > 1 = from n channels
     const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 192;
     if (!wsdl::g_bn_resident || C < min_c || (HW & 3) != 0) return 0;
-    // 256 / 512 channels = one or two workgroups per CU: with four waves each a CU moved 7-11 GB/s (17.6 / 22.3 us for the
-    // 16.8 MB tensors of the 256-channel layers: 1.9 / 2.3 TB/s); sixteen waves of a quarter of the work each do better
-    if (n <= 1024 * 16 && C <= wsdl::g_bn_wide_c) return 1024;
+    // 256 / 512 channels = one or two workgroups per CU.  Sixteen waves of a quarter of the work each instead of four:
+    // forward 14.5 -> 11.6 us (256 channels) and 21.5 -> 16.6 us (512) on the 16 x 32 x 32 maps; backward 16.2 -> 15.0 us at 256
+    // channels but 22.0 -> 23.3 us at 512 (three tensors in flight per thread already): wide up to 512 / 256 channels
+    // (tools/bn_bench.py, profiles/r03_notes.md)
+    if (n <= 1024 * 16 && C <= (backward ? wsdl::g_bn_wide_c / 2 : wsdl::g_bn_wide_c)) return 1024;
     if (n <= 256 * 64) return 256;
     if (n <= 512 * 64) return 512;
     return 0;
@@ -733,7 +735,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!dy_bs) dy_bs = (long long)C * HW;
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
-    if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
+    if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW, true) : 0) {
         if (nt == 1024)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
