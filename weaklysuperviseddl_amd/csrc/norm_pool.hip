@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
 }
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
-static int resident_threads(int C, long long n, int HW) {
+static int resident_threads(int C, long long n, int HW, bool backward = false) {
     // g_bn_resident: 0 off, 1 = from 192 channels (fewer workgroups than that leave most CUs idle), n > 1 = from n channels
     const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 192;
     if (!wsdl::g_bn_resident || C < min_c || (HW & 3) != 0) return 0;
