@@ -7,6 +7,10 @@ O=$R/gpurun_out/refresh
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 step() { echo "[refresh] $*" >&2; }
+# WSDL_REFRESH_PART=A: bench, kernel stats, PMC traffic, roctx markers, MFMA busy of the step;  B: per-shape tables, 3x3 MFMA busy,
+# other configs (gpurun calls are limited to 20 minutes: the whole script does not fit one call);  unset: everything
+PART=${WSDL_REFRESH_PART:-AB}
+if [[ $PART == *A* ]]; then
 
 step "bench (full: roofline + cam + cpu baseline)"
 python3 $R/bench.py > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
@@ -39,6 +43,8 @@ step "PMC: MFMA busy cycles of the whole step"
 rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d $O/b_m -- python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --steps 3 --warmup 1 --serial > /dev/null 2>&1 || exit 1
 python3 $R/tools/pmc_table.py $O/b_m > $O/pmc_mfma_busy.txt 2>&1
 
+fi
+if [[ $PART == *B* ]]; then
 step "per-shape conv table (default fp16x2, bf16x3, fp32-MFMA kernels)"
 python3 $R/tools/conv_shapes_bench.py > $O/conv_shapes.txt 2>&1 || exit 1
 python3 $R/tools/conv_shapes_bench.py --opt conv_arith=0 > $O/conv_shapes_bf16x3.txt 2>&1 || exit 1
@@ -59,4 +65,6 @@ python3 $R/bench.py --no-cpu-baseline --no-cam --graph 1 > $O/bench_n1_hipgraph.
 step "loss / CAM kernels, other configs"
 python3 $R/tools/loss_cam_bench.py > $O/loss_cam_kernels.txt 2>&1 || exit 1
 python3 $R/tools/configs_bench.py > $O/other_configs.txt 2>&1 || exit 1
+python3 $R/tools/bn_bench.py > $O/bn_kernels.txt 2>&1 || exit 1
+fi
 step done
