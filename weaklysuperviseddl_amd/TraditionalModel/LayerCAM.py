@@ -184,14 +184,14 @@ class LayerCAMGenerator:
     def _get_lanes(self, n, dev):
         """The generator's lanes (stream + a plain generator over the same model each), created on demand.  The process
         should not hold more streams than it has hardware queues (4 by default on ROCm): with a fifth stream in use two lanes
-        shared a queue and three batches in flight took 0.27 ms/img instead of 0.185 - so the one-batch graph of
+        shared a queue and three batches in flight took 0.27 ms/img instead of 0.185 - so the lanes run on the library's
+        streams (``ops.lane_stream``: the side stream, the prep stream, then one more) and the one-batch graph of
         ``generate_batch`` is captured on lane 0's stream instead of on a stream of its own."""
         lanes = self.__dict__.setdefault("_lanes", [])
         while len(lanes) < n:
-            lanes.append({"stream": torch.cuda.Stream(device=dev), "graph": None, "key": None,
+            lanes.append({"stream": ops.lane_stream(dev, len(lanes)), "graph": None, "key": None,
                           "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged,
                                                    auto_graph=False)})
-            ops.register_lane_stream(lanes[-1]["stream"])
         return lanes
 
     @staticmethod

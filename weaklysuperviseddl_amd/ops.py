@@ -201,9 +201,8 @@ def amax_slot(device):
         if not torch.cuda.is_current_stream_capturing():
             # slots are read by kernels on the other streams of this library (weight gradients on the side stream, the
             # main stream joining a CAM lane): keep the caching allocator from recycling a retired pool under them
-            for st in [_side_streams.get(device)] + [lane for lane in _lane_streams.get(device, [])]:
-                if st is not None:
-                    buf.record_stream(st)
+            for st in library_streams(device):
+                buf.record_stream(st)
             buf.record_stream(torch.cuda.default_stream(device))
         pool = [buf, 0]
         _amax_pools[key] = pool
@@ -212,11 +211,29 @@ def amax_slot(device):
     return pool[0][i:i + 1]
 
 
-_lane_streams = {}     # device -> extra streams of this library that may read amax slots (LayerCAM lanes)
+_lane_streams = {}     # device -> the library's streams beyond the side and the prep stream (LayerCAM lanes 2, 3, ...)
 
 
-def register_lane_stream(stream):
-    _lane_streams.setdefault(stream.device, []).append(stream)
+def lane_stream(device, i):
+    """The i-th extra stream of the library on ``device``.  A ROCm process has four hardware queues by default and HIP
+    streams beyond them share one (their work then runs one behind the other): a training step that has run in the process
+    holds the side stream (and possibly the prep stream), so LayerCAM lanes with streams of their own made three batches in
+    flight take 0.27 ms/img instead of 0.185.  Lanes 0 and 1 therefore ARE the side and the prep stream; only further
+    lanes create streams, once per device whatever the number of generators."""
+    device = device if isinstance(device, torch.device) else torch.device(device)
+    if i == 0:
+        return side_stream(device)
+    if i == 1:
+        return prep_stream(device)
+    more = _lane_streams.setdefault(device, [])
+    while len(more) < i - 1:
+        more.append(torch.cuda.Stream(device=device))
+    return more[i - 2]
+
+
+def library_streams(device):
+    """Every stream this library has created on ``device`` (amax slots may be read on any of them)."""
+    return [st for st in (_side_streams.get(device), _prep_streams.get(device)) if st is not None] + list(_lane_streams.get(device, []))
 
 
 def _publish_amax(t, slot):
