@@ -514,7 +514,8 @@ def build_workload(cfg, B, S, device, rank, graph=False):
         loader = [(imgs224.to(device), (labels, None))]
 
         def step():
-            generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=device)
+            generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=device,
+                                  keep_on_device=True)
             masks = generate_pseudo_masks.last_masks
             img, m = stage_handoff(loader[0][0], masks, (S, S), device)
             return train_step(model, opt, img, m.long())

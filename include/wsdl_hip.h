@@ -314,6 +314,14 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
                            float alpha, int variant, float* cam, float thresh, uint8_t* mask,
                            void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
+/* keep_largest (TraditionalModel/PsuedoMasks.py:15-21: skimage label + regionprops, the largest area wins, the first
+ * label on ties, an empty mask stays empty) for n masks (n,h,w) of uint8 (non-zero = foreground) -> out (n,h,w) in {0,1};
+ * 8-connectivity, labels in raster order of a component's first pixel as skimage numbers them.  One workgroup per mask,
+ * labels in LDS up to 65535 pixels (224 x 224), in the workspace beyond.  out may alias mask.  Bit-exact. */
+size_t wsdl_keep_largest_workspace(int n, int h, int w);
+int wsdl_keep_largest(const uint8_t* mask, uint8_t* out, int n, int h, int w, void* ws, size_t ws_bytes,
+                      wsdl_stream_t stream);
+
 /* classic CAM normalisation (CAMGenerator.generate_all_cams, TraditionalModel/AlternatingDirectionCutLoss.py:343-372):
  * y = (relu(x) - min) / (max + 1e-8) per plane; the class-weighted channel sum itself is wsdl_conv2d_fwd with
  * fc.weight as a 1x1 kernel. */

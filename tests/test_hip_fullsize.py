@@ -346,3 +346,10 @@ def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
     masks2, img2, m2, losses2, p2, g2 = chain()
     assert all(np.array_equal(a, b) for a, b in zip(masks, masks2)) and torch.equal(img, img2) and torch.equal(m, m2)
     assert losses == losses2 and torch.equal(p1, p2) and torch.equal(g1, g2)
+    # the sync-free form of the chain (bench.py's cfg4 step): masks stay on the device from the CAM to the training step
+    generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev, keep_on_device=True)
+    dmasks = generate_pseudo_masks.last_masks
+    assert all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.uint8 for x in dmasks) and len(dmasks) == 16
+    assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(dmasks, masks))
+    img3, m3 = stage_handoff(imgs224, dmasks, (256, 256), dev)
+    assert torch.equal(img3, img) and torch.equal(m3, m)

@@ -749,3 +749,95 @@ def test_train_step_with_lovasz_softmax(dev):
     img, masks = bench.synthetic_batch(4, 64, 64, dev, 3)
     losses = [float(train_step(model, opt, img, masks, loss_fn="lovasz_softmax")) for _ in range(6)]
     assert all(np.isfinite(losses)) and min(losses[2:]) < losses[0], losses
+
+
+# ------------------------------------------------------------------ keep_largest on the device (PsuedoMasks.py:15-21)
+def _spiral(n):
+    """ONE 1-pixel-wide arm winding inwards with a 1-pixel gap: the component with the longest label-propagation path."""
+    m = np.zeros((n, n), np.uint8)
+    r, c, dr, dc = 0, 0, 0, 1
+    m[0, 0] = 1
+    turns = 0
+    while turns < 2:
+        nr, nc, ar, ac = r + dr, c + dc, r + 2 * dr, c + 2 * dc
+        ahead_taken = 0 <= ar < n and 0 <= ac < n and m[ar, ac]
+        if 0 <= nr < n and 0 <= nc < n and not m[nr, nc] and not ahead_taken:
+            r, c, turns = nr, nc, 0
+            m[r, c] = 1
+        else:
+            dr, dc, turns = dc, -dr, turns + 1
+    return m
+
+
+def _keep_largest_cases():
+    rng = np.random.RandomState(7)
+    cases = {}
+    for p in (0.1, 0.3, 0.45, 0.5, 0.6, 0.9):
+        cases[f"noise{p}"] = (rng.rand(224, 224) < p).astype(np.uint8)
+    yy, xx = np.mgrid[0:224, 0:224]
+    blobs = np.zeros((224, 224), np.uint8)
+    for cy, cx, r in ((60, 70, 40), (150, 160, 55), (30, 190, 20), (200, 30, 18)):
+        blobs |= ((yy - cy) ** 2 + (xx - cx) ** 2 < r * r).astype(np.uint8)
+    cases["blobs"] = blobs
+    cases["blobs_noisy"] = blobs | (rng.rand(224, 224) < 0.05).astype(np.uint8)
+    tie = np.zeros((224, 224), np.uint8)
+    tie[100:110, 150:160] = 1           # three components of 100 pixels: the first in raster order must win ...
+    tie[20:30, 200:210] = 1
+    tie[20:30, 10:20] = 1               # ... this one (same first row as the one before it, further left)
+    cases["tie"] = tie
+    cases["empty"] = np.zeros((224, 224), np.uint8)
+    cases["full"] = np.ones((224, 224), np.uint8)
+    cases["values"] = (blobs * 255).astype(np.uint8)                      # any non-zero value is foreground
+    cases["checker"] = ((yy + xx) % 2).astype(np.uint8)                   # diagonal neighbours connect (8-connectivity)
+    cases["spiral"] = _spiral(224)
+    comb = np.zeros((224, 224), np.uint8)                                 # teeth joined only by the LAST row
+    comb[:, ::2] = 1
+    comb[-1, :] = 1
+    cases["comb"] = comb
+    cases["ragged"] = (rng.rand(37, 53) < 0.55).astype(np.uint8)
+    cases["one_pixel"] = np.ones((1, 1), np.uint8)
+    cases["one_row"] = (rng.rand(1, 300) < 0.7).astype(np.uint8)
+    cases["one_col"] = (rng.rand(300, 1) < 0.7).astype(np.uint8)
+    cases["max_lds"] = (rng.rand(255, 257) < 0.52).astype(np.uint8)       # 65535 pixels: the last size with LDS labels
+    cases["big"] = (rng.rand(300, 310) < 0.55).astype(np.uint8)           # 32-bit labels in the workspace
+    cases["big_spiral"] = _spiral(320)
+    return cases
+
+
+def test_keep_largest_device_equals_the_reference_function(dev, golden):
+    """Bit-exact: against the fixture made by the reference's own keep_largest (skimage, tests/golden/make_golden.py), the
+    oracle on shapes the fixture does not hold (noise at the percolation threshold, ties, spirals, 8-connectivity, sizes
+    either side of the LDS limit), batched (different masks in one launch) and in place."""
+    import oracle
+    from weaklysuperviseddl_amd import ops
+    g = golden("keep_largest")
+    names = sorted(k[3:] for k in g.files if k.startswith("in_"))
+    assert names
+    for n in names:
+        m = np.ascontiguousarray(g["in_" + n]).astype(np.uint8)
+        out = ops.keep_largest_batched(T(m).to(dev)).cpu().numpy()
+        assert np.array_equal(out, g["out_" + n]), n
+    cases = _keep_largest_cases()
+    for n, m in cases.items():
+        want = np.asarray(oracle.keep_largest(m)).astype(np.uint8)
+        out = ops.keep_largest_batched(T(m).to(dev)).cpu().numpy()
+        assert out.dtype == np.uint8 and np.array_equal(out, want), (n, int(out.sum()), int(want.sum()))
+    # one launch over a batch of different 224 x 224 masks; bool input; in place through the C ABI
+    batch = [k for k, v in cases.items() if v.shape == (224, 224)]
+    stack = np.stack([cases[k] for k in batch])
+    want = np.stack([np.asarray(oracle.keep_largest(cases[k])).astype(np.uint8) for k in batch])
+    assert np.array_equal(ops.keep_largest_batched(T(stack).to(dev)).cpu().numpy(), want)
+    assert np.array_equal(ops.keep_largest_batched(T(stack != 0).to(dev)).cpu().numpy(), want)
+    from weaklysuperviseddl_amd._lib import lib
+    from weaklysuperviseddl_amd.ops import _p, _stream, workspace, check
+    buf = T(stack).to(dev)
+    nb = lib().wsdl_keep_largest_workspace(*stack.shape)
+    ws = workspace(nb, dev)
+    check(lib().wsdl_keep_largest(_p(buf), _p(buf), *stack.shape, _p(ws), ws.numel(), _stream()))
+    assert np.array_equal(buf.cpu().numpy(), want)
+    # idempotent
+    assert np.array_equal(ops.keep_largest_batched(T(want).to(dev)).cpu().numpy(), want)
+    with pytest.raises(ops.WsdlError):
+        ops.keep_largest_batched(torch.zeros(2, 8, 8, device=dev))         # float masks are refused, not cast
+    with pytest.raises(ops.WsdlError):
+        ops.keep_largest_batched(torch.zeros(2, 8, 8, dtype=torch.uint8))   # no CPU fallback

@@ -14,8 +14,11 @@ Mirrors reference TraditionalModel/PsuedoMasks.py: ``keep_largest`` (:15-21) and
     (SURVEY.md 8e); image ids stay the global ones, so the union over the ranks is the single-process result;
   * ``streams``: that many of the loader's batches are in flight on the device at once (``LayerCAMGenerator.generate_batches``);
     the masks are the same bit for bit;
-  * ``keep_largest`` stays on the host as in the reference (skimage there; scipy.ndimage here -
-    8-connectivity, raster label order, first label wins area ties, empty mask returned unchanged).
+  * ``keep_largest(mask)`` is the reference's host function (skimage there; scipy.ndimage here - 8-connectivity, raster
+    label order, first label wins area ties, empty mask returned unchanged).  ``generate_pseudo_masks`` itself labels
+    the whole batch on the device (``keep_largest_batched`` -> ``ops.keep_largest_batched``, one workgroup per mask, the
+    same result bit for bit): one device->host copy of the FINAL masks per batch, and none at all with
+    ``keep_on_device=True`` - the in-memory hand-off to stage 2 then never synchronises with the host.
 """
 import os
 
@@ -36,6 +39,19 @@ def keep_largest(mask):
     return (lab == (int(np.argmax(areas)) + 1)).astype(np.uint8)
 
 
+def _to_device_async(t, device):
+    """Host tensors go through pinned memory: a copy from pageable memory makes the host wait until the stream has
+    drained - one such copy per batch (the labels) serialised stage 1 with whatever the device was still running."""
+    if t.is_cuda or torch.device(device).type != "cuda":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+def keep_largest_batched(masks):
+    """``keep_largest`` for a (N,H,W) batch of uint8 device masks, on the device."""
+    return ops.keep_largest_batched(masks)
+
+
 def _to_png_u8(t):
     """torchvision.utils.save_image's quantisation: mul(255).add_(0.5).clamp_(0, 255) -> uint8, HWC."""
     return t.mul(255).add(0.5).clamp(0, 255).permute(1, 2, 0).to(torch.uint8).cpu().numpy()
@@ -43,7 +59,7 @@ def _to_png_u8(t):
 
 def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_largest_masks=True,
                           run_id="default", out_root="/content", max_images=500, write_png=True,
-                          device="cuda", rank=0, world=1, keep_images=False, streams=3):
+                          device="cuda", rank=0, world=1, keep_images=False, streams=3, keep_on_device=False):
     mask_dir = os.path.join(out_root, f"pseudo_masks_{run_id}")
     image_dir = os.path.join(out_root, f"images_{run_id}")
     if write_png:
@@ -67,10 +83,12 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
             if hasattr(layercam_gen, "generate_batches") else \
             [layercam_gen.generate_batch(g[1], alpha=alpha, class_idx=g[2], thresh=cam_thresh) for g in group]
         for (imgs, _d, _l, first_id, take), (_cam, m) in zip(group, outs):
-            m_host = m.cpu().numpy()
+            if keep_largest_masks:
+                m = keep_largest_batched(m)
+            m_host = m if keep_on_device and not write_png else m.cpu().numpy()
             for i in range(take):
                 gid = first_id + i
-                mi = keep_largest(m_host[i]) if keep_largest_masks else m_host[i]
+                mi = m_host[i]
                 masks.append(mi)
                 ids.append(gid)
                 if keep_images:
@@ -90,8 +108,8 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
         if j % world != rank:
             img_id += take
             continue
-        imgs_d = imgs[:take].to(device, non_blocking=True)
-        labels_d = torch.as_tensor(labels[:take]).to(device)
+        imgs_d = _to_device_async(imgs[:take], device)
+        labels_d = _to_device_async(torch.as_tensor(labels[:take]), device)
         group.append((imgs, imgs_d, labels_d, img_id, take))
         img_id += take
         if len(group) >= max(1, streams):
@@ -108,6 +126,18 @@ generate = generate_pseudo_masks   # north-star alias "PsuedoMasks.generate"
 
 _MEAN = (0.485, 0.456, 0.406)
 _STD = (0.229, 0.224, 0.225)
+
+
+_norm_cache = {}
+
+
+def _norm_constants(device):
+    """ImageNet mean / std on ``device``, made once: ``torch.tensor(..., device=...)`` is a copy from pageable host memory
+    and makes the host wait for the stream - per call it put stage 1 -> stage 2 in lockstep with the device."""
+    key = str(torch.device(device))
+    if key not in _norm_cache:
+        _norm_cache[key] = (torch.tensor(_MEAN, device=device).view(1, 3, 1, 1), torch.tensor(_STD, device=device).view(1, 3, 1, 1))
+    return _norm_cache[key]
 
 
 def nearest_resize_index(n_out, n_in, device):
@@ -135,10 +165,12 @@ def stage_handoff(images, masks, size=(256, 256), device="cuda"):
         q = ops.bilinear_resize(q.contiguous(), (q.shape[-2], W)).add(0.5).floor().clamp(0, 255)
     if q.shape[-2] != H:
         q = ops.bilinear_resize(q.contiguous(), (H, W)).add(0.5).floor().clamp(0, 255)
-    mean = torch.tensor(_MEAN, device=device).view(1, 3, 1, 1)
-    std = torch.tensor(_STD, device=device).view(1, 3, 1, 1)
+    mean, std = _norm_constants(device)
     img = (q / 255.0 - mean) / std
-    m = torch.as_tensor(np.asarray(masks)).to(device)
+    if isinstance(masks, (list, tuple)) and len(masks) and torch.is_tensor(masks[0]):
+        m = torch.stack(list(masks)).to(device)                        # device masks (keep_on_device): no host round trip
+    else:
+        m = torch.as_tensor(masks if torch.is_tensor(masks) else np.asarray(masks)).to(device)
     m = (m != 0).to(torch.uint8) * 255
     if tuple(m.shape[-2:]) != (H, W):
         ih = nearest_resize_index(H, m.shape[-2], device)

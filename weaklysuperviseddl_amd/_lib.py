@@ -67,6 +67,8 @@ SIGNATURES = {
     "wsdl_layercam_workspace": (_sz, [_i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "wsdl_layercam_epilogue": (_i, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                                     _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
+    "wsdl_keep_largest_workspace": (_sz, [_i, _i, _i]),
+    "wsdl_keep_largest": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "wsdl_plane_relu_minmax": (_i, [_vp, _vp, _i, _i, _vp]),
     "wsdl_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     "wsdl_kl_div_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),

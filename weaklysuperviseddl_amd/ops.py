@@ -1112,6 +1112,28 @@ def layercam_epilogue(acts, grads, out_hw=(224, 224), alpha=1.0, variant="modula
     return (cam, mask) if thresh is not None else cam
 
 
+def keep_largest_batched(masks):
+    """(N,H,W) (or (H,W)) uint8 / bool device masks -> uint8 {0,1}: the largest 8-connected component of each mask, the
+    first in raster order on area ties, an empty mask stays empty (reference PsuedoMasks.py:15-21, per image on the host
+    there).  No host synchronisation."""
+    if masks.dtype == torch.bool:
+        masks = masks.to(torch.uint8)
+    if masks.dtype != torch.uint8:
+        raise WsdlError("keep_largest: masks must be uint8 or bool")
+    m = _req(masks, "masks", torch.uint8).contiguous()
+    m3 = m.view(-1, m.shape[-2], m.shape[-1])
+    out = torch.empty_like(m3)
+    if m3.numel() == 0:
+        return out.view(m.shape)
+    n, h, w = m3.shape
+    nbytes = lib().wsdl_keep_largest_workspace(n, h, w)
+    if nbytes == 0:
+        raise WsdlError("keep_largest: bad mask geometry")
+    ws = workspace(nbytes, m.device)
+    check(lib().wsdl_keep_largest(_p(m3), _p(out), n, h, w, _p(ws), ws.numel(), _stream()))
+    return out.view(m.shape)
+
+
 def plane_relu_minmax(x):
     """(..., h, w) -> per-plane (relu(x) - min) / (max + 1e-8)."""
     x = _dense(x, "x")
