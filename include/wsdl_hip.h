@@ -65,6 +65,9 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      192 channels, n > 1 = from n channels; measured: resident wins at every channel count)
+ *   bn_wide_c    512*  resident BatchNorm kernels as 1024 threads x 4 float4 (instead of 256 x 16) up to this channel count
+ *                      (half of it for the backward): 16 waves per CU loading at once where one workgroup per channel would
+ *                      leave a CU with 4 - forward -20..23 %, backward -7 % at 256 channels (profiles/r03_bn_kernels.txt)
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
  *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,
