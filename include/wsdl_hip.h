@@ -199,10 +199,14 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float momentum, float eps, int B, int C, int HW,
                       const float* residual, int relu, long long y_bs,
                       float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
+                      uint8_t* relu_mask /* optional (relu, HW % 8 == 0, y_bs % 4 == 0): B*C*HW/8 bytes, bit e%8 of byte
+                                            e/8 = [y > 0] for the dense element index e - for relu = 3 of the backward */,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* Backward of the above.  relu = 1: the ReLU mask is read from the forward output y (needed when a residual was
  * added); relu = 2: the mask is recomputed from x - y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
- * expression - so y is neither read nor needs keeping (y may be NULL, beta is required); relu = 0: no activation.
+ * expression - so y is neither read nor needs keeping (y may be NULL, beta is required); relu = 3: the mask is read from
+ * the bits the forward wrote (relu_mask: 1/32 of y's bytes - the residual layers' backward reads four tensor streams
+ * instead of five; same result bit for bit as relu = 1); relu = 0: no activation.
  * dres (optional) receives the masked upstream gradient (the residual branch's gradient). */
 int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd,
@@ -210,6 +214,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       int B, int C, int HW, int relu, int accumulate_param_grads,
                       long long dy_bs, long long y_bs,
                       float* dx_amax /* optional: atomicMax of max|dx| into a ZEROED device scalar */,
+                      const uint8_t* relu_mask /* relu = 3 */,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
 /* eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (fed to wsdl_conv2d_fwd). */
 int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,

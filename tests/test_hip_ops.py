@@ -365,7 +365,11 @@ def test_conv_bad_geometry_raises(dev):
                                             ((8, 40, 1, 1), False, False), ((2, 16, 12, 20), False, True),
                                             # channel-resident fused kernels (C >= 192, B*HW <= 32768, HW % 4 == 0)
                                             ((4, 256, 8, 8), True, True), ((2, 192, 16, 16), False, False),
-                                            ((3, 200, 12, 4), True, False), ((24, 192, 32, 32), True, True)])
+                                            ((3, 200, 12, 4), True, False), ((24, 192, 32, 32), True, True),
+                                            # the ReLU mask as bits: two-pass form with odd run lengths, the three resident forms
+                                            ((3, 40, 8, 8), True, True), ((7, 16, 16, 24), True, True),
+                                            ((5, 256, 4, 6), True, True), ((16, 320, 32, 32), True, True),
+                                            ((16, 1024, 16, 16), True, True)])
 def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     from weaklysuperviseddl_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -397,6 +401,22 @@ def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     assert_close(dbeta, br.grad, what="bn dbeta")
     if res:
         assert_close(dres, rr.grad, what="bn dres")
+    if relu and res:
+        # the mask as bits from the forward kernel (what the fused conv -> BN -> +residual node keeps instead of y)
+        rm2, rv2 = rm.to(dev), rv.to(dev)
+        y2, mean2, invstd2, bits = ops.bn_train_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rm2, rv2, 0.1, 1e-5, r.to(dev), True,
+                                                    want_mask=True)
+        assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(invstd2, invstd)
+        if (H * W) % 8 == 0:
+            want = np.packbits((y.cpu().numpy() > 0).reshape(-1), bitorder="little")
+            assert bits is not None and bits.dtype == torch.uint8 and np.array_equal(bits.cpu().numpy(), want)
+            dx3, dg3, db3, dres3 = ops.bn_train_bwd(x.to(dev), dy.to(dev), None, gamma.to(dev), mean, invstd, True, True,
+                                                    relu_mask=bits)
+            assert torch.equal(dx3, dx) and torch.equal(dg3, dgamma) and torch.equal(db3, dbeta) and torch.equal(dres3, dres)
+            with pytest.raises(ops.WsdlError):
+                ops.bn_train_bwd(x.to(dev), dy.to(dev), None, gamma.to(dev), mean, invstd, True, True, relu_mask=bits[:-1])
+        else:
+            assert bits is None
     if relu and not res:
         # the mask recomputed from x (what the fused conv -> BN node uses: y is neither kept nor read) is THE SAME mask
         dx2, dg2, db2, _ = ops.bn_train_bwd(x.to(dev), dy.to(dev), None, gamma.to(dev), mean, invstd, True, False,

@@ -49,11 +49,12 @@ for C, HW, res, cnt in [(64, 4096, False, 7), (128, 1024, False, 8), (256, 1024,
     g, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     dy = torch.randn(B, C, H, H, device=dev)
-    y, mean, invstd = ops.bn_train_fwd(x, g, b, rm, rv, 0.1, 1e-5, r, True)
-    tf = timeit(lambda: ops.bn_train_fwd(x, g, b, rm, rv, 0.1, 1e-5, r, True))
-    tb = timeit(lambda: ops.bn_train_bwd(x, dy, y if res else None, g, mean, invstd, True, res, beta=None if res else b))
+    y, mean, invstd, bits = ops.bn_train_fwd(x, g, b, rm, rv, 0.1, 1e-5, r, True, want_mask=True, mask_if=res)   # WSDL_BN_RELU_BITS=0: bits is None
+    tf = timeit(lambda: ops.bn_train_fwd(x, g, b, rm, rv, 0.1, 1e-5, r, True, want_mask=True, mask_if=res))
+    tb = timeit(lambda: ops.bn_train_bwd(x, dy, y if (res and bits is None) else None, g, mean, invstd, True, res,
+                                         beta=None if res else b, relu_mask=bits))
     nb = x.numel() * 4
-    bf, bb = nb * (3 if res else 2), nb * (5 if res else 3)
+    bf, bb = nb * (3 if res else 2), nb * ((5 if bits is None else 4) if res else 3)     # algorithmic streams of 4 B / element
     tot += cnt * (tf + tb)
     print(f"{C:5d} x {HW:5d} (x{cnt:2d}) {'res' if res else '   '}     {tf:8.1f} {bf / tf / 1e6:6.2f} {tb:8.1f} {bb / tb / 1e6:6.2f}")
 print(f"sum over the step's launches: {tot / 1e3:.3f} ms")

@@ -31,12 +31,33 @@ static int stat_splits(int C, int HW) {
     return s;
 }
 
+// ReLU mask as bits (relu = 3 in the backward): bit e % 8 of byte e / 8 for the dense element index e of y - written by the
+// forward kernels when asked to (a residual was added, so the mask cannot be recomputed from x): the backward reads
+// 1/32 of the bytes it would read from y.  A float4 at element e (a multiple of 4) owns one nibble.
+__device__ __forceinline__ unsigned mask_nibble(const uint8_t* __restrict__ m, long long e) {
+    return ((unsigned)m[e >> 3] >> (unsigned)(e & 4)) & 0xFu;
+}
+__device__ __forceinline__ void apply_nibble(float4& g, unsigned nb) {
+    if (!(nb & 1u)) g.x = 0.f;
+    if (!(nb & 2u)) g.y = 0.f;
+    if (!(nb & 4u)) g.z = 0.f;
+    if (!(nb & 8u)) g.w = 0.f;
+}
+// forward side: lanes 2j and 2j+1 hold the float4s at elements e and e + 4 (e a multiple of 8): the even lane stores the byte.
+// Both lanes of a pair must be active (the callers' index ranges start and end on even float4 indices).
+__device__ __forceinline__ void store_mask_pair(uint8_t* __restrict__ m, long long e, const float4& o) {
+    const unsigned nb = (o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u);
+    const unsigned hi = (unsigned)__shfl_down((int)nb, 1, 64);
+    if (!(threadIdx.x & 1)) m[e >> 3] = (uint8_t)(nb | (hi << 4));
+}
+
 // ws layout for BN: double part[C][kStatSplit][2]
 __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                 const float* __restrict__ y, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, double* __restrict__ part, int B, int C,
                                 int HW, long long dy_bs, long long y_bs, int relu, int backward, int nsplit,
-                                const float* __restrict__ gamma, const float* __restrict__ beta) {
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const uint8_t* __restrict__ rmask) {
     // forward : part = (sum x, sum x^2) ; backward: part = (sum dy', sum dy'*xhat), dy' = dy*[y>0]
     // relu == 2: the mask [y > 0] is recomputed from x (y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
     // expression - no residual was added): y is not read
@@ -73,6 +94,8 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
                     if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) g.y = 0.f;
                     if (!(fmaf(xv.z - mu, mg, mb) > 0.f)) g.z = 0.f;
                     if (!(fmaf(xv.w - mu, mg, mb) > 0.f)) g.w = 0.f;
+                } else if (relu == 3) {
+                    apply_nibble(g, mask_nibble(rmask, ((long long)b * C + c) * HW + r));
                 } else if (relu) {
                     const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
                     if (!(yv.x > 0.f)) g.x = 0.f;
@@ -96,6 +119,9 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
             float g = dy[(long long)b * dy_bs + (long long)c * HW + r];
             if (relu == 2) {
                 if (!(fmaf(xv - mu, mg, mb) > 0.f)) g = 0.f;
+            } else if (relu == 3) {
+                const long long e = ((long long)b * C + c) * HW + r;
+                if (!((rmask[e >> 3] >> (e & 7)) & 1)) g = 0.f;
             } else if (relu && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
             a0 += g;
             a1 += (double)g * ((xv - mu) * is);
@@ -120,7 +146,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
                                 float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                 long long n, int nsplit, const float* __restrict__ res,
                                 float* __restrict__ y, int C, int HW, long long y_bs, int relu, int B,
-                                float* __restrict__ amax) {
+                                float* __restrict__ amax, uint8_t* __restrict__ rmask) {
     float vmax = 0.f;
     const int c = blockIdx.y;
     double s0 = 0.0, s1 = 0.0;
@@ -144,8 +170,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     const float g = istd * gamma[c], be = beta[c];
     if ((HW & 3) == 0 && (y_bs & 3) == 0) {
         const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
-        const int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
-        const int lo = blockIdx.x * per, hi = min(lo + per, n4);
+        int per = (n4 + (int)gridDim.x - 1) / (int)gridDim.x;
+        if (rmask) per = (per + 1) & ~1;            // mask bytes are written by lane pairs: runs start on even float4s
+        const int lo = min(blockIdx.x * per, n4), hi = min(lo + per, n4);
         for (int i4 = lo + threadIdx.x; i4 < hi; i4 += blockDim.x) {
             const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long src = ((long long)b * C + c) * HW + r;
@@ -159,6 +186,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
             if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = v;
             vmax = amax4(vmax, v);
+            if (rmask) store_mask_pair(rmask, src, v);
         }
     } else {
         const int nn = B * HW;
@@ -185,7 +213,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ dbeta, int accumulate, long long n, int nsplit,
                                     float* __restrict__ dx,
                                     float* __restrict__ dres, int C, int HW, long long dy_bs, long long y_bs,
-                                    int relu, int B, float* __restrict__ amax, const float* __restrict__ beta) {
+                                    int relu, int B, float* __restrict__ amax, const float* __restrict__ beta,
+                                    const uint8_t* __restrict__ rmask) {
     // grid = (W, C), as bn_apply_kernel: one prologue per run of a few thousand values of channel c
     float vmax = 0.f;
     const int c = blockIdx.y;
@@ -218,6 +247,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                 if (!(yv.y > 0.f)) g.y = 0.f;
                 if (!(yv.z > 0.f)) g.z = 0.f;
                 if (!(yv.w > 0.f)) g.w = 0.f;
+            } else if (relu == 3) {
+                apply_nibble(g, mask_nibble(rmask, src));
             } else if (relu == 2) {
                 if (!(fmaf(xv.x - mu, mg, mb) > 0.f)) g.x = 0.f;
                 if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) g.y = 0.f;
@@ -243,6 +274,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
             float g = dy[(long long)b * dy_bs + (long long)c * HW + r];
             if (relu == 1 && !(y[(long long)b * y_bs + (long long)c * HW + r] > 0.f)) g = 0.f;
             if (relu == 2 && !(fmaf(x[src] - mu, mg, mb) > 0.f)) g = 0.f;
+            if (relu == 3 && !((rmask[src >> 3] >> (src & 7)) & 1)) g = 0.f;
             const float xh = (x[src] - mu) * is;
             const float o = gi * (g - k0 - xh * k1);
             dx[src] = o;
@@ -264,7 +296,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
-    long long y_bs, int relu, float* __restrict__ amax) {
+    long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask) {
     // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
     // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
     __shared__ double sm[16];
@@ -320,6 +352,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = o;
             vmax = amax4(vmax, o);
+            if (rmask) store_mask_pair(rmask, ((long long)b * C + c) * HW + r, o);
         }
     }
     if (amax) publish_amax(vmax, amax);
@@ -331,7 +364,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
-    float* __restrict__ amax, const float* __restrict__ beta) {
+    float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask) {
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -354,6 +387,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
                 if (!(fmaf(xv.y - mu, mg, mb) > 0.f)) gv.y = 0.f;
                 if (!(fmaf(xv.z - mu, mg, mb) > 0.f)) gv.z = 0.f;
                 if (!(fmaf(xv.w - mu, mg, mb) > 0.f)) gv.w = 0.f;
+            } else if (relu == 3) {
+                apply_nibble(gv, mask_nibble(rmask, ((long long)b * C + c) * HW + r));
             } else if (relu) {
                 const float4 yv = *reinterpret_cast<const float4*>(y + (long long)b * y_bs + (long long)c * HW + r);
                 if (!(yv.x > 0.f)) gv.x = 0.f;
@@ -681,8 +716,9 @@ size_t wsdl_bn_workspace(int C) {
 int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                       float* save_invstd, float* running_mean, float* running_var, float momentum,
                       float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
-                      float* y_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                      float* y_amax, uint8_t* relu_mask, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
+    WSDL_REQUIRE(!relu_mask || (relu && (HW & 7) == 0), "bn_train_fwd: the bit mask needs relu and HW %% 8 == 0");
     WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_fwd: bad shape");
     WSDL_REQUIRE((long long)B * HW > 1, "bn_train_fwd: needs more than one value per channel (as torch)");
     if (ws_bytes < wsdl_bn_workspace(C)) {
@@ -690,30 +726,31 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
         return WSDL_EWORKSPACE;
     }
     if (!y_bs) y_bs = (long long)C * HW;
+    WSDL_REQUIRE(!relu_mask || (y_bs & 3) == 0, "bn_train_fwd: the bit mask needs a 16-byte aligned batch stride");
     hipStream_t s = wsdl::as_stream(stream);
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
         if (nt == 1024)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax);
+                               y_amax, relu_mask);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax);
+                               y_amax, relu_mask);
         else
             hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax);
+                               y_amax, relu_mask);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, nullptr, nullptr, nullptr,
-                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns, nullptr, nullptr);
+                       nullptr, part, B, C, HW, 0ll, 0ll, 0, 0, ns, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(bn_apply_kernel, channel_grid(B, C, HW), dim3(256), 0, s, x, gamma, beta, part, save_mean,
                        save_invstd, running_mean, running_var, momentum, eps, (long long)B * HW, ns, residual, y, C,
-                       HW, y_bs, relu, B, y_amax);
+                       HW, y_bs, relu, B, y_amax, (y_bs & 3) == 0 ? relu_mask : nullptr);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -721,12 +758,14 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
 int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* beta,
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, float* dres, int B, int C, int HW, int relu,
-                      int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax, void* ws,
-                      size_t ws_bytes, wsdl_stream_t stream) {
+                      int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax,
+                      const uint8_t* relu_mask, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
     WSDL_REQUIRE(relu != 1 || y, "bn_train_bwd: relu = 1 takes the mask from the forward output y");
     WSDL_REQUIRE(relu != 2 || beta, "bn_train_bwd: relu = 2 recomputes the mask from x and needs beta");
-    WSDL_REQUIRE(relu >= 0 && relu <= 2, "bn_train_bwd: relu must be 0, 1 or 2");
+    WSDL_REQUIRE(relu != 3 || (relu_mask && (HW & 7) == 0 && (dy_bs & 3) == 0),
+                 "bn_train_bwd: relu = 3 takes the mask bits written by wsdl_bn_train_fwd (HW %% 8 == 0)");
+    WSDL_REQUIRE(relu >= 0 && relu <= 3, "bn_train_bwd: relu must be 0, 1, 2 or 3");
     WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_bwd: bad shape");
     if (ws_bytes < wsdl_bn_workspace(C)) {
         wsdl::set_error("bn_train_bwd: workspace too small");
@@ -739,25 +778,25 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
         if (nt == 1024)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta);
+                               dx_amax, beta, relu_mask);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta);
+                               dx_amax, beta, relu_mask);
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta);
+                               dx_amax, beta, relu_mask);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
     double* part = static_cast<double*>(ws);
     const int ns = stat_splits(C, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, ns), dim3(256), 0, s, x, dy, y, save_mean, save_invstd,
-                       part, B, C, HW, dy_bs, y_bs, relu, 1, ns, gamma, beta);
+                       part, B, C, HW, dy_bs, y_bs, relu, 1, ns, gamma, beta, relu_mask);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, channel_grid(B, C, HW), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                        save_invstd, part, dgamma, dbeta, accumulate_param_grads, (long long)B * HW, ns, dx, dres, C, HW,
-                       dy_bs, y_bs, relu, B, dx_amax, beta);
+                       dy_bs, y_bs, relu, B, dx_amax, beta, relu_mask);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

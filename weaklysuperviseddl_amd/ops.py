@@ -429,7 +429,15 @@ def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps):
     return scale, shift
 
 
-def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, out=None):
+# The ReLU mask of a residual layer as bits written by the forward kernel (1/32 of the bytes of y, which the backward would
+# otherwise read for it): WSDL_BN_RELU_BITS=0 reads y instead (A/B; same result bit for bit).
+BN_RELU_BITS = [os.environ.get("WSDL_BN_RELU_BITS", "1") != "0"]
+
+
+def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, out=None,
+                 want_mask=False, mask_if=True):
+    """``want_mask``: returns a fourth value - the ReLU mask as bits (uint8, numel/8 bytes; ``bn_train_bwd(relu_mask=)``),
+    or None where the kernels do not write one (no ReLU, H*W not a multiple of 8, ``mask_if`` false)."""
     x = _dense(x, "x")
     B, Cc, H, W = x.shape
     if out is None:
@@ -443,27 +451,35 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     if residual is not None:
         residual = _dense(residual, "residual")
     y_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
+    mask = None
+    if want_mask and mask_if and relu and BN_RELU_BITS[0] and (H * W) % 8 == 0 and y_bs % 4 == 0:
+        mask = torch.empty(x.numel() // 8, device=x.device, dtype=torch.uint8)
     check(lib().wsdl_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(invstd), _p(running_mean),
                                   _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
-                                  int(relu), y_bs, _p(y_amax), _p(ws), ws.numel(), _stream()))
+                                  int(relu), y_bs, _p(y_amax), _p(mask), _p(ws), ws.numel(), _stream()))
     if y_amax is not None:
         _publish_amax(out, y_amax)
-    return out, mean, invstd
+    return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
 
 
 def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None, accumulate=False,
-                 beta=None):
-    """``relu``: True with ``y`` = the forward output (mask read from it), or True with ``y=None`` and ``beta`` given:
-    the mask is recomputed from x (no residual was added in the forward) and y is never touched."""
+                 beta=None, relu_mask=None):
+    """``relu``: True with ``y`` = the forward output (mask read from it), or True with ``relu_mask`` = the bits the
+    forward wrote (``bn_train_fwd(want_mask=True)``), or True with ``y=None`` and ``beta`` given: the mask is recomputed
+    from x (no residual was added in the forward) and y is never touched."""
     x = _dense(x, "x")
     dy, dy_bs = _planes(dy, "dy")
     B, Cc, H, W = x.shape
     y_bs = 0
     mode = 0
     if relu:
-        if y is None:
+        if relu_mask is not None:
+            if relu_mask.dtype != torch.uint8 or relu_mask.numel() * 8 != x.numel() or not relu_mask.is_cuda:
+                raise WsdlError("bn_train_bwd: relu_mask must be the uint8 bit mask of the forward (numel / 8 bytes)")
+            mode = 3
+        elif y is None:
             if beta is None:
-                raise WsdlError("bn_train_bwd: relu needs the forward output or beta")
+                raise WsdlError("bn_train_bwd: relu needs the forward output, its bit mask or beta")
             mode = 2
         else:
             mode = 1
@@ -478,7 +494,7 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if mode == 1 else None), _p(gamma),
                                   _p(_dense(beta) if mode == 2 else None), _p(mean), _p(invstd), _p(dx),
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, mode, int(acc), dy_bs, y_bs,
-                                  _p(dx_amax), _p(ws), ws.numel(), _stream()))
+                                  _p(dx_amax), _p(relu_mask if mode == 3 else None), _p(ws), ws.numel(), _stream()))
     if dx_amax is not None:
         _publish_amax(dx, dx_amax)
     dx._wsdl_fresh = True
@@ -577,14 +593,15 @@ class _ConvBNAct(torch.autograd.Function):
         wf, wd = _cached_prep(cache, weight, x.requires_grad)
         x_amax = amax_of(x, _split_kc(x.shape[1], weight.shape[2] * weight.shape[3]) or _wgrad_split(weight.shape))
         conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, x_amax=x_amax)
-        y, mean, invstd = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
-                                       residual, relu)
+        y, mean, invstd, rbits = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
+                                              residual, relu, want_mask=True, mask_if=bool(relu) and residual is not None)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
         ctx.x_amax = x_amax              # saved tensors come back as new Python objects: keep the scalar explicitly
-        # the ReLU mask is recomputed from the conv output in the backward unless a residual was added (then y is kept)
-        ctx.save_for_backward(x, conv, y if (relu and residual is not None) else None, gamma, mean, invstd, wd,
-                              beta if relu else None)
+        # the ReLU mask is recomputed from the conv output in the backward unless a residual was added: then the forward
+        # kernel wrote it as bits (or, where it cannot - H*W not a multiple of 8 - y is kept and read)
+        ctx.save_for_backward(x, conv, y if (relu and residual is not None and rbits is None) else None, gamma, mean, invstd,
+                              wd, beta if relu else None, rbits)
         if passthrough:
             xv = x.view_as(x)
             if x_amax is not None:
@@ -594,7 +611,7 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dxres=None):
-        x, conv, y, gamma, mean, invstd, wd, beta_s = ctx.saved_tensors
+        x, conv, y, gamma, mean, invstd, wd, beta_s, rbits = ctx.saved_tensors
         stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
         pw, pg, pb = ctx.params
         need_res = has_res and ctx.needs_input_grad[4]
@@ -602,12 +619,13 @@ class _ConvBNAct(torch.autograd.Function):
         if sg is not None:
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
             dconv, _, _, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res,
-                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_s)
+                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_s, relu_mask=rbits)
             dgamma = dbeta = None
             sg.grad_ready(pg)
             sg.grad_ready(pb)
         else:
-            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s)
+            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s,
+                                                      relu_mask=rbits)
         def input_grad():
             dx = None
             if ctx.needs_input_grad[0]:
