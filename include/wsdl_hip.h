@@ -64,7 +64,7 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
- *                      192 channels, n > 1 = from n channels; measured: resident wins at every channel count)
+ *                      64 channels, n > 1 = from n channels; measured: resident wins at every channel count of the networks)
  *   bn_wide_c    512*  resident BatchNorm kernels as 1024 threads x 4 float4 (instead of 256 x 16) up to this channel count
  *                      (half of it for the backward): 16 waves per CU loading at once where one workgroup per channel would
  *                      leave a CU with 4 - forward -20..23 %, backward -7 % at 256 channels (profiles/r03_bn_kernels.txt)
@@ -163,10 +163,13 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y,
 size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw,
                                    int stride, int pad, int dil, int dgrad);
 
-/* dx = conv_transpose(dy, w)  (+ dx if accumulate).  dy is (B,Cout,OH,OW) with batch stride dy_bs. */
+/* dx = conv_transpose(dy, w)  (+ dx if accumulate).  dy is (B,Cout,OH,OW) with batch stride dy_bs.
+ * acc_mask (optional, with accumulate): bit e % 8 of byte e / 8 says whether element e of the value already in dx counts -
+ * dx then holds a bottleneck block's output gradient and the mask is the block's final ReLU as written by
+ * wsdl_bn_train_fwd(relu_mask): dx = dgrad + [y > 0] * dx, the identity branch's gradient without a tensor of its own. */
 int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
-                      int stride, int pad, int dil, int accumulate,
+                      int stride, int pad, int dil, int accumulate, const uint8_t* acc_mask,
                       long long dy_bs, const float* dy_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
 /* dw[Cout][Cin][kh][kw] = sum_{b,oh,ow} dy * x_shifted  (+ dw if accumulate).  Split over pixel

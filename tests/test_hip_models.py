@@ -584,6 +584,36 @@ def test_bottleneck_vs_the_references_vendored_block(dev, golden):
             assert rel_err(blk.eval()(x.detach()), T(g[f"b{i}/y_eval"])) < 1e-3, i
 
 
+def test_identity_link_is_taken_and_changes_nothing(dev, monkeypatch):
+    """A chain of identity bottlenecks (train mode): from the second block on, the gradient of a block's output is a buffer
+    the library owns, so the last node hands (dy, ReLU bits) to the first through ``ops.IdentityLink`` and no ``dres`` tensor
+    is written.  Same gradients bit for bit as the ``dres`` path (WSDL_IDENTITY_LINK=0), and the link path really ran."""
+    from weaklysuperviseddl_amd import nn as wnn, ops
+
+    def run(link_on):
+        monkeypatch.setattr(ops, "IDENTITY_LINK", [link_on])
+        torch.manual_seed(0)
+        blocks = torch.nn.Sequential(*[wnn.Bottleneck(256, 64) for _ in range(3)]).to(dev).train()
+        x = torch.randn(4, 256, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_()
+        calls = []
+        real = ops.conv2d_dgrad
+
+        def counting(*a, **k):
+            calls.append(k.get("acc_mask") is not None)
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "conv2d_dgrad", counting)
+        y = blocks(x)
+        head = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+        (y * head).sum().backward()
+        monkeypatch.setattr(ops, "conv2d_dgrad", real)
+        return y.detach(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()], sum(calls)
+
+    y1, dx1, g1, n1 = run(True)
+    y0, dx0, g0, n0 = run(False)
+    assert n0 == 0 and n1 == 2, (n0, n1)         # blocks 1 and 2 (the last block's dy comes from torch's mul: not owned)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
 def test_cfg1_layercam_on_the_stated_batch_of_8(dev, cam_models):
     """BASELINE configs[0]: ClassificationModel + LayerCAM on 8 synthetic 224 x 224 RGB images - the full stated batch
     (B changes the tile / split-K choices of the small-grid kernels), class_idx = i mod 37, against the

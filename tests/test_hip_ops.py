@@ -94,6 +94,16 @@ def test_conv_fwd_dgrad_wgrad(dev, case, arithmetic):
     # accumulate forms
     dx2 = ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d, accumulate_into=dx.clone())
     assert_close(dx2, 2 * xr.grad, what="dgrad accumulate")
+    if x.numel() % 8 == 0:
+        # masked accumulate (the identity branch of a bottleneck): dx = dgrad + [bit] * previous, exactly
+        prev = torch.randn(x.shape, generator=g)
+        keep = torch.rand(x.shape, generator=g) < 0.5
+        bits = T(np.packbits(keep.numpy().reshape(-1), bitorder="little")).to(dev)
+        dx3 = ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d, accumulate_into=prev.to(dev), acc_mask=bits)
+        dx4 = ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d, accumulate_into=(prev * keep).to(dev))
+        assert torch.equal(dx3, dx4), "masked accumulate"
+        with pytest.raises(ops.WsdlError):
+            ops.conv2d_dgrad(dyd, wdg, w.shape, x.shape, s, p, d, acc_mask=bits)
     dw2 = ops.conv2d_wgrad(xd, dyd, w.shape, s, p, d, out=dw.clone(), accumulate=True)
     assert_close(dw2, 2 * wr.grad, what="wgrad accumulate")
 
@@ -369,7 +379,10 @@ def test_conv_bad_geometry_raises(dev):
                                             # the ReLU mask as bits: two-pass form with odd run lengths, the three resident forms
                                             ((3, 40, 8, 8), True, True), ((7, 16, 16, 24), True, True),
                                             ((5, 256, 4, 6), True, True), ((16, 320, 32, 32), True, True),
-                                            ((16, 1024, 16, 16), True, True)])
+                                            ((16, 1024, 16, 16), True, True),
+                                            # 64 / 128 channels in the resident forms (forward 1024 x 16 float4 at 16 x 64 x 64)
+                                            ((16, 64, 64, 64), True, False), ((16, 128, 32, 32), True, True),
+                                            ((16, 256, 64, 64), True, True)])
 def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     from weaklysuperviseddl_amd import ops
     g = torch.Generator().manual_seed(11)
@@ -384,23 +397,31 @@ def test_batchnorm_train_fwd_bwd(dev, shape, relu, res):
     yr = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
     if res:
         yr = yr + rr
-    if relu:
-        yr = F.relu(yr)
+    pre = yr
     dy = torch.randn(shape, generator=g)
-    yr.backward(dy)
-
     rm_d, rv_d = rm.to(dev), rv.to(dev)
     y, mean, invstd = ops.bn_train_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rm_d, rv_d, 0.1, 1e-5,
                                        r.to(dev) if res else None, relu)
+    if relu:
+        # An element whose pre-activation is within rounding of zero may take the other side of the ReLU in another fp32
+        # implementation (a handful among the 16.8 million of the largest case) - and one such element moves its channel's
+        # dgamma by more than 1e-3.  The reference backward therefore runs through OUR mask, after checking that the two
+        # masks differ only there.
+        ours, theirs = (y.cpu() > 0), (pre.detach() > 0)
+        differ = ours != theirs
+        assert (pre.detach().abs()[differ] <= 1e-5).all() and differ.float().mean().item() < 1e-5, int(differ.sum())
+        yr = pre * ours
+    safe = torch.ones_like(pre.detach(), dtype=torch.bool)
+    yr.backward(dy)
     assert_close(y, yr, what="bn fwd")
     assert_close(rm_d, rm_ref, what="running mean")
     assert_close(rv_d, rv_ref, what="running var")
     dx, dgamma, dbeta, dres = ops.bn_train_bwd(x.to(dev), dy.to(dev), y, gamma.to(dev), mean, invstd, relu, res)
-    assert_close(dx, xr.grad, what="bn dx")
+    assert_close(dx.cpu() * safe, xr.grad * safe, what="bn dx")
     assert_close(dgamma, gr.grad, what="bn dgamma")
     assert_close(dbeta, br.grad, what="bn dbeta")
     if res:
-        assert_close(dres, rr.grad, what="bn dres")
+        assert_close(dres.cpu() * safe, rr.grad * safe, what="bn dres")
     if relu and res:
         # the mask as bits from the forward kernel (what the fused conv -> BN -> +residual node keeps instead of y)
         rm2, rv2 = rm.to(dev), rv.to(dev)

@@ -52,7 +52,22 @@ struct ConvP {
     int xcd_py;         // split kernels: > 0 = XCD-aware tile order with this many row groups (1, 2, 4 or 8); 0 = launch order
     const float* x_amax;   // split kernels, fp16x2 arithmetic: device scalar >= max|x| (the scale of the activation operand)
     float* y_amax;         // optional: receives max|y| of what the epilogue stores (atomicMax into a zeroed device scalar)
+    // accumulate with a bit mask (dgrad of a bottleneck's first convolution): the value already in y counts only where bit
+    // e % 8 of acc_mask[e / 8] is set, e = the element's index from acc_base (= y of the whole batch) - y holds the block
+    // output's gradient and the mask is the block's final ReLU, so the masked gradient of the identity branch is never
+    // written out by the BatchNorm backward
+    const uint8_t* acc_mask;
+    const float* acc_base;
 };
+
+__device__ __forceinline__ float acc_prev(const ConvP& p, const float* ptr) {
+    float o = *ptr;
+    if (p.acc_mask) {
+        const long long e = ptr - p.acc_base;
+        if (!((p.acc_mask[e >> 3] >> (e & 7)) & 1)) o = 0.f;
+    }
+    return o;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Pipeline: LDS double buffer, ONE barrier per K-chunk.  Iteration q: registers (holding chunk q+1, whose
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(ConvP p) {
                 if (p.shift) v += p.shift[co];
                 const long long off = (long long)co * OHOW;
                 if (rbp) v += rbp[off];
-                if (p.accumulate) v += yb[off];
+                if (p.accumulate) v += acc_prev(p, yb + off);
                 if (p.relu) v = fmaxf(v, 0.f);
                 yb[off] = v;
             }
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(kThreads, 4) void conv_igemm_fast_kernel(ConvP p) {
                 if (p.shift) v += p.shift[co];
                 const long long off = (long long)co * OHOW;
                 if (rbp) v += rbp[off];
-                if (p.accumulate) v += yb[off];
+                if (p.accumulate) v += acc_prev(p, yb + off);
                 if (p.relu) v = fmaxf(v, 0.f);
                 yb[off] = v;
             }
@@ -548,7 +563,7 @@ __global__ void conv_splitk_reduce_kernel(ConvP p) {
         const long long off = (long long)co * OHOW + orp;
         if (p.res) v += p.res[(long long)ob * p.res_bs + off];
         float* y = p.y + (long long)ob * p.y_bs + off;
-        if (p.accumulate) v += *y;
+        if (p.accumulate) v += acc_prev(p, y);
         if (p.relu) v = fmaxf(v, 0.f);
         *y = v;
         vmax = fmaxf(vmax, fabsf(v));
@@ -580,7 +595,18 @@ __global__ void conv_splitk_reduce_vec4_kernel(ConvP p) {
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         float4* y = reinterpret_cast<float4*>(p.y + (long long)ob * p.y_bs + off);
-        if (p.accumulate) { const float4 o = *y; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (p.accumulate) {
+            float4 o = *y;
+            if (p.acc_mask) {
+                const long long e = reinterpret_cast<const float*>(y) - p.acc_base;      // a multiple of 4
+                const unsigned nb = ((unsigned)p.acc_mask[e >> 3] >> (unsigned)(e & 4)) & 0xFu;
+                if (!(nb & 1u)) o.x = 0.f;
+                if (!(nb & 2u)) o.y = 0.f;
+                if (!(nb & 4u)) o.z = 0.f;
+                if (!(nb & 8u)) o.w = 0.f;
+            }
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *y = v;
         vmax = amax4(vmax, v);
@@ -1712,9 +1738,10 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin
 }
 
 int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, int Cin, int H, int W,
-                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate, const uint8_t* acc_mask,
                       long long dy_bs, const float* dy_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
     WSDL_REQUIRE(dy && wt_dgrad && dx, "conv2d_dgrad: null pointer");
+    WSDL_REQUIRE(!acc_mask || accumulate, "conv2d_dgrad: acc_mask masks the accumulated value (accumulate = 1)");
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
     ConvP p{};
@@ -1728,6 +1755,7 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
     p.res_bs = p.y_bs;
     WSDL_REQUIRE(p.x_bs >= (long long)Cout * OH * OW, "conv2d_dgrad: batch stride smaller than an image");
     p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
+    p.acc_mask = acc_mask; p.acc_base = dx;
     p.x_amax = dy_amax; p.y_amax = nullptr;
     return launch_igemm_sliced(p, H * W, (long long)Cout * OH * OW, wsdl::as_stream(stream),
                                2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);

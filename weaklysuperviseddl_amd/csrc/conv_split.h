@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 if (p.shift) v += p.shift[co];
                 const long long off = (long long)co * OHOW;
                 if (rbp) v += rbp[off];
-                if (p.accumulate) v += yb[off];
+                if (p.accumulate) v += acc_prev(p, yb + off);
                 if (p.relu) v = fmaxf(v, 0.f);
                 yb[off] = v;
                 vmax = fmaxf(vmax, fabsf(v));

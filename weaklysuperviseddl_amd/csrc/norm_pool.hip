@@ -435,8 +435,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
 static int resident_threads(int C, long long n, int HW, bool backward = false) {
-    // g_bn_resident: 0 off, 1 = from 192 channels (fewer workgroups than that leave most CUs idle), n > 1 = from n channels
-    const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 192;
+    // g_bn_resident: 0 off, 1 = from 64 channels, n > 1 = from n channels.  (Round 2 started at 192: fewer workgroups leave
+    // most CUs idle - but the two-pass form's second read costs more: 128 x 1024 forward 13.9 -> 9.9 us, backward 15.3 -> 10.2;
+    // 64 x 4096 forward 22.0 -> 16.8 in the 1024 x 16 form; profiles/r03_notes.md)
+    const int min_c = wsdl::g_bn_resident > 1 ? wsdl::g_bn_resident : 64;
     if (!wsdl::g_bn_resident || C < min_c || (HW & 3) != 0) return 0;
     // 256 / 512 channels = one or two workgroups per CU.  Sixteen waves of a quarter of the work each instead of four:
     // forward 14.5 -> 11.6 us (256 channels) and 21.5 -> 16.6 us (512) on the 16 x 32 x 32 maps; backward 16.2 -> 15.0 us at 256
@@ -445,6 +447,7 @@ static int resident_threads(int C, long long n, int HW, bool backward = false) {
     if (n <= 1024 * 16 && C <= (backward ? wsdl::g_bn_wide_c / 2 : wsdl::g_bn_wide_c)) return 1024;
     if (n <= 256 * 64) return 256;
     if (n <= 512 * 64) return 512;
+    if (!backward && n <= 1024 * 64) return 1025;      // forward only: 1024 threads x 16 float4 (the 64 x 64 maps at B = 16)
     return 0;
 }
 
@@ -729,7 +732,11 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     WSDL_REQUIRE(!relu_mask || (y_bs & 3) == 0, "bn_train_fwd: the bit mask needs a 16-byte aligned batch stride");
     hipStream_t s = wsdl::as_stream(stream);
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
-        if (nt == 1024)
+        if (nt == 1025)
+            hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 16>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
+                               save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
+                               y_amax, relu_mask);
+        else if (nt == 1024)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
                                y_amax, relu_mask);

@@ -118,7 +118,7 @@ class Linear(nn.Module):
         return ops.linear(x, self.weight, self.bias)
 
 
-def conv_bn(x, conv, bn, relu, residual=None, passthrough=False):
+def conv_bn(x, conv, bn, relu, residual=None, passthrough=False, link=None):
     """conv -> bn (batch stats when bn.training, folded running stats otherwise) -> +residual -> relu."""
     if conv.bias is not None:
         raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
@@ -127,7 +127,7 @@ def conv_bn(x, conv, bn, relu, residual=None, passthrough=False):
     cache = conv.__dict__.setdefault("_wsdl_cache", {})         # derived tensors, keyed on versions / epochs
     return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                            conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache,
-                           passthrough)
+                           passthrough, link)
 
 
 class FusedSequential(nn.Sequential):
@@ -165,11 +165,15 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # x feeds conv1 AND the identity / downsample branch: route the second use through conv1's node (see
         # ops.conv_bn_act) so that the two input gradients are summed in conv1's dgrad epilogue
-        y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True)
+        # identity blocks in train mode: the identity branch's gradient goes from the last node to the first through an
+        # ops.IdentityLink instead of through a tensor of its own
+        link = ops.IdentityLink() if (self.downsample is None and self.bn1.training and self.bn3.training
+                                      and torch.is_grad_enabled()) else None
+        y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True, link=link)
         if self.downsample is not None:
             idt = self.downsample(idt)
         y = conv_bn(y, self.conv2, self.bn2, True)
-        return conv_bn(y, self.conv3, self.bn3, True, residual=idt)   # relu(bn3(conv3) + identity)
+        return conv_bn(y, self.conv3, self.bn3, True, residual=idt, link=link)   # relu(bn3(conv3) + identity)
 
 
 def make_resnet50_stages(replace_stride_with_dilation):

@@ -366,7 +366,12 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
     return out
 
 
-def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into=None, dy_amax=None):
+def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into=None, dy_amax=None, acc_mask=None):
+    """``accumulate_into``: dx = dgrad + that tensor, in place.  ``acc_mask`` (bits from ``bn_train_fwd(want_mask=True)``, same
+    shape as dx): only the elements of ``accumulate_into`` whose bit is set count (the masked gradient of an identity branch)."""
+    if acc_mask is not None and (accumulate_into is None or acc_mask.dtype != torch.uint8
+                                 or acc_mask.numel() * 8 != accumulate_into.numel() or not accumulate_into.is_contiguous()):
+        raise WsdlError("conv2d_dgrad: acc_mask needs a dense accumulate_into tensor of 8 x its number of bytes")
     if dy_amax is None:
         dy_amax = amax_of(dy, _split_kc(wshape[0], wshape[2] * wshape[3]))
     dy, dy_bs = _planes(dy, "dy")
@@ -376,7 +381,7 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 1)
     ws = workspace(nws, dy.device) if nws else None
     check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
-                                  int(accumulate_into is not None), dy_bs, _p(dy_amax), _p(ws),
+                                  int(accumulate_into is not None), _p(acc_mask), dy_bs, _p(dy_amax), _p(ws),
                                   ws.numel() if ws is not None else 0, _stream()))
     dx._wsdl_fresh = True        # a buffer this library has just produced and nobody else holds (see _owned)
     return dx
@@ -582,12 +587,36 @@ def _sink_of(param):
     return sink
 
 
+class IdentityLink:
+    """Shared by the two ``conv_bn_act`` calls that open and close an identity bottleneck (train mode).  The gradient of the
+    block's input through the identity branch is [y > 0] * dy (dy: the gradient of the block's output, y its final ReLU).
+    Routed through autograd it is a tensor the last BatchNorm backward writes (``dres``) and the first convolution's dgrad
+    epilogue reads back.  With a link the last node leaves (dy, the ReLU's bits) here, returns no gradient for the residual
+    input, and the first node - whose backward always runs later: its output's gradient depends on the rest of the block -
+    adds [bits] * dy inside its dgrad epilogue, in dy's own buffer: one tensor write and one allocation less per block.
+    Only when dy is a buffer the library owns (``_owned``); otherwise the ``dres`` path runs as before.  WSDL_IDENTITY_LINK=0
+    switches it off (A/B; same result bit for bit)."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None
+
+
+IDENTITY_LINK = [os.environ.get("WSDL_IDENTITY_LINK", "1") != "0"]
+
+
 class _ConvBNAct(torch.autograd.Function):
     """Train-mode conv -> BatchNorm(batch statistics) -> (+residual) -> ReLU as one autograd node."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil, relu,
-                momentum, eps, cache=None, passthrough=False):
+                momentum, eps, cache=None, passthrough=False, link=None):
+        # link (IdentityLink, shared by the first and the last node of an identity bottleneck): the last node's backward
+        # does not write the masked gradient of the identity branch; it leaves (dy, mask bits) in the link and the first
+        # node's dgrad epilogue adds [mask] * dy into dy's buffer - see IdentityLink
+        ctx.link = link
+        if link is not None:
+            ctx.set_materialize_grads(False)
         # passthrough: also hand x back as a second output (the identity branch of a bottleneck).  The gradient that
         # arrives for it is then added inside the dgrad kernel's epilogue instead of by a separate autograd add.
         wf, wd = _cached_prep(cache, weight, x.requires_grad)
@@ -615,6 +644,13 @@ class _ConvBNAct(torch.autograd.Function):
         stride, pad, dil, relu, wshape, xshape, has_res = ctx.cfg
         pw, pg, pb = ctx.params
         need_res = has_res and ctx.needs_input_grad[4]
+        link = ctx.link
+        if dy is None:
+            raise WsdlError("conv -> BatchNorm node: no gradient arrived for its output")
+        if (link is not None and need_res and rbits is not None and IDENTITY_LINK[0] and _owned(dy)
+                and tuple(dy.shape) == tuple(conv.shape)):
+            link.pending = (dy, rbits)       # consumed by the block's first node (its backward runs after this one)
+            need_res = False
         sg = _sink_of(pg) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and _sink_of(pg) is _sink_of(pb)) else None
         if sg is not None:
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
@@ -626,17 +662,25 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s,
                                                       relu_mask=rbits)
+        pend = None
+        if link is not None and link.pending is not None and not has_res:
+            pend, link.pending = link.pending, None
+
         def input_grad():
             dx = None
             if ctx.needs_input_grad[0]:
                 if wd is None:
                     raise WsdlError("conv backward: dgrad weights were not prepared")
-                into = None
-                if _owned(dxres) and tuple(dxres.shape) == tuple(xshape):
+                into, bits = None, None
+                if pend is not None and tuple(pend[0].shape) == tuple(xshape):
+                    into, bits = pend       # the block output's gradient + the final ReLU's bits: dx = dgrad(...) + [bits] * it
+                elif _owned(dxres) and tuple(dxres.shape) == tuple(xshape):
                     into = dxres        # the identity branch's gradient (a fresh BN-backward output): dx = dgrad(...) + it
-                dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into)
+                dx = conv2d_dgrad(dconv, wd, wshape, xshape, stride, pad, dil, accumulate_into=into, acc_mask=bits)
                 if into is None and dxres is not None:
                     dx = dx + dxres
+                elif bits is not None and dxres is not None:
+                    dx = dx + dxres          # (does not happen: the link replaces the gradient of the passthrough output)
             elif dxres is not None:
                 dx = dxres
             return dx
@@ -656,7 +700,7 @@ class _ConvBNAct(torch.autograd.Function):
         if not WGRAD_AFTER_DGRAD[0]:
             dx = input_grad()
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                dres, None, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class _ConvAffineAct(torch.autograd.Function):
@@ -972,13 +1016,13 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ functional API
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
-                momentum=0.1, eps=1e-5, training=True, cache=None, passthrough=False):
+                momentum=0.1, eps=1e-5, training=True, cache=None, passthrough=False, link=None):
     """passthrough=True returns (y, x'): x' is x routed through this node, to be used as the identity branch so that
     its gradient is summed in the dgrad epilogue (train mode; eval mode returns x itself)."""
     if training:
         bump_stats_epoch()          # running statistics are about to be rewritten behind torch's back
         return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
-                                bool(relu), momentum, eps, cache, bool(passthrough))
+                                bool(relu), momentum, eps, cache, bool(passthrough), link)
     key = _cache_key(gamma, beta, running_mean, running_var) if cache is not None else None
     if cache is not None and cache.get("fold_key") == key:
         scale, shift = cache["fold"]
