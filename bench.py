@@ -327,7 +327,9 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
     from weaklysuperviseddl_amd import ops
     gen, imgs, cls = cam_setup(device)
     n_img = imgs.shape[0]
-    for _ in range(2):
+    # warm-up: eager pass, capture, and enough replays for the clocks to settle after the idle stretch of the set-up (with 2
+    # warm-up calls the first measurement of a process read anything from 0.34 to 0.53 ms/img)
+    for _ in range(12):
         gen.generate_batch(imgs, 1.0, cls, thresh=0.3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -336,6 +338,7 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / iters * 1e3
     out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
+           "launch": "hipGraph replay of the batch (LayerCAMGenerator.generate_batch, WSDL_CAM_SELF_GRAPH=0: eager)",
            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
     # stage 1 as generate_pseudo_masks runs it: three of the loader's batches of 8 in flight on three streams
     nb, lanes = int(os.environ.get("WSDL_CAM_NB", "6")), int(os.environ.get("WSDL_CAM_LANES", "3"))
@@ -351,7 +354,7 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
         ops.prof_reset()
         ops.prof_enable(True)
         for _ in range(iters):
-            gen.generate_batch(imgs, 1.0, cls, thresh=0.3)
+            gen._generate_batch_eager(imgs, 1.0, cls, 0.3)      # eager launches: a hipGraph replay records no per-launch events
         torch.cuda.synchronize()
         ops.prof_enable(False)
         kms, work, exe, exe_split = conv_class_totals(ops)
