@@ -39,7 +39,9 @@ CONV_CASES = [
     (1, 64, 12, 12, 32, 3, 1, 12, 12),     # ASPP-like: dilation >= feature size on some taps
     (2, 32, 18, 22, 64, 3, 2, 1, 1),       # stride 2 (layer2.0.conv2)
     (2, 48, 16, 16, 96, 1, 2, 0, 1),       # 1x1 stride 2 (downsample)
-    (2, 3, 40, 36, 64, 7, 2, 3, 1),        # stem 7x7 s2, Cin=3 (unaligned K)
+    (2, 3, 40, 36, 64, 7, 2, 3, 1),        # stem 7x7 s2, Cin=3 (unaligned K): the stem kernel, partial tiles
+    (3, 3, 33, 71, 64, 7, 2, 3, 1),        # ... odd sizes, three column tiles
+    (2, 3, 30, 30, 32, 7, 2, 3, 1),        # same geometry, 32 output channels: the generic fp32 kernel
     (3, 64, 9, 11, 2, 1, 1, 0, 1),         # classifier[4]: Cout=2
     (2, 256, 8, 8, 21, 1, 1, 0, 1),        # aux head: Cout=21
     (4, 128, 1, 1, 37, 1, 1, 0, 1),        # fc as 1x1 conv on a 1x1 map
@@ -882,3 +884,30 @@ def test_keep_largest_device_equals_the_reference_function(dev, golden):
         ops.keep_largest_batched(torch.zeros(2, 8, 8, device=dev))         # float masks are refused, not cast
     with pytest.raises(ops.WsdlError):
         ops.keep_largest_batched(torch.zeros(2, 8, 8, dtype=torch.uint8))   # no CPU fallback
+
+
+def test_stem_kernel_equals_the_generic_fp32_kernel(dev):
+    """The 7x7 stride-2 stem on its own kernel (patch + weights in LDS) against the generic fp32 implicit-GEMM kernel: both exact
+    fp32 products, different summation order - 1e-5 - with the eval-mode epilogue (scale, shift, ReLU, published amax)."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 3, 224, 224, generator=g).to(dev)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).to(dev)
+    sc, sh = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+    wf, _ = ops.prep_weights(w)
+    outs = []
+    try:
+        for on in (1, 0):
+            ops.set_option("stem_kernel", on)
+            y = ops.conv2d_fwd(x, wf, w.shape, 2, 3, 1)
+            ye = ops.conv2d_fwd(x, wf, w.shape, 2, 3, 1, sc, sh, None, True)
+            outs.append((y, ye, ops.amax_of(ye, True) if hasattr(ye, "_wsdl_amax") else None))
+    finally:
+        ops.set_option("stem_kernel", 1)
+    (y1, ye1, a1), (y0, ye0, a0) = outs
+    assert tuple(y1.shape) == (4, 64, 112, 112)
+    assert rel_err(y1, y0) < 1e-5 and rel_err(ye1, ye0) < 1e-5
+    ref = F.conv2d(x.cpu(), w.cpu(), None, 2, 3)
+    assert rel_err(y1, ref) < 1e-4
+    if a1 is not None:
+        assert abs(a1.item() - ye1.abs().max().item()) <= 1e-6 * ye1.abs().max().item()

@@ -1479,6 +1479,107 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     return WSDL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stem: 7x7, stride 2, padding 3, three input channels, 64 output channels (ResNet's conv1; K = 147 is no multiple of
+// 16, so it ran on the generic fp32 kernel with per-element bounds checks: 150 us at B = 16, 256 x 256 - alone at the head
+// of the step).  One workgroup per 8 x 32 tile of output pixels: the 21 x 69 x 3 input patch and all 64 x 147 weights go
+// to LDS once (56 KB: two workgroups per CU), the implicit GEMM runs from LDS on v_mfma_f32_32x32x2_f32 - exact fp32
+// products as before, k = tap * 3 + ci as in the k-major weight layout.  The patch is stored de-interleaved by column
+// parity so that the 32 pixels of a fragment (input columns 2 ox + kx) read consecutive words.
+constexpr int kStemTH = 8, kStemTW = 32;
+constexpr int kStemIH = 2 * kStemTH + 5;            // 21 input rows
+constexpr int kStemHalf = kStemTW + 3;              // 35 columns of one parity (69 = 35 even + 34 odd)
+constexpr int kStemIW = 2 * kStemHalf;              // row stride in LDS
+constexpr int kStemPlane = kStemIH * kStemIW;
+constexpr int kStemK = 148;                         // 147 + one zero row: K steps of 2
+int g_stem_kernel = 1;
+
+__global__ __launch_bounds__(256, 2) void stem_conv7x7s2_kernel(ConvP p, int tiles_w, int tiles_h) {
+    __shared__ float w_s[kStemK * 64];              // [k][cout]
+    __shared__ float x_s[3 * kStemPlane];
+    __shared__ int koff[kStemK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tw = blockIdx.x % tiles_w, th = (blockIdx.x / tiles_w) % tiles_h, b = blockIdx.x / (tiles_w * tiles_h);
+    const int oy0 = th * kStemTH, ox0 = tw * kStemTW;
+    for (int i = tid; i < 147 * 64; i += 256) w_s[i] = p.wt[i];
+    if (tid < 64) w_s[147 * 64 + tid] = 0.f;
+    if (tid < kStemK) {
+        const int k = tid < 147 ? tid : 0;
+        const int tap = k / 3, ci = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+        koff[tid] = ci * kStemPlane + ky * kStemIW + (kx & 1) * kStemHalf + (kx >> 1);
+    }
+    const float* xb = p.x + (long long)b * p.x_bs;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3, HW = p.H * p.W;
+    for (int i = tid; i < 3 * kStemIH * (2 * kStemTW + 5); i += 256) {
+        const int ci = i / (kStemIH * 69), r = i - ci * (kStemIH * 69);
+        const int row = r / 69, col = r - row * 69;
+        const int iy = iy0 + row, ix = ix0 + col;
+        float v = 0.f;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xb[(long long)ci * HW + iy * p.W + ix];
+        x_s[ci * kStemPlane + row * kStemIW + (col & 1) * kStemHalf + (col >> 1)] = v;
+    }
+    __syncthreads();
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int base0 = (2 * (2 * wid)) * kStemIW + l31, base1 = base0 + 2 * kStemIW;     // output rows 2 wid, 2 wid + 1
+#pragma unroll 2
+    for (int st = 0; st < kStemK / 2; ++st) {
+        const int k = 2 * st + lh;
+        const int ko = koff[k];
+        const float b0 = x_s[base0 + ko], b1 = x_s[base1 + ko];
+        const float a0 = w_s[k * 64 + l31], a1 = w_s[k * 64 + 32 + l31];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // D row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = lane & 31 (the pixel): 128-byte runs of one channel
+    const int OHOW = p.OH * p.OW;
+    float vmax = 0.f;
+    const int ox = ox0 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int oy = oy0 + 2 * wid + j;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        float* yb = p.y + (long long)b * p.y_bs + oy * p.OW + ox;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r];
+                if (p.scale) v *= p.scale[co];
+                if (p.shift) v += p.shift[co];
+                if (p.relu) v = fmaxf(v, 0.f);
+                yb[(long long)co * OHOW] = v;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+    }
+    if (p.y_amax) publish_amax(vmax, p.y_amax);
+}
+
+static bool stem_eligible(const ConvP& p) {
+    return g_stem_kernel && p.KH == 7 && p.KW == 7 && p.Cin == 3 && p.Cout == 64 && p.ah == 2 && p.bh == 1 && p.ch == -3 &&
+           p.sh == 1 && !p.res && !p.accumulate && p.OH * 2 >= p.H && (long long)p.B * p.OH * p.OW < (1ll << 31);
+}
+
+static int launch_stem(const ConvP& p, hipStream_t s, double flops) {
+    const int tiles_w = wsdl::cdiv(p.OW, kStemTW), tiles_h = wsdl::cdiv(p.OH, kStemTH);
+    const long long blocks = (long long)p.B * tiles_w * tiles_h;
+    WSDL_REQUIRE(blocks < (1ll << 31), "conv2d_fwd: too many stem tiles");
+    const double bytes = 4.0 * ((double)p.B * 3 * p.H * p.W + 147.0 * 64 + (double)p.P * 64);
+    wsdl::ProfScope prof(WSDL_PROF_IGEMM_64x256_U, s, flops, flops, bytes);
+    hipLaunchKernelGGL(stem_conv7x7s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, tiles_w, tiles_h);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
 // The buffer-descriptor kernels address the input tensor with 32-bit byte offsets.  A batch whose input extent
 // reaches 2 GiB (large batches of large maps - 288 GB of HBM invite them) is processed in batch slices that each
 // stay below it; a single image of >= 2 GiB falls through to launch_igemm's own handling.
@@ -1630,6 +1731,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
@@ -1733,6 +1835,7 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y, int B, int Cin
     WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * OH * OW, "conv2d_fwd: batch stride smaller than an image");
     p.relu = relu; p.accumulate = 0; p.P = B * OH * OW;
     p.x_amax = x_amax; p.y_amax = y_amax;
+    if (stem_eligible(p)) return launch_stem(p, wsdl::as_stream(stream), 2.0 * p.P * (double)Cout * p.K);
     return launch_igemm_sliced(p, OH * OW, (long long)Cin * H * W, wsdl::as_stream(stream),
                                2.0 * p.P * (double)Cout * p.K, ws, ws_bytes);
 }
