@@ -1574,7 +1574,7 @@ static int launch_stem(const ConvP& p, hipStream_t s, double flops) {
     const long long blocks = (long long)p.B * tiles_w * tiles_h;
     WSDL_REQUIRE(blocks < (1ll << 31), "conv2d_fwd: too many stem tiles");
     const double bytes = 4.0 * ((double)p.B * 3 * p.H * p.W + 147.0 * 64 + (double)p.P * 64);
-    wsdl::ProfScope prof(WSDL_PROF_IGEMM_64x256_U, s, flops, flops, bytes);
+    wsdl::ProfScope prof(WSDL_PROF_STEM, s, flops, flops, bytes);
     hipLaunchKernelGGL(stem_conv7x7s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, tiles_w, tiles_h);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;

@@ -1306,7 +1306,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 19
+PROF_NCLASSES = 20
 
 
 def prof_class_name(cls):
