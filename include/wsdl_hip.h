@@ -161,6 +161,20 @@ int wsdl_conv2d_fwd(const float* x, const void* wt_fwd, float* y,
                     const float* x_amax /* device scalar >= max|x| (fp16x2 split launches; else may be NULL) */,
                     float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
                     void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* The split layouts of MANY convolutions in one launch (the re-layout after an optimiser step).  Entries must be convolutions
+ * whose forward AND dgrad layouts are split layouts (wsdl_conv2d_weight_layout_bytes: plain = 0 for both; kh*kw <= 9) under the
+ * fp16x2 arithmetic; w_amax as in wsdl_conv2d_prep_weights but REQUIRED.  `desc` is a DEVICE array of n entries, block_begin =
+ * the running sum of grid_x * grid_y with grid_x = ceil(Cin / 32), grid_y = ceil(Cout / 32); total_blocks = its final value. */
+typedef struct wsdl_prep_desc {
+    const float* w;          /* [Cout][Cin][taps] */
+    void* wt_fwd;            /* may be NULL */
+    void* wt_dgrad;          /* may be NULL */
+    const float* w_amax;     /* device scalar >= max|w| */
+    int Cout, Cin, taps, grid_x;
+    int block_begin, reserved;
+} wsdl_prep_desc;
+int wsdl_conv2d_prep_weights_multi(const wsdl_prep_desc* desc, int n, int total_blocks, wsdl_stream_t stream);
+
 /* Optional scratch for forward / dgrad: grids too small to fill 256 CUs (small batches of small maps) are split
  * along K into slabs summed in fixed order.  Returns 0 when the geometry does not benefit; ws may be NULL. */
 size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw,

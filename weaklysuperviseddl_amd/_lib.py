@@ -32,6 +32,7 @@ SIGNATURES = {
     "wsdl_conv2d_prep_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "wsdl_conv2d_fwd": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_vp, _vp, _vp, _i, _ll, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
     "wsdl_conv2d_igemm_workspace": (_sz, [_i] * 11),
+    "wsdl_conv2d_prep_weights_multi": (_i, [_vp, _i, _i, _vp]),
     "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _vp, _ll, _vp, _vp, _sz, _vp]),
     "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),

@@ -1864,6 +1864,14 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
                                2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
 }
 
+int wsdl_conv2d_prep_weights_multi(const wsdl_prep_desc* desc, int n, int total_blocks, wsdl_stream_t stream) {
+    WSDL_REQUIRE(desc && n > 0 && total_blocks > 0, "prep_weights_multi: bad arguments");
+    WSDL_REQUIRE(g_conv_arith == 1 && g_conv_split, "prep_weights_multi: only the fp16x2 split layouts");
+    hipLaunchKernelGGL(prep_weights_split_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, wsdl::as_stream(stream), desc, n);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
 size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
                                    int pad, int dil, int dgrad) {
     int OH, OW;

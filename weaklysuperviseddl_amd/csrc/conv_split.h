@@ -521,15 +521,15 @@ __global__ void multi_amax_kernel(const float* const* __restrict__ ptrs, const l
 // One thread converts 8 consecutive k of one row and writes NP 16-byte runs.  AR = 1: `amax` (device scalar, the
 // tensor's max|w|, already reduced) gives the scale; it is also copied into both layouts' trailers.
 template <int AR>
-__global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ fwd,
-                                          unsigned char* __restrict__ dg, int Cout, int Cin, int T,
-                                          const float* __restrict__ amax) {
+__device__ __forceinline__ void prep_weights_split_body(const float* __restrict__ w, unsigned char* __restrict__ fwd,
+                                                        unsigned char* __restrict__ dg, int Cout, int Cin, int T,
+                                                        const float* __restrict__ amax, int bx, int by) {
     constexpr int NP = SplitArith<AR>::NP;
     constexpr int K16B = split_k16_bytes(AR);
     // a block stages w[co0..co0+31][ci0..ci0+31][all taps] like prep_weights_tiled_kernel (T <= 9)
     constexpr int LDT = 32 * 9 + 1;
     __shared__ float tile[32 * LDT];
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int ci0 = bx * 32, co0 = by * 32;
     const int tid = threadIdx.x;
     const int nci = min(32, Cin - ci0), nco = min(32, Cout - co0);
     const int run = nci * T;
@@ -537,7 +537,7 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
     if constexpr (AR == 1) {
         int e;
         ws = pow2_scale(*amax, e);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        if (bx == 0 && by == 0 && tid == 0) {
             const long long body = split_layout_bytes(AR, (long long)T * Cin, Cout) - 16;     // same for both layouts
             if (fwd) *reinterpret_cast<float*>(fwd + body) = *amax;
             if (dg) *reinterpret_cast<float*>(dg + body) = *amax;
@@ -583,6 +583,30 @@ __global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned 
             emit(dg + ((long long)(k / 16) * Cin + ci0 + cil) * K16B + (k % 16) * 2, v);
         }
     }
+}
+
+template <int AR>
+__global__ void prep_weights_split_kernel(const float* __restrict__ w, unsigned char* __restrict__ fwd,
+                                          unsigned char* __restrict__ dg, int Cout, int Cin, int T,
+                                          const float* __restrict__ amax) {
+    prep_weights_split_body<AR>(w, fwd, dg, Cout, Cin, T, amax, blockIdx.x, blockIdx.y);
+}
+
+// All the split layouts of a model in ONE launch (the per-step re-layout after the optimiser step was 66 launches of 7 us on
+// the side stream, beside the first layers of the next forward).  Workgroup b belongs to the last entry whose block_begin
+// is <= b; the table lives on the device and is built once per set of buffers.
+template <int AR>
+__global__ void prep_weights_split_multi_kernel(const wsdl_prep_desc* __restrict__ d, int n) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+    }
+    const wsdl_prep_desc q = d[lo];
+    const int lb = b - q.block_begin;
+    prep_weights_split_body<AR>(q.w, static_cast<unsigned char*>(q.wt_fwd), static_cast<unsigned char*>(q.wt_dgrad), q.Cout, q.Cin,
+                                q.taps, q.w_amax, lb % q.grid_x, lb / q.grid_x);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -103,7 +103,7 @@ def prep_stream(device):
     return st
 
 
-def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=False, after=None):
+def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=False, after=None, _head=True):
     """Lay out next step's weights on the side stream (called right after the optimiser step of these weights): the
     re-layout kernels leave the forward chain; each conv waits on its own event (``use_events=False``: the main stream
     joins the side stream instead - inside a captured graph).
@@ -115,11 +115,11 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
         return
     dev = convs[0].weight.device
     main, side = torch.cuda.current_stream(dev), side_stream(dev)
-    if _PREFETCH_HEAD > 0 and len(convs) > 2 * _PREFETCH_HEAD:
+    if _head and _PREFETCH_HEAD > 0 and len(convs) > 2 * _PREFETCH_HEAD:
         # the forward that follows waits for its FIRST layers' layouts: give those their own (small) amax launch instead of
         # queueing them behind the amax pass over all 158 MB of weights (105 us before the next step could start)
-        prefetch_weight_layouts(convs[:_PREFETCH_HEAD], use_events, epoch_ahead, pingpong, after)
-        return prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong, after)
+        prefetch_weight_layouts(convs[:_PREFETCH_HEAD], use_events, epoch_ahead, pingpong, after, False)
+        return prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong, after, False)
     if after is not None and use_events:
         side = prep_stream(dev)
         side.wait_event(after)
@@ -127,22 +127,43 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
         side.wait_stream(main)
     ev = None
     with torch.cuda.stream(side):
-        amaxes = multi_amax([m.weight for m in convs]) if CONV_ARITH[0] == 1 else None
+        amaxes = multi_amax([m.weight for m in convs], persistent=True) if CONV_ARITH[0] == 1 else None
+        batch = []          # convolutions whose existing split layouts are rewritten by ONE launch (after the loop)
         for i, m in enumerate(convs):
             cache = m.__dict__.setdefault("_wsdl_cache", {})
             fresh = cache.get("prep_layout") == LAYOUT_EPOCH[0]
             old = cache.get("prep") if fresh else None
             target = (cache.get("prep_spare") if fresh else None) if pingpong else old
-            wf, wd = prep_weights(m.weight, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=target)
-            ev = None
-            if use_events:
-                ev = torch.cuda.Event()
-                ev.record(side)
             w = m.weight
+            in_batch = (MULTI_PREP[0] and amaxes is not None and target is not None and target[0] is not None
+                        and target[1] is not None and w.is_contiguous() and _both_split(w))
+            ev = None
+            if in_batch:
+                wf, wd = target
+                batch.append((w, wf, wd, amaxes[i:i + 1], cache))
+            else:
+                wf, wd = prep_weights(w, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=target)
+                if use_events:
+                    ev = torch.cuda.Event()
+                    ev.record(side)
             cache["prep_key"] = (PARAM_EPOCH[0] + epoch_ahead, w._version, w.data_ptr())
             cache["prep"], cache["prep_event"] = (wf, wd), ev
             cache["prep_spare"] = old if pingpong else None
             cache["prep_layout"] = LAYOUT_EPOCH[0]
+        if batch and torch.cuda.is_current_stream_capturing() and not prep_weights_multi([b[:4] for b in batch], lookup_only=True):
+            # a capture cannot copy a new descriptor table to the device: launch them one by one (as before)
+            for w, wf, wd, a, _c in batch:
+                prep_weights(w, True, True, a, reuse=(wf, wd))
+            batch = []
+        if batch:
+            prep_weights_multi([b[:4] for b in batch])
+            if use_events:
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for b in batch:
+                    b[4]["prep_event"] = ev
+            else:
+                ev = None
     if not use_events:
         main.wait_stream(side)          # graph capture: no cross-replay events - the step ends with the layouts complete
     return ev                           # recorded behind the last re-layout (None without events)
@@ -312,21 +333,70 @@ def prep_weights(w, want_fwd=True, want_dgrad=True, w_amax=None, reuse=None):
 _multi_amax_cache = {}
 
 
-def multi_amax(tensors):
+def multi_amax(tensors, persistent=False):
     """max|t| of every tensor of a FIXED list in one launch -> (n,) device tensor.  The pointer / count tables live on
-    the device and are built once per list (parameters keep their addresses inside the flat optimiser buffer)."""
+    the device and are built once per list (parameters keep their addresses inside the flat optimiser buffer).
+    ``persistent``: the result goes into one buffer per list, overwritten by the next call (stream-ordered consumers only)."""
     key = tuple((t.data_ptr(), t.numel()) for t in tensors)
     ent = _multi_amax_cache.get(key)
     dev = tensors[0].device
     if ent is None:
         ptrs = torch.tensor([k[0] for k in key], dtype=torch.int64).to(dev)
         counts = torch.tensor([k[1] for k in key], dtype=torch.int64).to(dev)
-        ent = _multi_amax_cache[key] = (ptrs, counts)
+        ent = _multi_amax_cache[key] = (ptrs, counts, torch.empty(len(tensors), device=dev, dtype=torch.float32))
         if len(_multi_amax_cache) > 64:
             _multi_amax_cache.pop(next(iter(_multi_amax_cache)))
-    out = torch.empty(len(tensors), device=dev, dtype=torch.float32)
+    out = ent[2] if persistent else torch.empty(len(tensors), device=dev, dtype=torch.float32)
     check(lib().wsdl_multi_amax(_p(ent[0]), _p(ent[1]), len(tensors), _p(out), _stream()))
     return out
+
+
+MULTI_PREP = [os.environ.get("WSDL_MULTI_PREP", "1") != "0"]      # the per-step re-layout of all split layouts in one launch
+_both_split_cache = {}
+_prep_tables = {}
+
+
+def _both_split(w):
+    """Are the forward and the dgrad layout of this weight both split layouts (what wsdl_conv2d_prep_weights_multi takes)?"""
+    import ctypes
+    key = tuple(w.shape)
+    r = _both_split_cache.get(key)
+    if r is None:
+        Cout, Cin, kh, kw = key
+        pf, pd = ctypes.c_int(0), ctypes.c_int(0)
+        lib().wsdl_conv2d_weight_layout_bytes(Cout, Cin, kh, kw, 0, ctypes.byref(pf))
+        lib().wsdl_conv2d_weight_layout_bytes(Cout, Cin, kh, kw, 1, ctypes.byref(pd))
+        r = _both_split_cache[key] = (pf.value == 0 and pd.value == 0 and kh * kw <= 9)
+    return r
+
+
+class _PrepDesc(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("wt_fwd", C.c_void_p), ("wt_dgrad", C.c_void_p), ("w_amax", C.c_void_p),
+                ("Cout", C.c_int), ("Cin", C.c_int), ("taps", C.c_int), ("grid_x", C.c_int),
+                ("block_begin", C.c_int), ("reserved", C.c_int)]
+
+
+def prep_weights_multi(entries, lookup_only=False):
+    """entries: [(weight, wt_fwd, wt_dgrad, w_amax (1,) device tensor)] with existing layout buffers, all ``_both_split``:
+    one launch re-lays them all out (include/wsdl_hip.h wsdl_conv2d_prep_weights_multi).  The descriptor table goes to the
+    device once per set of addresses (weights live in the flat optimiser buffer, layout buffers are reused step after step)."""
+    key = tuple((w.data_ptr(), wf.data_ptr(), wd.data_ptr(), a.data_ptr()) for w, wf, wd, a in entries)
+    ent = _prep_tables.get(key)
+    if lookup_only:
+        return ent is not None
+    if ent is None:
+        arr = (_PrepDesc * len(entries))()
+        blocks = 0
+        for d, (w, wf, wd, a) in zip(arr, entries):
+            Cout, Cin, kh, kw = w.shape
+            d.w, d.wt_fwd, d.wt_dgrad, d.w_amax = w.data_ptr(), wf.data_ptr(), wd.data_ptr(), a.data_ptr()
+            d.Cout, d.Cin, d.taps, d.grid_x, d.block_begin = Cout, Cin, kh * kw, (Cin + 31) // 32, blocks
+            blocks += d.grid_x * ((Cout + 31) // 32)
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
+        ent = _prep_tables[key] = (table, len(entries), blocks)
+        if len(_prep_tables) > 16:
+            _prep_tables.pop(next(iter(_prep_tables)))
+    check(lib().wsdl_conv2d_prep_weights_multi(_p(ent[0]), ent[1], ent[2], _stream()))
 
 
 def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, residual=None, relu=False, out=None,
