@@ -614,6 +614,41 @@ def test_identity_link_is_taken_and_changes_nothing(dev, monkeypatch):
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
 
 
+def test_projection_shortcut_link_changes_nothing(dev, monkeypatch):
+    """Blocks with a projection shortcut (conv + BatchNorm): the last node hands the shortcut node the block output's dy itself
+    and the final ReLU's bits (``IdentityLink(projection=True)``) - no masked copy of dy is written by any block of the
+    chain; gradients equal those of the ``dres`` path bit for bit."""
+    from weaklysuperviseddl_amd import nn as wnn, ops
+
+    def run(link_on):
+        monkeypatch.setattr(ops, "IDENTITY_LINK", [link_on])
+        torch.manual_seed(0)
+        ds0 = wnn.FusedSequential(wnn.Conv2d(128, 256, 1, stride=2), wnn.BatchNorm2d(256))
+        ds2 = wnn.FusedSequential(wnn.Conv2d(256, 512, 1), wnn.BatchNorm2d(512))
+        blocks = torch.nn.Sequential(wnn.Bottleneck(128, 64, stride=2, downsample=ds0), wnn.Bottleneck(256, 64),
+                                     wnn.Bottleneck(256, 128, downsample=ds2)).to(dev).train()
+        x = torch.randn(4, 128, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_()
+        dres_calls = []
+        real = ops.bn_train_bwd
+
+        def counting(*a, **k):
+            dres_calls.append(bool(a[7]))          # want_dres
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "bn_train_bwd", counting)
+        y = blocks(x)
+        head = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+        (y * head).sum().backward()
+        monkeypatch.setattr(ops, "bn_train_bwd", real)
+        stats = [b.clone() for b in blocks.buffers()]
+        return y.detach(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()], stats, sum(dres_calls)
+
+    y1, dx1, g1, s1, n1 = run(True)
+    y0, dx0, g0, s0, n0 = run(False)
+    assert (n1, n0) == (0, 3), (n1, n0)
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+    assert all(torch.equal(a, b) for a, b in zip(s1, s0))
+
+
 def test_cfg1_layercam_on_the_stated_batch_of_8(dev, cam_models):
     """BASELINE configs[0]: ClassificationModel + LayerCAM on 8 synthetic 224 x 224 RGB images - the full stated batch
     (B changes the tile / split-K choices of the small-grid kernels), class_idx = i mod 37, against the

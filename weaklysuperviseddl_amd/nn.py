@@ -167,11 +167,16 @@ class Bottleneck(nn.Module):
         # ops.conv_bn_act) so that the two input gradients are summed in conv1's dgrad epilogue
         # identity blocks in train mode: the identity branch's gradient goes from the last node to the first through an
         # ops.IdentityLink instead of through a tensor of its own
-        link = ops.IdentityLink() if (self.downsample is None and self.bn1.training and self.bn3.training
-                                      and torch.is_grad_enabled()) else None
-        y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True, link=link)
-        if self.downsample is not None:
-            idt = self.downsample(idt)
+        train = self.bn1.training and self.bn3.training and torch.is_grad_enabled()
+        ds = self.downsample
+        proj = (train and ds is not None and len(ds) == 2 and isinstance(ds[0], Conv2d) and isinstance(ds[1], BatchNorm2d)
+                and ds[1].training and ds[0].bias is None)
+        link = ops.IdentityLink(projection=proj) if (train and (ds is None or proj)) else None
+        y, idt = conv_bn(x, self.conv1, self.bn1, True, passthrough=True, link=None if proj else link)
+        if proj:
+            idt = conv_bn(idt, ds[0], ds[1], False, link=link)       # the projection shortcut, joined to the last node
+        elif ds is not None:
+            idt = ds(idt)
         y = conv_bn(y, self.conv2, self.bn2, True)
         return conv_bn(y, self.conv3, self.bn3, True, residual=idt, link=link)   # relu(bn3(conv3) + identity)
 

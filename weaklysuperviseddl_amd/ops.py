@@ -666,10 +666,14 @@ class IdentityLink:
     adds [bits] * dy inside its dgrad epilogue, in dy's own buffer: one tensor write and one allocation less per block.
     Only when dy is a buffer the library owns (``_owned``); otherwise the ``dres`` path runs as before.  WSDL_IDENTITY_LINK=0
     switches it off (A/B; same result bit for bit)."""
-    __slots__ = ("pending",)
+    __slots__ = ("pending", "projection")
 
-    def __init__(self):
+    def __init__(self, projection=False):
+        # projection: the block's shortcut is a convolution + BatchNorm (the first block of a layer).  Then the link joins the
+        # block's LAST node and that shortcut node: the last node hands the shortcut dy itself as "gradient" (an alias: no
+        # tensor written) and the bits here; the shortcut's BatchNorm backward applies them (relu = 3) to what it reads.
         self.pending = None
+        self.projection = projection
 
 
 IDENTITY_LINK = [os.environ.get("WSDL_IDENTITY_LINK", "1") != "0"]
@@ -717,23 +721,43 @@ class _ConvBNAct(torch.autograd.Function):
         link = ctx.link
         if dy is None:
             raise WsdlError("conv -> BatchNorm node: no gradient arrived for its output")
-        if (link is not None and need_res and rbits is not None and IDENTITY_LINK[0] and _owned(dy)
-                and tuple(dy.shape) == tuple(conv.shape)):
-            link.pending = (dy, rbits)       # consumed by the block's first node (its backward runs after this one)
-            need_res = False
+        alias_dres = False
+        if (link is not None and need_res and rbits is not None and IDENTITY_LINK[0] and tuple(dy.shape) == tuple(conv.shape)
+                and dy.is_contiguous()):
+            if link.projection:
+                link.pending = (dy, rbits)   # consumed by the shortcut's node, which receives dy itself as its gradient
+                need_res, alias_dres = False, True
+            elif _owned(dy):
+                link.pending = (dy, rbits)   # consumed by the block's first node (its backward runs after this one)
+                need_res = False
+        # the shortcut node of a projection block: its "gradient" is the block output's dy, to be masked by the bits
+        shortcut_bits = None
+        if link is not None and link.projection and not has_res:
+            if link.pending is not None:
+                src, shortcut_bits = link.pending
+                link.pending = None
+                if src.data_ptr() != dy.data_ptr() or tuple(src.shape) != tuple(dy.shape):
+                    raise WsdlError("projection shortcut: the gradient that arrived is not the block output's (autograd "
+                                    "copied or summed it) - set WSDL_IDENTITY_LINK=0")
+        if shortcut_bits is not None:
+            relu_b, y_b, beta_b, bits_b = True, None, None, shortcut_bits      # dy' = [bits] * dy, then this node's BatchNorm
+        else:
+            relu_b, y_b, beta_b, bits_b = relu, y, beta_s, rbits
         sg = _sink_of(pg) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and _sink_of(pg) is _sink_of(pb)) else None
         if sg is not None:
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
-            dconv, _, _, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res,
-                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_s, relu_mask=rbits)
+            dconv, _, _, dres = bn_train_bwd(conv, dy, y_b, _dense(gamma), mean, invstd, relu_b, need_res,
+                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_b, relu_mask=bits_b)
             dgamma = dbeta = None
             sg.grad_ready(pg)
             sg.grad_ready(pb)
         else:
-            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y, _dense(gamma), mean, invstd, relu, need_res, beta=beta_s,
-                                                      relu_mask=rbits)
+            dconv, dgamma, dbeta, dres = bn_train_bwd(conv, dy, y_b, _dense(gamma), mean, invstd, relu_b, need_res, beta=beta_b,
+                                                      relu_mask=bits_b)
+        if alias_dres:
+            dres = dy
         pend = None
-        if link is not None and link.pending is not None and not has_res:
+        if link is not None and not link.projection and link.pending is not None and not has_res:
             pend, link.pending = link.pending, None
 
         def input_grad():
