@@ -44,6 +44,9 @@ class _ASPPPooling(wnn.FusedSequential):
         return ops.bilinear_resize(super().forward(x), size)
 
 
+_ASPP_IN_PLACE = os.environ.get("WSDL_ASPP_IN_PLACE", "1") != "0"     # A/B: 0 = plane copies of all five branches
+
+
 class ASPP(nn.Module):
     def __init__(self, cin=2048, rates=(12, 24, 36), cout=256):
         super().__init__()
@@ -56,11 +59,26 @@ class ASPP(nn.Module):
     def forward(self, x):
         # x feeds five branches: chain it through the four conv nodes (ops.conv_bn_act passthrough) so that the five
         # input gradients are summed inside the dgrad epilogues instead of by four 134 MB autograd adds
+        branches = list(self.convs)
+        if x.is_cuda and all(b[1].training for b in branches[:-1]) and _ASPP_IN_PLACE:
+            # train mode: the BatchNorm kernels of the four convolution branches write straight into their channel slices of
+            # the concatenation (and publish into ONE amax slot); only the pooling branch is copied in
+            B, _, H, W = x.shape
+            cs = [b[0].out_channels for b in branches[:-1]]
+            cat = torch.empty(B, self.project[0].in_channels, H, W, device=x.device, dtype=torch.float32)
+            slot = ops.amax_slot(x.device) if ops.CONV_ARITH[0] == 1 else None
+            outs, off = [], 0
+            for b, c in zip(branches[:-1], cs):
+                y, x = wnn.conv_bn(x, b[0], b[1], True, passthrough=True, out_holder=[cat[:, off:off + c], slot])
+                outs.append(y)
+                off += c
+            outs.append(branches[-1](x))
+            return self.project(ops.concat_into(cat, slot, outs))
         outs = []
-        for b in list(self.convs)[:-1]:
+        for b in branches[:-1]:
             y, x = wnn.conv_bn(x, b[0], b[1], True, passthrough=True)
             outs.append(y)
-        outs.append(self.convs[-1](x))
+        outs.append(branches[-1](x))
         return self.project(ops.concat_channels(outs))
 
 

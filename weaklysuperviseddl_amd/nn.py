@@ -118,7 +118,7 @@ class Linear(nn.Module):
         return ops.linear(x, self.weight, self.bias)
 
 
-def conv_bn(x, conv, bn, relu, residual=None, passthrough=False, link=None):
+def conv_bn(x, conv, bn, relu, residual=None, passthrough=False, link=None, out_holder=None):
     """conv -> bn (batch stats when bn.training, folded running stats otherwise) -> +residual -> relu."""
     if conv.bias is not None:
         raise RuntimeError("conv_bn: a conv followed by BN carries no bias on this path")
@@ -127,7 +127,7 @@ def conv_bn(x, conv, bn, relu, residual=None, passthrough=False, link=None):
     cache = conv.__dict__.setdefault("_wsdl_cache", {})         # derived tensors, keyed on versions / epochs
     return ops.conv_bn_act(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, conv.stride,
                            conv.padding, conv.dilation, relu, residual, bn.momentum, bn.eps, bn.training, cache,
-                           passthrough, link)
+                           passthrough, link, out_holder if bn.training else None)
 
 
 class FusedSequential(nn.Sequential):

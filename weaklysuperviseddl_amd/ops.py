@@ -510,7 +510,7 @@ BN_RELU_BITS = [os.environ.get("WSDL_BN_RELU_BITS", "1") != "0"]
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, residual=None, relu=False, out=None,
-                 want_mask=False, mask_if=True):
+                 want_mask=False, mask_if=True, amax_into=None):
     """``want_mask``: returns a fourth value - the ReLU mask as bits (uint8, numel/8 bytes; ``bn_train_bwd(relu_mask=)``),
     or None where the kernels do not write one (no ReLU, H*W not a multiple of 8, ``mask_if`` false)."""
     x = _dense(x, "x")
@@ -525,7 +525,8 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
     if residual is not None:
         residual = _dense(residual, "residual")
-    y_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
+    # amax_into: a slot shared by several producers (the branches of a concatenation: the maximum over all of them)
+    y_amax = (amax_into if amax_into is not None else amax_slot(x.device)) if CONV_ARITH[0] == 1 else None
     mask = None
     if want_mask and mask_if and relu and BN_RELU_BITS[0] and (H * W) % 8 == 0 and y_bs % 4 == 0:
         mask = torch.empty(x.numel() // 8, device=x.device, dtype=torch.uint8)
@@ -657,6 +658,12 @@ def _sink_of(param):
     return sink
 
 
+def _alias(t):
+    """A tensor over the same memory that autograd knows nothing about (not a view of ``t`` in its books): what a kernel
+    that writes into a slice of somebody else's buffer returns as its output."""
+    return torch.empty(0, device=t.device, dtype=t.dtype).set_(t.untyped_storage(), t.storage_offset(), t.shape, t.stride())
+
+
 class IdentityLink:
     """Shared by the two ``conv_bn_act`` calls that open and close an identity bottleneck (train mode).  The gradient of the
     block's input through the identity branch is [y > 0] * dy (dy: the gradient of the block's output, y its final ReLU).
@@ -684,7 +691,9 @@ class _ConvBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil, relu,
-                momentum, eps, cache=None, passthrough=False, link=None):
+                momentum, eps, cache=None, passthrough=False, link=None, out_holder=None):
+        # out_holder ([view into a larger buffer, shared amax slot] - a list, so that autograd does not see the tensors): the
+        # BatchNorm kernel writes its output straight into a channel slice of a concatenation buffer (ASPP) - see concat_into
         # link (IdentityLink, shared by the first and the last node of an identity bottleneck): the last node's backward
         # does not write the masked gradient of the identity branch; it leaves (dy, mask bits) in the link and the first
         # node's dgrad epilogue adds [mask] * dy into dy's buffer - see IdentityLink
@@ -697,7 +706,9 @@ class _ConvBNAct(torch.autograd.Function):
         x_amax = amax_of(x, _split_kc(x.shape[1], weight.shape[2] * weight.shape[3]) or _wgrad_split(weight.shape))
         conv = conv2d_fwd(x, wf, weight.shape, stride, pad, dil, x_amax=x_amax)
         y, mean, invstd, rbits = bn_train_fwd(conv, _dense(gamma), _dense(beta), running_mean, running_var, momentum, eps,
-                                              residual, relu, want_mask=True, mask_if=bool(relu) and residual is not None)
+                                              residual, relu, out=_alias(out_holder[0]) if out_holder else None,
+                                              want_mask=True, mask_if=bool(relu) and residual is not None,
+                                              amax_into=out_holder[1] if out_holder else None)
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
         ctx.x_amax = x_amax              # saved tensors come back as new Python objects: keep the scalar explicitly
@@ -794,7 +805,7 @@ class _ConvBNAct(torch.autograd.Function):
         if not WGRAD_AFTER_DGRAD[0]:
             dx = input_grad()
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
-                dres, None, None, None, None, None, None, None, None, None, None, None)
+                dres, None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 class _ConvAffineAct(torch.autograd.Function):
@@ -1019,6 +1030,46 @@ class _ConcatChannels(torch.autograd.Function):
         return tuple(outs)
 
 
+class _ConcatInto(torch.autograd.Function):
+    """torch.cat(dim=1) into a buffer some of whose channel slices the producers have already written (``out_holder`` of
+    ``conv_bn_act``): only the other inputs are copied.  ``holder`` = [buffer, shared amax slot or None]."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        base, slot = holder
+        B, Ctot, H, W = base.shape
+        Cs = [int(t.shape[1]) for t in xs]
+        if sum(Cs) != Ctot:
+            raise WsdlError("concat_into: channel counts do not add up to the buffer's")
+        off, tot = 0, Ctot * H * W
+        for t, c in zip(xs, Cs):
+            dst = base[:, off:off + c]
+            in_place = (t.data_ptr() == dst.data_ptr() and tuple(t.shape) == tuple(dst.shape) and t.stride() == dst.stride())
+            if not in_place:
+                t = _dense(t, "cat input")
+                check(lib().wsdl_copy_planes(_p(t), _vp(dst.data_ptr()), B, c, H * W, 0, tot, _stream()))
+                if slot is not None:      # this input's maximum joins the slot the in-place producers published into
+                    check(lib().wsdl_amax(_p(t), B, c * H * W, c * H * W, _p(slot), 0, _stream()))
+            off += c
+        ctx.Cs = Cs
+        out = _alias(base)
+        if slot is not None:
+            _publish_amax(out, slot)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, off = [None], 0
+        for c in ctx.Cs:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat_into(base, slot, xs):
+    return _ConcatInto.apply([base, slot], *xs)
+
+
 class _AddAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, relu):
@@ -1110,13 +1161,13 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------ functional API
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, stride, pad, dil, relu, residual=None,
-                momentum=0.1, eps=1e-5, training=True, cache=None, passthrough=False, link=None):
+                momentum=0.1, eps=1e-5, training=True, cache=None, passthrough=False, link=None, out_holder=None):
     """passthrough=True returns (y, x'): x' is x routed through this node, to be used as the identity branch so that
     its gradient is summed in the dgrad epilogue (train mode; eval mode returns x itself)."""
     if training:
         bump_stats_epoch()          # running statistics are about to be rewritten behind torch's back
         return _ConvBNAct.apply(x, weight, gamma, beta, residual, running_mean, running_var, stride, pad, dil,
-                                bool(relu), momentum, eps, cache, bool(passthrough), link)
+                                bool(relu), momentum, eps, cache, bool(passthrough), link, out_holder)
     key = _cache_key(gamma, beta, running_mean, running_var) if cache is not None else None
     if cache is not None and cache.get("fold_key") == key:
         scale, shift = cache["fold"]
