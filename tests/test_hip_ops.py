@@ -911,3 +911,58 @@ def test_stem_kernel_equals_the_generic_fp32_kernel(dev):
     assert rel_err(y1, ref) < 1e-4
     if a1 is not None:
         assert abs(a1.item() - ye1.abs().max().item()) <= 1e-6 * ye1.abs().max().item()
+
+
+def test_prep_weights_multi_equals_the_single_launches(dev):
+    """All split layouts in one launch (wsdl_conv2d_prep_weights_multi, a device table of descriptors) == one launch per
+    convolution, byte for byte: 1x1 and 3x3, channel counts that are not multiples of the 32 x 32 staging tile."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(31)
+    shapes = [(64, 64, 3, 3), (256, 64, 1, 1), (128, 256, 1, 1), (48, 80, 3, 3), (512, 512, 3, 3), (2048, 512, 1, 1), (16, 16, 1, 1)]
+    ws = [(torch.randn(s, generator=g) * (0.5 + i)).to(dev) for i, s in enumerate(shapes)]
+    assert all(ops._both_split(w) for w in ws) and not ops._both_split(torch.empty(64, 3, 7, 7)) and not ops._both_split(torch.empty(2, 256, 1, 1))
+    amax = ops.multi_amax(ws)
+    single = [ops.prep_weights(w, True, True, amax[i:i + 1]) for i, w in enumerate(ws)]
+    multi = [(torch.zeros_like(f), torch.zeros_like(d)) for f, d in single]
+    ops.prep_weights_multi([(w, f, d, amax[i:i + 1]) for i, (w, (f, d)) in enumerate(zip(ws, multi))])
+    for (f1, d1), (f2, d2), s in zip(single, multi, shapes):
+        assert torch.equal(f1.view(torch.int32), f2.view(torch.int32)) and torch.equal(d1.view(torch.int32), d2.view(torch.int32)), s
+    # the table is cached per set of addresses: a second call with new weight values re-lays them out
+    for w in ws:
+        w.mul_(1.5)
+    amax2 = ops.multi_amax(ws)
+    single2 = [ops.prep_weights(w, True, True, amax2[i:i + 1]) for i, w in enumerate(ws)]
+    amax.copy_(amax2)
+    ops.prep_weights_multi([(w, f, d, amax[i:i + 1]) for i, (w, (f, d)) in enumerate(zip(ws, multi))])
+    for (f1, d1), (f2, d2) in zip(single2, multi):
+        assert torch.equal(f1.view(torch.int32), f2.view(torch.int32)) and torch.equal(d1.view(torch.int32), d2.view(torch.int32))
+
+
+def test_concat_into_with_producers_writing_in_place(dev):
+    """ops.concat_into: BatchNorm kernels write two of three inputs straight into their channel slices of the buffer and publish
+    into one shared amax slot; the third input is copied in and its maximum joins the slot.  == torch.cat, gradients are the
+    slices, the slot holds the exact maximum."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator().manual_seed(33)
+    B, H, W = 3, 8, 12
+    xs = [torch.randn(B, c, H, W, generator=g).to(dev) for c in (16, 24)]
+    third = (torch.randn(B, 8, H, W, generator=g) * 3).to(dev).requires_grad_()
+    gam = [torch.rand(c, generator=g).to(dev) + 0.5 for c in (16, 24)]
+    bet = [torch.randn(c, generator=g).to(dev) for c in (16, 24)]
+    cat = torch.empty(B, 48, H, W, device=dev)
+    slot = ops.amax_slot(dev)
+    ys, ref, off = [], [], 0
+    for x, ga, be, c in zip(xs, gam, bet, (16, 24)):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        y, _, _ = ops.bn_train_fwd(x, ga, be, rm, rv, 0.1, 1e-5, None, True, out=ops._alias(cat[:, off:off + c]), amax_into=slot)
+        yr, _, _ = ops.bn_train_fwd(x, ga, be, rm.clone(), rv.clone(), 0.1, 1e-5, None, True)
+        ys.append(y)
+        ref.append(yr)
+        off += c
+    out = ops.concat_into(cat, slot, ys + [third])
+    want = torch.cat(ref + [third.detach()], dim=1)
+    assert torch.equal(out, want) and out.data_ptr() == cat.data_ptr()
+    assert abs(ops.amax_of(out, True).item() - want.abs().max().item()) <= 1e-6 * want.abs().max().item()
+    dy = torch.randn(out.shape, generator=g).to(dev)
+    out.backward(dy)
+    assert torch.equal(third.grad, dy[:, 40:48])
