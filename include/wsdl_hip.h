@@ -70,6 +70,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      leave a CU with 4 - forward -20..23 %, backward -7 % at 256 channels (profiles/r03_bn_kernels.txt)
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
+ *   wgrad_direct   1*  fp16x2 weight-gradient kernel with the x operand's MFMA fragments loaded straight from global memory (no LDS, no
+ *                      lane exchange for x; dY double-buffered in LDS, one barrier per chunk) where OW % 32 == 0, stride 1 and every
+ *                      tap's column shift is a multiple of 4 elements (1x1, dilation 4 / 12 / 24 / 36): 7-10 % faster there, bit-identical;
+ *                      2 = also for misaligned taps (a third 16-byte load per tile: 0-7 % slower), 0 = the LDS-staged kernel everywhere
  *   stem_kernel    1*  7x7 stride-2 convolution of 3 -> 64 channels (ResNet's conv1) on its own kernel: input patch and all weights
  *                      in LDS, fp32 MFMA (0: the generic fp32 implicit-GEMM kernel, the A/B partner)
  *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,

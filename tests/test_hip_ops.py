@@ -966,3 +966,30 @@ def test_concat_into_with_producers_writing_in_place(dev):
     dy = torch.randn(out.shape, generator=g).to(dev)
     out.backward(dy)
     assert torch.equal(third.grad, dy[:, 40:48])
+
+
+@pytest.mark.parametrize("case", [(2, 128, 32, 32, 128, 3, 1, 1), (2, 128, 32, 32, 256, 3, 2, 2), (1, 256, 32, 32, 128, 3, 4, 4),
+                                  (2, 128, 32, 32, 128, 3, 12, 12), (2, 256, 32, 32, 128, 1, 0, 1), (1, 128, 16, 64, 128, 3, 1, 1),
+                                  (3, 128, 8, 96, 128, 3, 36, 36)])
+def test_wgrad_direct_fragments_equal_the_lds_staged_kernel(dev, case):
+    """conv_wgrad_split16d_kernel (x fragments straight from global memory, masked at the image's left / right edge) against the
+    LDS-staged kernel it replaces where OW % 32 == 0 and stride = 1: the same products in the same order - bit for bit - and
+    against torch; dilations whose taps hang over the edge, rows of several chunks, taps that are dead altogether."""
+    from weaklysuperviseddl_amd import ops
+    B, Cin, H, W, Cout, k, pad, dil = case
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[:, :, :, 0] *= 3.0          # edge columns carry weight: a wrong mask shows
+    x[:, :, :, -1] *= 3.0
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    wr = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    F.conv2d(x, wr, None, 1, pad, dil).backward(dy)
+    outs = []
+    try:
+        for on in (2, 0):           # 2: the direct kernel also where taps are misaligned (dilation 1, 2: a third load per tile)
+            ops.set_option("wgrad_direct", on)
+            outs.append(ops.conv2d_wgrad(x.to(dev), dy.to(dev), wr.shape, 1, pad, dil))
+    finally:
+        ops.set_option("wgrad_direct", 1)
+    assert torch.equal(outs[0], outs[1]), (case, rel_err(outs[0], outs[1]))
+    assert_close(outs[0], wr.grad, what=f"wgrad {case}")

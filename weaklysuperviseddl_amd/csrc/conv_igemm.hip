@@ -1621,6 +1621,7 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
+int g_wgrad_direct = 1;      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
 int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
 int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
@@ -1732,6 +1733,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_direct")) { g_wgrad_direct = value; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
@@ -2029,8 +2031,19 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     if (g_wgrad_mfma16) {
                         hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();
-                        hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
-                                           (unsigned)dys_bytes, dy_amax);
+                        // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
+                        // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
+                        // with a third load for misaligned taps (dilation 1, 2) it is 0-7 % slower than the LDS-staged kernel
+                        // (wgrad_direct = 2 forces it for those too)
+                        bool taps_aligned = true;
+                        for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
+                        if (g_wgrad_direct && (taps_aligned || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
+                            (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
+                            hipLaunchKernelGGL(conv_wgrad_split16d_kernel, grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else
+                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
                     } else {
                         hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();

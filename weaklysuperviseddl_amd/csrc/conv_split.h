@@ -1072,7 +1072,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
             const unsigned x0 = even ? rb[2 * i] : recv;
             const unsigned x1 = even ? recv : rb[2 * i + 1];
             unsigned ph, pl;
+#ifdef WSDL_EXP_W_NOSPLIT        // timing-only build: x as if it arrived pre-split
+            ph = x0;
+            pl = x1;
+#else
             split2h(__builtin_bit_cast(float, x0) * xs, __builtin_bit_cast(float, x1) * xs, ph, pl);
+#endif
             unsigned char* d = Bs + st_row + i * 16 * ROW;
             *reinterpret_cast<unsigned*>(d + st_u0) = ph;
             *reinterpret_cast<unsigned*>(d + st_u1) = pl;
@@ -1086,10 +1091,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     if (t_dh >= p.H || (p.OH - 1) * p.stride + t_dh < 0 || t_dw >= p.W || (p.OW - 1) * p.stride + t_dw < 0) return;
     int c0 = next_valid(chunk_begin);
     if (c0 < chunk_end) load_tiles(c0);
+#ifdef WSDL_EXP_W_NOSTAGE            // timing-only build: the LDS image filled once (real data), the loop is barrier + ds_read + MFMA
+    if (c0 < chunk_end) store_tiles();
+#endif
     while (c0 < chunk_end) {
+#ifndef WSDL_EXP_W_NOSTAGE
         store_tiles();
         const int c1 = next_valid(c0 + 1);
         if (c1 < chunk_end) load_tiles(c1);
+#else
+        const int c1 = c0 + 1;
+#endif
         lds_barrier();
         half8 a[TMI][2], b[TNI][2];
 #pragma unroll
@@ -1102,6 +1114,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
             b[j][0] = *reinterpret_cast<const half8*>(Bb + j * 16 * ROW + fr0);
             b[j][1] = *reinterpret_cast<const half8*>(Bb + j * 16 * ROW + fr1);
         }
+#ifdef WSDL_EXP_W_NOMFMA             // timing-only build: staging, barriers and the fragment reads, no matrix work
+#pragma unroll
+        for (int i = 0; i < TMI; ++i)
+#pragma unroll
+            for (int j = 0; j < TNI; ++j) acc[i][j][0] += (float)a[i][0][0] + (float)a[i][1][1] + (float)b[j][0][2] + (float)b[j][1][3];
+#else
 #pragma unroll
         for (int i = 0; i < TMI; ++i)
 #pragma unroll
@@ -1112,6 +1130,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
                 c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
+#endif
         lds_barrier();
         c0 = c1;
     }
@@ -1125,6 +1144,204 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
+                slab[(long long)co * p.N + n] = acc[i][j][r] * out_scale;
+            }
+        }
+}
+
+// The same GEMM with the x operand's fragments taken STRAIGHT FROM GLOBAL MEMORY (round 3).  Timing-only builds of the
+// kernel above (profiles/r03_notes.md) showed it bound by its staging, not by the matrix cores: loads, the neighbour
+// exchange, the split and the LDS stores of x alone take 79 % of its time, the matrix loop alone 69 %.  Both operands are
+// K-major here (K = pixels, contiguous in NCHW), and a lane of v_mfma_f32_16x16x32_f16 holds 8 consecutive k of one row:
+// with 32-pixel chunks inside one output row (OW % 32 == 0, stride 1) those are 32 consecutive bytes of x - two 16-byte
+// loads per 16 x 32 tile, split in registers, no LDS, no lane exchange.  The four waves sit side by side along N (each:
+// all 128 rows of dY x 32 columns), so no x fragment is loaded or split twice; dY (pre-split rows, plain copies) still
+// goes through LDS, now double-buffered with ONE barrier per chunk.  Per chunk and thread: 8 vector loads instead of 20,
+// 4 LDS stores instead of 20.  Elements whose input column lies outside the image are zeroed by selects (the loads
+// themselves cannot fault: buffer descriptor).
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP p, const unsigned char* __restrict__ dys,
+                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
+    constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
+    constexpr int TMI = BM / 16, TNI = 2;
+    constexpr int A_U = BM * ROW / 16 / kThreads;          // 16-byte units per thread, exact
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][BM * ROW];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_order) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int L = (bz * gy + by) * gx + bx, eighth = (gx * gy * (int)gridDim.z) >> 3;
+        const int Lp = (L & 7) * eighth + (L >> 3);
+        bz = Lp / (gx * gy);
+        const int r = Lp - bz * (gx * gy);
+        by = r / gx;
+        bx = r - by * gx;
+    }
+    const int n0 = bx * BN, m0 = by * BM;
+    const int HW = p.H * p.W;
+    const __amdgpu_buffer_rsrc_t rdy =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(dys), 0, (int)dys_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    int ex, ed;
+    const float xs = pow2_scale(*p.x_amax, ex);
+    (void)pow2_scale(*dy_amax, ed);
+    const float out_scale = pow2(-(ex + ed));
+
+    const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
+    const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
+    if (t_dh >= p.H || (p.OH - 1) + t_dh < 0 || t_dw >= p.W || (p.OW - 1) + t_dw < 0) return;     // a dead tap (stride 1)
+    const int l15 = lane & 15, lg = lane >> 4;
+    // this lane's rows of x for its two tiles (channel ci0 + 32 wid + 16 j + l15), at its 8-pixel group
+    unsigned vrow[TNI];
+#pragma unroll
+    for (int j = 0; j < TNI; ++j) vrow[j] = (unsigned)((ci0 + wid * 32 + j * 16 + l15) * HW + lg * 8);
+
+    unsigned voff_a[A_U];
+#pragma unroll
+    for (int e = 0; e < A_U; ++e) voff_a[e] = (unsigned)(m0 * ROW + (tid + e * kThreads) * 16);
+
+    f32x4 acc[TMI][TNI];
+#pragma unroll
+    for (int i = 0; i < TMI; ++i)
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int chunk_begin = bz * p.chunks_per_split;
+    const int total_chunks = (p.P + BK - 1) / BK;
+    const int chunk_end = min(chunk_begin + p.chunks_per_split, total_chunks);
+    const int cpr = p.OW / BK;                      // chunks per output row
+
+    // chunk c -> element offset of (row ih, column iw0) of image pb (may point in front of the row: masked), iw0, validity
+    int c_iw0 = 0;
+    long long c_base = 0;
+    auto decode = [&](int c) {
+        const int grow = c / cpr, ow0 = (c - grow * cpr) * BK;
+        const int pb = grow / p.OH, oh = grow - pb * p.OH;
+        const int ih = oh + t_dh;
+        c_iw0 = ow0 + t_dw;
+        c_base = (long long)pb * p.x_bs + (long long)ih * p.W + c_iw0;
+        return ih >= 0 && ih < p.H && c_iw0 + BK > 0 && c_iw0 < p.W;
+    };
+    auto next_valid = [&](int c) {
+        for (; c < chunk_end; ++c)
+            if (decode(c)) break;
+        return c;
+    };
+    // One instance of the main loop per misalignment (a generic lambda over a compile-time SH): with SH a run-time value the
+    // element selects and the third load slowed EVERY shape by 12-35 %.
+    auto run = [&](auto sh_c) {
+        constexpr int SH = decltype(sh_c)::value;
+        u32x4 ra[A_U];
+        u32x4 rbx[TNI][3];
+        int ld_iw0 = 0;                                 // iw0 of the chunk whose x values sit in rbx
+        // 16-byte loads need 16-byte aligned addresses (the hardware drops the low address bits).  Rows, channels and chunks are
+        // multiples of four elements apart (W % 4 == 0 is required by the host), so the misalignment is the tap's column shift
+        // modulo 4 - the same for every chunk of this workgroup: load from the aligned address below (three loads cover the
+        // eight elements) and pick element e + sh.
+        auto load_tiles = [&](int c) {                  // decode(c) has just run
+            const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
+    #pragma unroll
+            for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+            // a chunk that starts in front of the tensor's first row wraps to a huge offset: out of range, zeros
+            const unsigned cb = (unsigned)(c_base * 4ll);
+    #pragma unroll
+            for (int j = 0; j < TNI; ++j) {
+                const unsigned vo = vrow[j] * 4u + cb - (unsigned)(SH * 4);
+                rbx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+                rbx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 16u, 0, 0);
+                if constexpr (SH != 0) rbx[j][2] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 32u, 0, 0);
+            }
+            ld_iw0 = c_iw0;
+        };
+        auto store_a = [&](int buf) {
+    #pragma unroll
+            for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As[buf] + (tid + e * kThreads) * 16) = ra[e];
+        };
+        const unsigned fr0 = (unsigned)(l15 * ROW + ((lg ^ (l15 >> 1)) << 4)), fr1 = (unsigned)(l15 * ROW + (((4 + lg) ^ (l15 >> 1)) << 4));
+
+        int c0 = next_valid(chunk_begin);
+        int buf = 0;
+        if (c0 < chunk_end) {
+            load_tiles(c0);
+            store_a(0);
+        }
+        while (c0 < chunk_end) {
+            // x of this chunk: registers -> masked, scaled, split fragments (before the next chunk's loads reuse rbx)
+            half8 b[TNI][2];
+            {
+                const int first = ld_iw0 + lg * 8;                 // input column of this lane's element 0
+                const int lo = -first, hi = p.W - first;           // valid elements: lo <= e < hi
+    #pragma unroll
+                for (int j = 0; j < TNI; ++j) {
+                    // (through scalars: __builtin_bit_cast applied to a vector ELEMENT read element 0 for every e - hipcc 7.2)
+                    unsigned d[12];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d[e] = rbx[j][0][e];
+                        d[4 + e] = rbx[j][1][e];
+                        d[8 + e] = SH != 0 ? rbx[j][2][e] : 0u;
+                    }
+                    float v[8];
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const unsigned u = d[e + SH];
+                        v[e] = __builtin_bit_cast(float, u);
+                    }
+                    u32x4 ph, pl;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = (2 * e >= lo && 2 * e < hi) ? v[2 * e] * xs : 0.f;
+                        const float x1 = (2 * e + 1 >= lo && 2 * e + 1 < hi) ? v[2 * e + 1] * xs : 0.f;
+                        unsigned h, l;
+                        split2h(x0, x1, h, l);
+                        ph[e] = h;
+                        pl[e] = l;
+                    }
+                    b[j][0] = __builtin_bit_cast(half8, ph);
+                    b[j][1] = __builtin_bit_cast(half8, pl);
+                }
+            }
+            const int c1 = next_valid(c0 + 1);
+            if (c1 < chunk_end) load_tiles(c1);                    // in flight during this chunk's MFMAs
+            lds_barrier();                                         // As[buf] is complete; nobody still reads As[buf ^ 1]
+            const unsigned char* Ab = As[buf];
+    #pragma unroll
+            for (int i = 0; i < TMI; ++i) {
+                const half8 a0 = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr0);
+                const half8 a1 = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr1);
+    #pragma unroll
+                for (int j = 0; j < TNI; ++j) {
+                    f32x4 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+            }
+            if (c1 < chunk_end) store_a(buf ^ 1);
+            buf ^= 1;
+            c0 = c1;
+        }
+
+    };
+    switch (t_dw & 3) {
+        case 0: run(std::integral_constant<int, 0>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        default: run(std::integral_constant<int, 3>{}); break;
+    }
+
+    float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
+#pragma unroll
+    for (int i = 0; i < TMI; ++i)
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) {
+            const int n = n0 + wid * 32 + j * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + i * 16 + lg * 4 + r;
                 slab[(long long)co * p.N + n] = acc[i][j][r] * out_scale;
             }
         }
