@@ -2039,8 +2039,12 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                         for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
                         if (g_wgrad_direct && (taps_aligned || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
                             (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
-                            hipLaunchKernelGGL(conv_wgrad_split16d_kernel, grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
+                            if (taps_aligned)
+                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<true>, grid, dim3(kThreads), 0, s, p, dys,
+                                                   (unsigned)dys_bytes, dy_amax);
+                            else
+                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<false>, grid, dim3(kThreads), 0, s, p, dys,
+                                                   (unsigned)dys_bytes, dy_amax);
                         else
                             hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);

@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 // goes through LDS, now double-buffered with ONE barrier per chunk.  Per chunk and thread: 8 vector loads instead of 20,
 // 4 LDS stores instead of 20.  Elements whose input column lies outside the image are zeroed by selects (the loads
 // themselves cannot fault: buffer descriptor).
+template <bool ALIGNED>     // ALIGNED: every tap's column shift is a multiple of 4 elements (the host checked): only that loop is compiled in
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                          unsigned dys_bytes, const float* __restrict__ dy_amax) {
     constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
@@ -1233,64 +1234,74 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
     // element selects and the third load slowed EVERY shape by 12-35 %.
     auto run = [&](auto sh_c) {
         constexpr int SH = decltype(sh_c)::value;
-        u32x4 ra[A_U];
-        u32x4 rbx[TNI][3];
-        int ld_iw0 = 0;                                 // iw0 of the chunk whose x values sit in rbx
+        // Register ring of TWO chunks: the loads of chunk k + 2 are issued while chunk k is multiplied (one chunk ahead left the
+        // loop at load + MFMA time one after the other - timing-only builds: 172 + 182 us alone, 300 together on l4.conv2).
+        u32x4 ra[2][A_U];
+        u32x4 rbx[2][TNI][3];
+        int ld_iw0[2] = {0, 0};                         // iw0 of the chunk whose x values sit in rbx[slot]
         // 16-byte loads need 16-byte aligned addresses (the hardware drops the low address bits).  Rows, channels and chunks are
-        // multiples of four elements apart (W % 4 == 0 is required by the host), so the misalignment is the tap's column shift
-        // modulo 4 - the same for every chunk of this workgroup: load from the aligned address below (three loads cover the
-        // eight elements) and pick element e + sh.
-        auto load_tiles = [&](int c) {                  // decode(c) has just run
+        // multiples of four elements apart (the host checks it), so the misalignment is the tap's column shift modulo 4 - the
+        // same for every chunk of this workgroup: load from the aligned address below (three loads cover the eight elements)
+        // and pick element e + SH.
+        auto load_tiles = [&](auto slot_c, int c) {     // decode(c) has just run
+            constexpr int S = decltype(slot_c)::value;
             const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
-    #pragma unroll
-            for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+#pragma unroll
+            for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
             // a chunk that starts in front of the tensor's first row wraps to a huge offset: out of range, zeros
             const unsigned cb = (unsigned)(c_base * 4ll);
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < TNI; ++j) {
                 const unsigned vo = vrow[j] * 4u + cb - (unsigned)(SH * 4);
-                rbx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
-                rbx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 16u, 0, 0);
-                if constexpr (SH != 0) rbx[j][2] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 32u, 0, 0);
+                rbx[S][j][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0);
+                rbx[S][j][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 16u, 0, 0);
+                if constexpr (SH != 0) rbx[S][j][2] = __builtin_amdgcn_raw_buffer_load_b128(rx, vo + 32u, 0, 0);
             }
-            ld_iw0 = c_iw0;
+            ld_iw0[S] = c_iw0;
         };
-        auto store_a = [&](int buf) {
-    #pragma unroll
-            for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As[buf] + (tid + e * kThreads) * 16) = ra[e];
+        auto store_a = [&](auto slot_c, int buf) {
+            constexpr int S = decltype(slot_c)::value;
+#pragma unroll
+            for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As[buf] + (tid + e * kThreads) * 16) = ra[S][e];
         };
         const unsigned fr0 = (unsigned)(l15 * ROW + ((lg ^ (l15 >> 1)) << 4)), fr1 = (unsigned)(l15 * ROW + (((4 + lg) ^ (l15 >> 1)) << 4));
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
 
-        int c0 = next_valid(chunk_begin);
+        int c0 = next_valid(chunk_begin), c1 = chunk_end;
         int buf = 0;
         if (c0 < chunk_end) {
-            load_tiles(c0);
-            store_a(0);
+            load_tiles(S0{}, c0);
+            c1 = next_valid(c0 + 1);
+            if (c1 < chunk_end) load_tiles(S1{}, c1);
+            store_a(S0{}, 0);
         }
-        while (c0 < chunk_end) {
-            // x of this chunk: registers -> masked, scaled, split fragments (before the next chunk's loads reuse rbx)
+        // one chunk: its operands sit in slot S (dY already in As[buf]), the next chunk's in slot 1 - S
+        auto step = [&](auto slot_c) {
+            constexpr int S = decltype(slot_c)::value;
+            // x of this chunk: registers -> masked, scaled, split fragments (before the loads below reuse the slot)
             half8 b[TNI][2];
             {
-                const int first = ld_iw0 + lg * 8;                 // input column of this lane's element 0
+                const int first = ld_iw0[S] + lg * 8;              // input column of this lane's element 0
                 const int lo = -first, hi = p.W - first;           // valid elements: lo <= e < hi
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < TNI; ++j) {
                     // (through scalars: __builtin_bit_cast applied to a vector ELEMENT read element 0 for every e - hipcc 7.2)
                     unsigned d[12];
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        d[e] = rbx[j][0][e];
-                        d[4 + e] = rbx[j][1][e];
-                        d[8 + e] = SH != 0 ? rbx[j][2][e] : 0u;
+                        d[e] = rbx[S][j][0][e];
+                        d[4 + e] = rbx[S][j][1][e];
+                        d[8 + e] = SH != 0 ? rbx[S][j][2][e] : 0u;
                     }
                     float v[8];
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const unsigned u = d[e + SH];
                         v[e] = __builtin_bit_cast(float, u);
                     }
                     u32x4 ph, pl;
-    #pragma unroll
+#pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x0 = (2 * e >= lo && 2 * e < hi) ? v[2 * e] * xs : 0.f;
                         const float x1 = (2 * e + 1 >= lo && 2 * e + 1 < hi) ? v[2 * e + 1] * xs : 0.f;
@@ -1303,34 +1314,52 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
                     b[j][1] = __builtin_bit_cast(half8, pl);
                 }
             }
-            const int c1 = next_valid(c0 + 1);
-            if (c1 < chunk_end) load_tiles(c1);                    // in flight during this chunk's MFMAs
+            int c2 = chunk_end;
+            if (c1 < chunk_end) c2 = next_valid(c1 + 1);
+#ifndef WSDL_EXP_D_NOLOAD            // timing-only build: operands loaded once, the loop is convert + barrier + LDS reads + MFMA
+            if (c2 < chunk_end) load_tiles(slot_c, c2);            // slot S is free: x converted, dY stored one step ago
+#endif
             lds_barrier();                                         // As[buf] is complete; nobody still reads As[buf ^ 1]
             const unsigned char* Ab = As[buf];
-    #pragma unroll
+#pragma unroll
             for (int i = 0; i < TMI; ++i) {
                 const half8 a0 = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr0);
                 const half8 a1 = *reinterpret_cast<const half8*>(Ab + i * 16 * ROW + fr1);
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < TNI; ++j) {
                     f32x4 c = acc[i][j];
+#ifdef WSDL_EXP_D_NOMFMA             // timing-only build: everything but the matrix work
+                    c[0] += (float)a0[0] + (float)a1[1] + (float)b[j][0][2] + (float)b[j][1][3];
+#else
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b[j][0], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[j][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b[j][0], c, 0, 0, 0);
+#endif
                     acc[i][j] = c;
                 }
             }
-            if (c1 < chunk_end) store_a(buf ^ 1);
+#ifndef WSDL_EXP_D_NOLOAD
+            if (c1 < chunk_end) store_a(std::integral_constant<int, 1 - S>{}, buf ^ 1);
             buf ^= 1;
+#endif
             c0 = c1;
+            c1 = c2;
+        };
+        while (c0 < chunk_end) {
+            step(S0{});
+            if (c0 >= chunk_end) break;
+            step(S1{});
         }
-
     };
-    switch (t_dw & 3) {
-        case 0: run(std::integral_constant<int, 0>{}); break;
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        default: run(std::integral_constant<int, 3>{}); break;
+    if constexpr (ALIGNED) {
+        run(std::integral_constant<int, 0>{});
+    } else {
+        switch (t_dw & 3) {
+            case 0: run(std::integral_constant<int, 0>{}); break;
+            case 1: run(std::integral_constant<int, 1>{}); break;
+            case 2: run(std::integral_constant<int, 2>{}); break;
+            default: run(std::integral_constant<int, 3>{}); break;
+        }
     }
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
