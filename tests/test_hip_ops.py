@@ -922,7 +922,9 @@ def test_prep_weights_multi_equals_the_single_launches(dev):
     ws = [(torch.randn(s, generator=g) * (0.5 + i)).to(dev) for i, s in enumerate(shapes)]
     assert all(ops._both_split(w) for w in ws) and not ops._both_split(torch.empty(64, 3, 7, 7)) and not ops._both_split(torch.empty(2, 256, 1, 1))
     amax = ops.multi_amax(ws)
-    single = [ops.prep_weights(w, True, True, amax[i:i + 1]) for i, w in enumerate(ws)]
+    sized = [ops.prep_weights(w, True, True, amax[i:i + 1]) for i, w in enumerate(ws)]      # (the buffers have unwritten padding:
+    single = [ops.prep_weights(w, True, True, amax[i:i + 1], reuse=(torch.zeros_like(f), torch.zeros_like(d)))   # start both from zeros)
+              for i, (w, (f, d)) in enumerate(zip(ws, sized))]
     multi = [(torch.zeros_like(f), torch.zeros_like(d)) for f, d in single]
     ops.prep_weights_multi([(w, f, d, amax[i:i + 1]) for i, (w, (f, d)) in enumerate(zip(ws, multi))])
     for (f1, d1), (f2, d2), s in zip(single, multi, shapes):
@@ -931,7 +933,8 @@ def test_prep_weights_multi_equals_the_single_launches(dev):
     for w in ws:
         w.mul_(1.5)
     amax2 = ops.multi_amax(ws)
-    single2 = [ops.prep_weights(w, True, True, amax2[i:i + 1]) for i, w in enumerate(ws)]
+    single2 = [ops.prep_weights(w, True, True, amax2[i:i + 1], reuse=(torch.zeros_like(f), torch.zeros_like(d)))
+               for i, (w, (f, d)) in enumerate(zip(ws, sized))]
     amax.copy_(amax2)
     ops.prep_weights_multi([(w, f, d, amax[i:i + 1]) for i, (w, (f, d)) in enumerate(zip(ws, multi))])
     for (f1, d1), (f2, d2) in zip(single2, multi):
@@ -986,10 +989,12 @@ def test_wgrad_direct_fragments_equal_the_lds_staged_kernel(dev, case):
     F.conv2d(x, wr, None, 1, pad, dil).backward(dy)
     outs = []
     try:
-        for on in (2, 0):           # 2: the direct kernel also where taps are misaligned (dilation 1, 2: a third load per tile)
+        # 2: the direct kernel for every tap alignment (a third 16-byte load per tile where misaligned); 1 (default): 16-byte loads
+        # where all taps are aligned, 8-byte loads for dilation 2, the LDS-staged kernel for dilation 1; 0: LDS-staged everywhere
+        for on in (2, 1, 0):
             ops.set_option("wgrad_direct", on)
             outs.append(ops.conv2d_wgrad(x.to(dev), dy.to(dev), wr.shape, 1, pad, dil))
     finally:
         ops.set_option("wgrad_direct", 1)
-    assert torch.equal(outs[0], outs[1]), (case, rel_err(outs[0], outs[1]))
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (case, rel_err(outs[0], outs[2]), rel_err(outs[1], outs[2]))
     assert_close(outs[0], wr.grad, what=f"wgrad {case}")

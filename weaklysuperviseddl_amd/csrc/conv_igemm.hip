@@ -2035,15 +2035,22 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                         // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
                         // with a third load for misaligned taps (dilation 1, 2) it is 0-7 % slower than the LDS-staged kernel
                         // (wgrad_direct = 2 forces it for those too)
-                        bool taps_aligned = true;
-                        for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
-                        if (g_wgrad_direct && (taps_aligned || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
+                        bool taps_aligned = true, taps_even = true;
+                        for (int kx = 0; kx < kw; ++kx) {
+                            taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
+                            taps_even = taps_even && (((kx * dil - pad) & 1) == 0);
+                        }
+                        // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
+                        // kernel on l3.conv2: the third load's registers spill; not used)
+                        const bool direct8 = false;
+                        (void)taps_even;
+                        if (g_wgrad_direct && (taps_aligned || direct8 || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
                             (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
                             if (taps_aligned)
-                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<true>, grid, dim3(kThreads), 0, s, p, dys,
+                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
                             else
-                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<false>, grid, dim3(kThreads), 0, s, p, dys,
+                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<3>, grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
                         else
                             hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,

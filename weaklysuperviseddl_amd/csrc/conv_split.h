@@ -1159,7 +1159,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 // goes through LDS, now double-buffered with ONE barrier per chunk.  Per chunk and thread: 8 vector loads instead of 20,
 // 4 LDS stores instead of 20.  Elements whose input column lies outside the image are zeroed by selects (the loads
 // themselves cannot fault: buffer descriptor).
-template <bool ALIGNED>     // ALIGNED: every tap's column shift is a multiple of 4 elements (the host checked): only that loop is compiled in
+// MODE (checked by the host): 0 - every tap's column shift is a multiple of 4 elements, only the aligned loop is compiled in (237
+// registers); 3 - any shift (four loops: 256 registers and spills - the A/B partner of the LDS-staged kernel for dilation 1 and
+// 2, not the default anywhere; a two-loop form for dilation 2 spilled as well: 128 us against 112 on l3.conv2).
+template <int MODE>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                          unsigned dys_bytes, const float* __restrict__ dy_amax) {
     constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
@@ -1351,7 +1354,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
             step(S1{});
         }
     };
-    if constexpr (ALIGNED) {
+    if constexpr (MODE == 0) {
         run(std::integral_constant<int, 0>{});
     } else {
         switch (t_dw & 3) {
