@@ -1014,8 +1014,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 #pragma unroll
         for (int j = 0; j < TNI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[A_U];
-    unsigned rb[B_PER];
+    // register ring of TWO chunks (round 3: the loads of chunk k + 2 are issued while chunk k is multiplied - one chunk ahead
+    // left load time exposed, see conv_wgrad_split16d_kernel)
+    u32x4 ra[2][A_U];
+    unsigned rb[2][B_PER];
     const int chunk_begin = zsplit * w_cps;
     const int total_chunks = (W_P + BK - 1) / BK;
     const int chunk_end = min(chunk_begin + w_cps, total_chunks);
@@ -1049,28 +1051,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         }
         return c;
     };
-    auto load_tiles = [&](int c) {
+    auto load_tiles = [&](auto slot_c, int c) {      // decode(c) has just run (nvb)
+        constexpr int S = decltype(slot_c)::value;
         const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+        for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
 #pragma unroll
         for (int e = 0; e < B_PER; ++e)
-            rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
+            rb[S][e] = __builtin_amdgcn_raw_buffer_load_b32(rx, nvb, (unsigned)(((e & 1) + 16 * (e >> 1)) * HW) * 4u, 0);
     };
     const bool even = (px & 1) == 0;
     const int pair = px >> 1;
     // narrow form: rows 2 hw + (odd lane) + 16 i share (row >> 1) & 7 = hw & 7
     const unsigned st_row = (unsigned)((2 * hw + (even ? 0 : 1)) * ROW + (pair & 3) * 4);
     const unsigned st_u0 = (unsigned)((((pair >> 2)) ^ (hw & 7)) << 4), st_u1 = (unsigned)(((4 + (pair >> 2)) ^ (hw & 7)) << 4);
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[e];
+        for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As + (tid + e * kThreads) * 16) = ra[S][e];
 #pragma unroll
         for (int i = 0; i < B_PER / 2; ++i) {
-            const unsigned give = even ? rb[2 * i + 1] : rb[2 * i];
+            const unsigned give = even ? rb[S][2 * i + 1] : rb[S][2 * i];
             const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)give, 0xB1, 0xF, 0xF, true);
-            const unsigned x0 = even ? rb[2 * i] : recv;
-            const unsigned x1 = even ? recv : rb[2 * i + 1];
+            const unsigned x0 = even ? rb[S][2 * i] : recv;
+            const unsigned x1 = even ? recv : rb[S][2 * i + 1];
             unsigned ph, pl;
 #ifdef WSDL_EXP_W_NOSPLIT        // timing-only build: x as if it arrived pre-split
             ph = x0;
@@ -1089,18 +1093,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     const unsigned char* Ab = As + wm * (BM / 2) * ROW;
     const unsigned char* Bb = Bs + wn * (BN / 2) * ROW;
     if (t_dh >= p.H || (p.OH - 1) * p.stride + t_dh < 0 || t_dw >= p.W || (p.OW - 1) * p.stride + t_dw < 0) return;
-    int c0 = next_valid(chunk_begin);
-    if (c0 < chunk_end) load_tiles(c0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    int c0 = next_valid(chunk_begin), c1 = chunk_end;
+    if (c0 < chunk_end) {
+        load_tiles(S0{}, c0);
+        c1 = next_valid(c0 + 1);
+        if (c1 < chunk_end) load_tiles(S1{}, c1);
+    }
 #ifdef WSDL_EXP_W_NOSTAGE            // timing-only build: the LDS image filled once (real data), the loop is barrier + ds_read + MFMA
-    if (c0 < chunk_end) store_tiles();
+    if (c0 < chunk_end) store_tiles(S0{});
 #endif
-    while (c0 < chunk_end) {
+    // one chunk: its operands sit in register slot S, the next chunk's in slot 1 - S
+    auto step = [&](auto slot_c) {
+        int c2 = chunk_end;
 #ifndef WSDL_EXP_W_NOSTAGE
-        store_tiles();
-        const int c1 = next_valid(c0 + 1);
-        if (c1 < chunk_end) load_tiles(c1);
+        store_tiles(slot_c);
+        if (c1 < chunk_end) c2 = next_valid(c1 + 1);
+        if (c2 < chunk_end) load_tiles(slot_c, c2);            // the slot is free again; in flight during two chunks' MFMAs
 #else
-        const int c1 = c0 + 1;
+        if (c1 < chunk_end) c2 = c1 + 1;
 #endif
         lds_barrier();
         half8 a[TMI][2], b[TNI][2];
@@ -1133,6 +1145,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 #endif
         lds_barrier();
         c0 = c1;
+        c1 = c2;
+    };
+    while (c0 < chunk_end) {
+        step(S0{});
+        if (c0 >= chunk_end) break;
+        step(S1{});
     }
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
