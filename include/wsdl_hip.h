@@ -74,6 +74,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      lane exchange for x; dY double-buffered in LDS, one barrier per chunk) where OW % 32 == 0, stride 1 and every
  *                      tap's column shift is a multiple of 4 elements (1x1, dilation 4 / 12 / 24 / 36): 7-10 % faster there, bit-identical;
  *                      2 = also for misaligned taps (a third 16-byte load per tile: 0-7 % slower), 0 = the LDS-staged kernel everywhere
+ *   wgrad_dyraw    1*  the direct-fragment kernel reads dY as fp32 and splits it while staging (no dy_split16 pre-pass) for 1x1 convolutions
+ *                      with at most 10 N tiles (7-11 % faster there); 2 = for every launch of that kernel (3x3: 7-21 % slower), 0 = never
  *   stem_kernel    1*  7x7 stride-2 convolution of 3 -> 64 channels (ResNet's conv1) on its own kernel: input patch and all weights
  *                      in LDS, fp32 MFMA (0: the generic fp32 implicit-GEMM kernel, the A/B partner)
  *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,

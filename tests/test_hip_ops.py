@@ -973,7 +973,7 @@ def test_concat_into_with_producers_writing_in_place(dev):
 
 @pytest.mark.parametrize("case", [(2, 128, 32, 32, 128, 3, 1, 1), (2, 128, 32, 32, 256, 3, 2, 2), (1, 256, 32, 32, 128, 3, 4, 4),
                                   (2, 128, 32, 32, 128, 3, 12, 12), (2, 256, 32, 32, 128, 1, 0, 1), (1, 128, 16, 64, 128, 3, 1, 1),
-                                  (3, 128, 8, 96, 128, 3, 36, 36)])
+                                  (3, 128, 8, 96, 128, 3, 36, 36), (2, 1024, 32, 32, 256, 1, 0, 1)])
 def test_wgrad_direct_fragments_equal_the_lds_staged_kernel(dev, case):
     """conv_wgrad_split16d_kernel (x fragments straight from global memory, masked at the image's left / right edge) against the
     LDS-staged kernel it replaces where OW % 32 == 0 and stride = 1: the same products in the same order - bit for bit - and
@@ -997,4 +997,13 @@ def test_wgrad_direct_fragments_equal_the_lds_staged_kernel(dev, case):
     finally:
         ops.set_option("wgrad_direct", 1)
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), (case, rel_err(outs[0], outs[2]), rel_err(outs[1], outs[2]))
+    # dY read as fp32 and split while staged (default for 1x1 convolutions of few N tiles: the last case; 2 = every aligned launch)
+    try:
+        ops.set_option("wgrad_dyraw", 2)
+        raw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), wr.shape, 1, pad, dil)
+        ops.set_option("wgrad_dyraw", 0)
+        pre = ops.conv2d_wgrad(x.to(dev), dy.to(dev), wr.shape, 1, pad, dil)
+    finally:
+        ops.set_option("wgrad_dyraw", 1)
+    assert torch.equal(raw, pre) and torch.equal(raw, outs[2]), case
     assert_close(outs[0], wr.grad, what=f"wgrad {case}")

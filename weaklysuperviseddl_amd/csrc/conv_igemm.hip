@@ -1621,6 +1621,7 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
+int g_wgrad_dyraw = 1;       // direct-fragment kernel: dY read as fp32 and split while staged (no dy_split16_kernel pass)
 int g_wgrad_direct = 1;      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
 int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
 int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
@@ -1734,6 +1735,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_direct")) { g_wgrad_direct = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_dyraw")) { g_wgrad_dyraw = value; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
@@ -2029,8 +2031,6 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
                     if (g_wgrad_mfma16) {
-                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
-                        WSDL_LAUNCH_CHECK();
                         // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
                         // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
                         // with a third load for misaligned taps (dilation 1, 2) it is 0-7 % slower than the LDS-staged kernel
@@ -2045,16 +2045,32 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                         const bool direct8 = false;
                         (void)taps_even;
                         if (g_wgrad_direct && (taps_aligned || direct8 || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
-                            (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0)
-                            if (taps_aligned)
+                            (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
+                            // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
+                            // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
+                            // workgroup splits its slice again; 7-11 % faster there, 7-21 % slower on the 3x3 shapes with 36-72 N tiles)
+                            const bool dyraw = taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
+                                               (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
+                                               reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
+                            if (!dyraw) {
+                                hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                                WSDL_LAUNCH_CHECK();
+                            }
+                            if (dyraw)
+                                hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                                   (unsigned)dys_bytes, dy_amax);
+                            else if (taps_aligned)
                                 hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
                             else
                                 hipLaunchKernelGGL(conv_wgrad_split16d_kernel<3>, grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
-                        else
+                        } else {
+                            hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                            WSDL_LAUNCH_CHECK();
                             hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
+                        }
                     } else {
                         hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();

@@ -1180,7 +1180,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 // MODE (checked by the host): 0 - every tap's column shift is a multiple of 4 elements, only the aligned loop is compiled in (237
 // registers); 3 - any shift (four loops: 256 registers and spills - the A/B partner of the LDS-staged kernel for dilation 1 and
 // 2, not the default anywhere; a two-loop form for dilation 2 spilled as well: 128 us against 112 on l3.conv2).
-template <int MODE>
+// DYRAW: dY is read as fp32 from the tensor itself (p.dy) and split by the staging threads on its way into LDS - no
+// dy_split16_kernel pre-pass for the launch (it re-reads and re-writes dY once per layer; here every N tile's workgroup
+// splits its 128 x 32 slice again: 8 splits per thread and chunk).
+template <int MODE, bool DYRAW = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                          unsigned dys_bytes, const float* __restrict__ dy_amax) {
     constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
@@ -1208,8 +1211,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     int ex, ed;
     const float xs = pow2_scale(*p.x_amax, ex);
-    (void)pow2_scale(*dy_amax, ed);
+    const float ds = pow2_scale(*dy_amax, ed);
     const float out_scale = pow2(-(ex + ed));
+    // DYRAW: eight lanes per row of dY (16 bytes = 4 pixels each), rows t / 8 + 32 e: full 128-byte lines per load instruction
+    const __amdgpu_buffer_rsrc_t rdr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    const int OHOW_ = p.OH * p.OW;
+    const int dr_row = tid >> 3, dr_q = tid & 7;                   // row within a group of 32, 4-pixel group of the chunk
 
     const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
     const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
@@ -1237,13 +1245,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
 
     // chunk c -> element offset of (row ih, column iw0) of image pb (may point in front of the row: masked), iw0, validity
     int c_iw0 = 0;
-    long long c_base = 0;
+    long long c_base = 0, c_dy = 0;
     auto decode = [&](int c) {
         const int grow = c / cpr, ow0 = (c - grow * cpr) * BK;
         const int pb = grow / p.OH, oh = grow - pb * p.OH;
         const int ih = oh + t_dh;
         c_iw0 = ow0 + t_dw;
         c_base = (long long)pb * p.x_bs + (long long)ih * p.W + c_iw0;
+        c_dy = (long long)pb * p.dy_bs + (long long)oh * p.OW + ow0;       // element offset of the chunk's first pixel in channel 0
         return ih >= 0 && ih < p.H && c_iw0 + BK > 0 && c_iw0 < p.W;
     };
     auto next_valid = [&](int c) {
@@ -1266,9 +1275,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
         // and pick element e + SH.
         auto load_tiles = [&](auto slot_c, int c) {     // decode(c) has just run
             constexpr int S = decltype(slot_c)::value;
-            const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
+            if constexpr (DYRAW) {
+                const unsigned db = (unsigned)((c_dy + (long long)(m0 + dr_row) * OHOW_ + dr_q * 4) * 4ll);
 #pragma unroll
-            for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+                for (int e = 0; e < A_U; ++e)
+                    ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rdr, db + (unsigned)(e * 32 * OHOW_) * 4u, 0, 0);
+            } else {
+                const unsigned soff_a = (unsigned)c * (unsigned)(p.Cout * ROW);
+#pragma unroll
+                for (int e = 0; e < A_U; ++e) ra[S][e] = __builtin_amdgcn_raw_buffer_load_b128(rdy, voff_a[e], soff_a, 0);
+            }
             // a chunk that starts in front of the tensor's first row wraps to a huge offset: out of range, zeros
             const unsigned cb = (unsigned)(c_base * 4ll);
 #pragma unroll
@@ -1282,8 +1298,24 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
         };
         auto store_a = [&](auto slot_c, int buf) {
             constexpr int S = decltype(slot_c)::value;
+            if constexpr (DYRAW) {
+                // row r = dr_row + 32 e, pixels 4 dr_q .. + 3: unit dr_q / 2 of piece h (and 4 + that of piece l), its half dr_q & 1
 #pragma unroll
-            for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As[buf] + (tid + e * kThreads) * 16) = ra[S][e];
+                for (int e = 0; e < A_U; ++e) {
+                    const int r = dr_row + 32 * e;
+                    const unsigned u0 = ra[S][e][0], u1 = ra[S][e][1], u2 = ra[S][e][2], u3 = ra[S][e][3];
+                    unsigned h0, l0, h1, l1;
+                    split2h(__builtin_bit_cast(float, u0) * ds, __builtin_bit_cast(float, u1) * ds, h0, l0);
+                    split2h(__builtin_bit_cast(float, u2) * ds, __builtin_bit_cast(float, u3) * ds, h1, l1);
+                    const unsigned sw = (unsigned)((r >> 1) & 7);
+                    unsigned char* row = As[buf] + r * ROW + (dr_q & 1) * 8;
+                    *reinterpret_cast<u32x2*>(row + ((((unsigned)(dr_q >> 1)) ^ sw) << 4)) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(row + (((4u + (unsigned)(dr_q >> 1)) ^ sw) << 4)) = u32x2{l0, l1};
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < A_U; ++e) *reinterpret_cast<u32x4*>(As[buf] + (tid + e * kThreads) * 16) = ra[S][e];
+            }
         };
         const unsigned fr0 = (unsigned)(l15 * ROW + ((lg ^ (l15 >> 1)) << 4)), fr1 = (unsigned)(l15 * ROW + (((4 + lg) ^ (l15 >> 1)) << 4));
         using S0 = std::integral_constant<int, 0>;
