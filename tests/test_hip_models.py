@@ -613,6 +613,22 @@ def test_identity_link_is_taken_and_changes_nothing(dev, monkeypatch):
     assert n0 == 0 and n1 == 2, (n0, n1)         # blocks 1 and 2 (the last block's dy comes from torch's mul: not owned)
     assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
 
+    # gradient accumulation (two forward / backward passes without zeroing) and a second backward through a retained graph
+    def accumulate(link_on):
+        monkeypatch.setattr(ops, "IDENTITY_LINK", [link_on])
+        torch.manual_seed(0)
+        blocks = torch.nn.Sequential(*[wnn.Bottleneck(256, 64) for _ in range(3)]).to(dev).train()
+        x = torch.randn(4, 256, 16, 16, generator=torch.Generator().manual_seed(1)).to(dev).requires_grad_()
+        for k in range(2):
+            y = blocks(x * (1.0 + 0.5 * k))
+            y.square().mean().backward(retain_graph=(k == 1))
+        y.square().mean().backward()                       # the retained graph of the second pass once more
+        return x.grad.clone(), [p.grad.clone() for p in blocks.parameters()]
+
+    ax1, ag1 = accumulate(True)
+    ax0, ag0 = accumulate(False)
+    assert torch.equal(ax1, ax0) and all(torch.equal(a, b) for a, b in zip(ag1, ag0))
+
 
 def test_projection_shortcut_link_changes_nothing(dev, monkeypatch):
     """Blocks with a projection shortcut (conv + BatchNorm): the last node hands the shortcut node the block output's dy itself
