@@ -394,7 +394,7 @@ def prep_weights_multi(entries, lookup_only=False):
             blocks += d.grid_x * ((Cout + 31) // 32)
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(entries[0][0].device)
         ent = _prep_tables[key] = (table, len(entries), blocks)
-        if len(_prep_tables) > 16:
+        if len(_prep_tables) > 64:
             _prep_tables.pop(next(iter(_prep_tables)))
     check(lib().wsdl_conv2d_prep_weights_multi(_p(ent[0]), ent[1], ent[2], _stream()))
 
