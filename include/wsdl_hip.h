@@ -80,6 +80,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      in LDS, fp32 MFMA (0: the generic fp32 implicit-GEMM kernel, the A/B partner)
  *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,
  *                      most K slices, fewest 32-deep chunks per slice
+ *   layercam_tail_mod 32*  LayerCAM epilogue: the last hw % n pixels of a map are summed over the channels the way ATen's CPU sum
+ *                      handles its scalar columns (four interleaved streams), all others by its four-level cascade - the epilogue
+ *                      is bit-identical to the reference's torch-CPU arithmetic on identical inputs.  32 = torch built for AVX-512
+ *                      (the fixtures, the GPU boxes' hosts), 16 = an AVX2 torch, 0 = the cascade for every pixel
  * (Options measured slower and removed in round 3: conv_glds - weights by LDS-DMA; wgrad_wide - 8-pixel-run staging of x;
  *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.)
  * (* = default). */
@@ -341,7 +345,10 @@ int wsdl_compute_affinities(const float* image, float* out, int B, int H, int W,
 /* ---- LayerCAM epilogue (TraditionalModel/LayerCAM.py:52-76; variant 1 = notebook arithmetic,
  * AlternatingDirectionCutLoss.py:261-284) + threshold of PsuedoMasks.py:59-62 ------------------
  * act[l], grad[l]: (B,C[l],h[l],w[l]) device pointers, given as HOST arrays of n_layers entries.
- * cam: (B,outH,outW).  mask (optional, thresh >= 0): uint8 (cam >= thresh && cam > 0). */
+ * cam: (B,outH,outW).  mask (optional, thresh >= 0): uint8 (cam >= thresh && cam > 0).
+ * Every operation and the ORDER of the channel sum follow the reference's PyTorch-CPU path (ATen cascade_sum; bilinear
+ * weights and blends as UpSampleKernel.cpp evaluates them): on identical act / grad the CAM and the mask are bit-identical
+ * to the reference's for alpha in {1, 0.5, 2, 3} (csrc/layercam_optim.hip; option layercam_tail_mod). */
 size_t wsdl_layercam_workspace(int n_layers, int B, const int* C, const int* h, const int* w);
 int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, const int* C,
                            const int* h, const int* w, int n_layers, int B, int outH, int outW,

@@ -14,6 +14,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Parity COUNTS (how many mask pixels / CAM values differ from the reference's output) are part of the record: tests append
+# lines with report_line(), the summary prints them after the dots whether or not output is captured.
+_REPORT = []
+
+
+def report_line(text):
+    _REPORT.append(str(text))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _REPORT:
+        terminalreporter.write_line("parity counts:")
+        for line in _REPORT:
+            terminalreporter.write_line("  " + line)
+
+
+class cpu_threads:
+    """torch-CPU results are not independent of the thread count: ATen's `sum(dim=1)` hands the LAST thread's columns to a
+    different kernel when that thread gets fewer than 32 of them (e.g. 16 threads on a 14 x 14 map; tests/test_oracle_golden.py
+    ::test_channel_sum_order...).  Bit-exact comparisons against a live oracle run pin the count the fixtures were made with."""
+
+    def __init__(self, n=4):
+        self.n = n
+
+    def __enter__(self):
+        import torch
+        self.old = torch.get_num_threads()
+        torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        import torch
+        torch.set_num_threads(self.old)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

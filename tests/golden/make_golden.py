@@ -165,6 +165,31 @@ def gen_layercam():
     print("classic_cam.npz", len(co))
 
 
+def gen_layercam_wide():
+    """Channel counts that exercise every level of torch's cascade summation (300 = 256 + 2 x 16 + 12 left over, 600 = 2 x 256 +
+    5 x 16 + 8) on 14 x 14 maps (192 vectorised pixels + 4 scalar-column pixels): the reference's own bodies pin the ORDER
+    of the channel sum the HIP epilogue reproduces bit for bit."""
+    mod = lift(f"{REF}/LayerCAM.py", {"LayerCAMGenerator"})["LayerCAMGenerator"]
+    nb = lift(f"{REF}/AlternatingDirectionCutLoss.py", {"LayerCAMGenerator"})["LayerCAMGenerator"]
+    torch.manual_seed(17)
+    net = ToyCAMNet(c3=300, c4=600)
+    g = torch.Generator().manual_seed(18)
+    img = torch.rand(3, 112, 112, generator=g)
+    ci = torch.tensor([3])
+    out = {}
+    gen = mod(net, ["layer3", "layer4"])
+    out["modular_cam_a1.0"] = gen.generate(img, 1.0, class_idx=ci).numpy()
+    for n in ("layer3", "layer4"):
+        out[f"act_{n}"] = gen.activations[n].detach().numpy()
+        out[f"grad_{n}"] = gen.gradients[n].detach().numpy()
+    out["modular_cam_a3.0"] = gen.generate(img, 3.0, class_idx=ci).numpy()
+    gen = nb(net, ["layer3", "layer4"])
+    out["notebook_cam_a0.5"] = gen.generate(img, class_idx=ci, alpha=0.5).numpy()
+    assert np.array_equal(gen.activations["layer4"].detach().numpy(), out["act_layer4"])
+    np.savez_compressed(f"{HERE}/layercam_wide.npz", **out)
+    print("layercam_wide.npz", len(out))
+
+
 def gen_refine_and_metrics():
     ns = lift(f"{REF}/AlternatingDirectionCutLoss.py", {"LocalNormalizedCutLoss", "refine_pseudo_mask"})
     met = lift(f"{REF}/ExtraUtilities.py", {"compute_iou_and_acc"})["compute_iou_and_acc"]
@@ -383,7 +408,7 @@ def gen_keep_largest():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gens = dict(losses=gen_losses, layercam=gen_layercam, refine=gen_refine_and_metrics, lovasz=gen_lovasz,
+    gens = dict(losses=gen_losses, layercam=gen_layercam, layercam_wide=gen_layercam_wide, refine=gen_refine_and_metrics, lovasz=gen_lovasz,
                 bottleneck=gen_bottleneck, eval_helpers=gen_eval_helpers, keep_largest=gen_keep_largest)
     for name in (sys.argv[1:] or list(gens)):        # python make_golden.py [losses layercam ...]: only those
         gens[name]()

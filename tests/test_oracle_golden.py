@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 import oracle
 
@@ -66,16 +67,81 @@ def test_boundary_loss_and_grad(golden):
 
 
 def test_layercam_epilogue_both_variants(golden):
+    """The epilogue is where an INTEGER output (the pseudo mask) is decided: the oracle equals the reference's bodies bit
+    for bit on identical activations / gradients (same torch ops in the same order), not merely within a tolerance."""
     g = golden("layercam")
     for i in range(2):
         acts = [T(g[f"act_layer3_{i}"]), T(g[f"act_layer4_{i}"])]
         grads = [T(g[f"grad_layer3_{i}"]), T(g[f"grad_layer4_{i}"])]
         for a in (0.5, 1.0, 2.0):
-            _close(oracle.layercam_epilogue(acts, grads, (224, 224), a, "modular"), g[f"modular_cam_{i}_a{a}"],
-                   rel=1e-5)
+            assert torch.equal(oracle.layercam_epilogue(acts, grads, (224, 224), a, "modular"), T(g[f"modular_cam_{i}_a{a}"]))
         for a in (0.5, 2.0):
-            _close(oracle.layercam_epilogue(acts, grads, (224, 224), a, "notebook"), g[f"notebook_cam_{i}_a{a}"],
-                   rel=1e-5)
+            assert torch.equal(oracle.layercam_epilogue(acts, grads, (224, 224), a, "notebook"), T(g[f"notebook_cam_{i}_a{a}"]))
+    g = golden("layercam_wide")        # 300 / 600 channels: every level of torch's cascade summation
+    acts, grads = [T(g["act_layer3"]), T(g["act_layer4"])], [T(g["grad_layer3"]), T(g["grad_layer4"])]
+    assert torch.equal(oracle.layercam_epilogue(acts, grads, (224, 224), 1.0, "modular"), T(g["modular_cam_a1.0"]))
+    assert torch.equal(oracle.layercam_epilogue(acts, grads, (224, 224), 3.0, "modular"), T(g["modular_cam_a3.0"]))
+    assert torch.equal(oracle.layercam_epilogue(acts, grads, (224, 224), 0.5, "notebook"), T(g["notebook_cam_a0.5"]))
+
+
+def _cascade_rows(x):
+    """ATen SumKernel.cpp multi_row_sum over axis 0 of x (n, P): four levels, level step 16 (n <= 2^19)."""
+    import numpy as np
+    f32 = np.float32
+    acc = [np.zeros(x.shape[1], f32) for _ in range(4)]
+    i, n = 0, x.shape[0]
+    while i + 16 <= n:
+        for _ in range(16):
+            acc[0] = acc[0] + x[i]
+            i += 1
+        for j in range(1, 4):
+            acc[j] = acc[j] + acc[j - 1]
+            acc[j - 1] = np.zeros_like(acc[0])
+            if i & (15 << (4 * j)):
+                break
+    while i < n:
+        acc[0] = acc[0] + x[i]
+        i += 1
+    for j in range(1, 4):
+        acc[0] = acc[0] + acc[j]
+    return acc[0]
+
+
+def test_channel_sum_order_the_hip_epilogue_reproduces():
+    """csrc/layercam_optim.hip states torch-CPU's order of `relu(g * a).sum(dim=1)` on a contiguous NCHW tensor: the
+    four-level cascade for pixels below hw - hw % 32, four interleaved streams for the rest.  This is that statement in
+    numpy, checked against the torch of this machine - if a torch release changes the order, this test says so before
+    the GPU tests do.  The reference's OWN result depends on the host's thread count: when the last thread of ATen's
+    column split is left with fewer than 32 columns (16 or 64 threads on a 14 x 14 map) those go through the cascade too
+    (`layercam_tail_mod = 0` in the library); 1-12, 24 and 32 threads give the order of the fixtures (the default)."""
+    import numpy as np
+    from conftest import cpu_threads
+
+    def expected(X, tail_mod):
+        C, hw = X.shape
+        out = _cascade_rows(X)
+        for p in range(hw - hw % tail_mod if tail_mod else hw, hw):
+            n = C // 4
+            ps = _cascade_rows(X[:4 * n, p].reshape(n, 4))
+            for c in range(4 * n, C):
+                ps[0] = ps[0] + X[c, p]
+            out[p] = ((ps[0] + ps[1]) + ps[2]) + ps[3]
+        return out
+
+    g = torch.Generator().manual_seed(3)
+    for threads in (1, 4, 8):
+        with cpu_threads(threads):
+            for C, hw in ((1024, 196), (2048, 196), (300, 196), (37, 169), (600, 81), (4097, 25), (64, 784), (18, 100), (530, 121)):
+                for B in (1, 2):
+                    w = F.relu(torch.randn(B, C, hw, 1, generator=g) * torch.randn(B, C, hw, 1, generator=g))
+                    ref = w.sum(dim=1).numpy().reshape(B, hw)
+                    for b in range(B):
+                        mine = expected(w[b].numpy().reshape(C, hw), 32)
+                        assert np.array_equal(mine, ref[b]), (threads, C, hw, B, b, int((mine != ref[b]).sum()))
+    with cpu_threads(16):       # the GPU boxes' host: 16 threads
+        for C in (1024, 2048):
+            w = F.relu(torch.randn(1, C, 14, 14, generator=g) * torch.randn(1, C, 14, 14, generator=g))
+            assert np.array_equal(expected(w[0].numpy().reshape(C, 196), 0), w.sum(dim=1).numpy().reshape(196))
 
 
 class _Toy(nn.Module):

@@ -55,6 +55,7 @@ struct ProfScope {
 // A/B switch (wsdl_set_option "bn_resident"): channel-resident fused BatchNorm kernels (norm_pool.hip)
 extern int g_bn_resident;
 extern int g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
+extern int g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
 
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
 constexpr int kReduceSlots = 4096;

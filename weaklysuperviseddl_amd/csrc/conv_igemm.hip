@@ -1281,7 +1281,16 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    if (g_conv_arith) {
+    if (g_conv_arith == 2) {
+        if constexpr (BK == 32) {
+            if (g_conv_mfma16) {
+                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2, true>), grid, dim3(kThreads), 0, s, p);
+                WSDL_LAUNCH_CHECK();
+                return WSDL_OK;
+            }
+        }
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2>), grid, dim3(kThreads), 0, s, p);
+    } else if (g_conv_arith) {
         if constexpr (BK == 32) {
             if (g_conv_mfma16) {
                 hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
@@ -1307,7 +1316,11 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     // bit 0: forward launches (p.bh > 0), bit 1: input-gradient launches (tap step negated)
     const bool bk32 = (g_t256_bk32 & (p.bh < 0 ? 2 : 1)) && p.Cin % 32 == 0;
-    if (g_conv_arith) {
+    if (g_conv_arith == 2) {
+        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 2, true>), grid, dim3(512), 0, s, p);
+        else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2>), grid, dim3(512), 0, s, p);
+    } else if (g_conv_arith) {
         if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
         else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
@@ -1745,9 +1758,18 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_min_chunks")) { g_ksplit_min_chunks = value > 0 ? value : 1; return WSDL_OK; }
-    if (!strcmp(name, "conv_arith")) { g_conv_arith = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "conv_arith")) {
+        WSDL_REQUIRE(value >= 0 && value <= 2, "conv_arith: 0 (bf16x3), 1 (fp16x2), 2 (fp16x2, low piece at 2^11)");
+        g_conv_arith = value;
+        return WSDL_OK;
+    }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
+    if (!strcmp(name, "layercam_tail_mod")) {
+        WSDL_REQUIRE(value >= 0 && value <= 32, "layercam_tail_mod: 0..32");
+        wsdl::g_layercam_tail_mod = value;
+        return WSDL_OK;
+    }
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
@@ -1793,8 +1815,12 @@ int wsdl_conv2d_prep_weights(const float* w, void* wt_fwd, void* wt_dgrad, int C
                                    wsdl::as_stream(stream), w, total, total, total, tr);
                 amax = tr;
             }
-            hipLaunchKernelGGL(prep_weights_split_kernel<1>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
-                               T, amax);
+            if (g_conv_arith == 2)
+                hipLaunchKernelGGL(prep_weights_split_kernel<2>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
+                                   T, amax);
+            else
+                hipLaunchKernelGGL(prep_weights_split_kernel<1>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
+                                   T, amax);
         } else {
             hipLaunchKernelGGL(prep_weights_split_kernel<0>, grid, dim3(256), 0, wsdl::as_stream(stream), w, f8, d8, Cout, Cin,
                                T, static_cast<const float*>(nullptr));
@@ -1870,8 +1896,11 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
 
 int wsdl_conv2d_prep_weights_multi(const wsdl_prep_desc* desc, int n, int total_blocks, wsdl_stream_t stream) {
     WSDL_REQUIRE(desc && n > 0 && total_blocks > 0, "prep_weights_multi: bad arguments");
-    WSDL_REQUIRE(g_conv_arith == 1 && g_conv_split, "prep_weights_multi: only the fp16x2 split layouts");
-    hipLaunchKernelGGL(prep_weights_split_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, wsdl::as_stream(stream), desc, n);
+    WSDL_REQUIRE(g_conv_arith >= 1 && g_conv_split, "prep_weights_multi: only the fp16x2 split layouts");
+    if (g_conv_arith == 2)
+        hipLaunchKernelGGL(prep_weights_split_multi_kernel<2>, dim3(total_blocks), dim3(256), 0, wsdl::as_stream(stream), desc, n);
+    else
+        hipLaunchKernelGGL(prep_weights_split_multi_kernel<1>, dim3(total_blocks), dim3(256), 0, wsdl::as_stream(stream), desc, n);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -58,6 +58,19 @@ __device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigne
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
 }
 
+// fp16x2 with the LOW piece carried at 2^11 times its value ("AR = 2"): l' = fp16((x - h) * 2^11).  |x - h| <= 2^-11 |h|, so l'
+// is a normal fp16 number whenever h is one - an element keeps its 22 bits down to 2^-29 of the tensor's maximum (2^-18 with the
+// unscaled l of AR = 1, whose low piece drops into fp16's subnormals there) and is represented to an absolute 2^-50 of the
+// maximum below that (2^-39).  The cross products ah*bl' + al'*bh then carry a factor 2^11 and are accumulated in a second
+// accumulator that the epilogue folds in:  a*b ~= ah*bh + 2^-11 (ah*bl' + al'*bh).  Same three MFMAs per product.
+__device__ __forceinline__ void split2hs(float x0, float x1, unsigned& h, unsigned& l) {
+    f32x2 v = {x0, x1};
+    const half2v hv = __builtin_convertvector(v, half2v);
+    h = __builtin_bit_cast(unsigned, hv);
+    f32x2 r = {(x0 - (float)hv[0]) * 2048.f, (x1 - (float)hv[1]) * 2048.f};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
+}
+
 // power-of-two scale that puts amax in [2^14, 2^15); 1 for amax = 0 / inf / NaN.  `e` returns its exponent.
 __device__ __forceinline__ float pow2_scale(float amax, int& e) {
     const unsigned bits = __builtin_bit_cast(unsigned, amax) & 0x7fffffffu;
@@ -86,6 +99,7 @@ template <> struct SplitArith<1> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
 };
+template <> struct SplitArith<2> : SplitArith<1> {};
 // the partial products of one k-step, smallest terms first
 template <int AR, typename F>
 __device__ __forceinline__ f32x16 split_products(const F (&a)[SplitArith<AR>::NP], const F (&b)[SplitArith<AR>::NP], f32x16 c) {
@@ -130,7 +144,7 @@ __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_t
 // stores (8 consecutive pixel rows, one unit).
 template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
-    static_assert(!MF || (AR == 1 && BK == 32), "16x16x32 form: fp16x2, K chunk 32");
+    static_assert(!MF || (AR >= 1 && BK == 32), "16x16x32 form: fp16x2, K chunk 32");
     using Ar = SplitArith<AR>;
     using frag = typename Ar::frag;
     constexpr int NP = Ar::NP;
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, wbytes, 0x00020000);
     float xs = 1.f, out_scale = 1.f;
-    if constexpr (AR == 1) {
+    if constexpr (AR >= 1) {
         int ex, ew;
         xs = pow2_scale(*p.x_amax, ex);
         (void)pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) + wbytes), ew);
@@ -263,12 +277,17 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     constexpr int RT = TS * TS / 64;                     // accumulator registers per tile
     using acc_t = std::conditional_t<MF, f32x4, f32x16>;
     acc_t acc[TMI][TNI];
+    constexpr int LO = AR == 2 ? 1 : 0;                  // AR = 2: the cross products (2^11 too large) have their own accumulator
+    acc_t acc_lo[LO ? TMI : 1][LO ? TNI : 1];
 #pragma unroll
     for (int i = 0; i < TMI; ++i)
 #pragma unroll
         for (int j = 0; j < TNI; ++j)
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < RT; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (LO) acc_lo[i][j][r] = 0.f;
+            }
 
     u32x4 ra[A_U];
     unsigned rb[B_PER];
@@ -313,8 +332,10 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #else
             if constexpr (AR == 0)
                 split3(x0, x1, pc[0][e], pc[1][e], pc[2][e]);
-            else
+            else if constexpr (AR == 1)
                 split2h(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
+            else
+                split2hs(x0 * xs, x1 * xs, pc[0][e], pc[1][e]);
 #endif
         }
         unsigned char* rowp = &Bs[buf][pl * ROW];
@@ -373,11 +394,19 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             for (int i = 0; i < TMI; ++i)
 #pragma unroll
                 for (int j = 0; j < TNI; ++j) {
-                    f32x4 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], c, 0, 0, 0);
-                    acc[i][j] = c;
+                    if constexpr (LO) {
+                        f32x4 c = acc_lo[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
+                        acc_lo[i][j] = c;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                    } else {
+                        f32x4 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][1], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i][0], b[j][0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
                 }
         } else {
             const unsigned char* Ab = As[cur] + (wm * (MI * 32) + l31) * ROW + lh * 16;
@@ -399,7 +428,13 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j) {
-                        if constexpr (!MF) acc[i][j] = split_products<AR>(a[i], b[j], acc[i][j]);
+                        if constexpr (!MF && LO) {
+                            acc_lo[i][j] = Ar::mma(a[i][1], b[j][0], acc_lo[i][j]);
+                            acc_lo[i][j] = Ar::mma(a[i][0], b[j][1], acc_lo[i][j]);
+                            acc[i][j] = Ar::mma(a[i][0], b[j][0], acc[i][j]);
+                        } else if constexpr (!MF) {
+                            acc[i][j] = split_products<AR>(a[i], b[j], acc[i][j]);
+                        }
                     }
             }
         }
@@ -439,7 +474,9 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
                     const int co = m0 + wm * (BM / WM) + i * TS + acc_row(r);
-                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = AR == 1 ? acc[i][j][r] * out_scale : acc[i][j][r];
+                    float v = acc[i][j][r];
+                    if constexpr (LO) v = fmaf(acc_lo[i][j][r], 0x1p-11f, v);
+                    if (co < p.Cout) sl[(long long)co * p.P + gpix] = AR >= 1 ? v * out_scale : v;
                 }
         }
         return;
@@ -461,7 +498,8 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 const int co = m0 + wm * (BM / WM) + i * TS + acc_row(r);
                 if (co >= p.Cout) continue;
                 float v = acc[i][j][r];
-                if constexpr (AR == 1) v *= out_scale;
+                if constexpr (LO) v = fmaf(acc_lo[i][j][r], 0x1p-11f, v);
+                if constexpr (AR >= 1) v *= out_scale;
                 if (p.scale) v *= p.scale[co];
                 if (p.shift) v += p.shift[co];
                 const long long off = (long long)co * OHOW;
@@ -534,7 +572,7 @@ __device__ __forceinline__ void prep_weights_split_body(const float* __restrict_
     const int nci = min(32, Cin - ci0), nco = min(32, Cout - co0);
     const int run = nci * T;
     float ws = 1.f;
-    if constexpr (AR == 1) {
+    if constexpr (AR >= 1) {
         int e;
         ws = pow2_scale(*amax, e);
         if (bx == 0 && by == 0 && tid == 0) {
@@ -554,8 +592,10 @@ __device__ __forceinline__ void prep_weights_split_body(const float* __restrict_
         for (int e = 0; e < 4; ++e) {
             if constexpr (AR == 0)
                 split3(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e], pc[2][e]);
-            else
+            else if constexpr (AR == 1)
                 split2h(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e]);
+            else
+                split2hs(v[2 * e], v[2 * e + 1], pc[0][e], pc[1][e]);
         }
 #pragma unroll
         for (int c = 0; c < NP; ++c) *reinterpret_cast<u32x4*>(dst + c * 32) = u32x4{pc[c][0], pc[c][1], pc[c][2], pc[c][3]};

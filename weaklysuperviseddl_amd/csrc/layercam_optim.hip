@@ -1,11 +1,36 @@
 // layercam_optim.hip - LayerCAM epilogue (channel-weighted sum / ReLU / min-max / bilinear / layer
 // mean / clamp-pow / threshold) and the fused flat Adam step.
 //
-// LayerCAM epilogue, three launches for all images and layers together:
-//   1. layercam_partial : grid (slices, layers, B).  Each block sums relu(g*a) over a slice of the
-//      channels for every pixel of the small map; consecutive lanes = consecutive pixels of one
+// The pseudo-mask is an INTEGER output (cam >= thresh), so the epilogue reproduces the arithmetic of the reference's
+// PyTorch-CPU path operation by operation AND in its order of summation: on identical activations / gradients the CAM
+// is bit-identical to `LayerCAMGenerator.generate` (TraditionalModel/LayerCAM.py:52-76) run on torch CPU, and so is
+// every mask pixel.  What that order is (ATen's SumKernel.cpp `cascade_sum`, outer reduction over the channel
+// dimension of a contiguous NCHW tensor; checked against torch 2.10 bit for bit by tests/test_hip_ops.py):
+//   * pixels p < hw - hw % kTailMod ("main"; ATen's vectorised columns): four-level cascade with level step 16 -
+//     acc0 sums 16 consecutive channels starting from 0, every 16 channels acc1 += acc0, every 256 acc2 += acc1, every
+//     4096 acc3 += acc2; channels beyond the last full 16 stay in acc0; result ((acc0 + acc1) + acc2) + acc3;
+//   * the last hw % kTailMod pixels (ATen's scalar columns, `row_sum`): four interleaved streams (channel i -> stream
+//     i % 4), each the same cascade over its C / 4 entries, then stream0 += the C % 4 left-over channels, += stream 1, 2, 3.
+//   kTailMod = 32 is two AVX-512 vectors of floats ("layercam_tail_mod" option: 16 for an AVX2 build of torch, 0 = the
+//   cascade for every pixel).  The level step is 16 for C <= 2^19 channels (max(4, ceil_log2(C) / 4) in ATen).
+//   relu(g * a) is a rounded product, min / max are order-free, `c -= min; c /= (max + 1e-8)` are IEEE operations,
+//   bilinear interpolation (align_corners=False) is ATen's  s = fma(scale, o + 0.5, -0.5),  t0 * w0 + t1 * w1  evaluated
+//   as fma(t0, w0, round(t1 * w1)) along x and then along y (UpSampleKernel.cpp's generic kernel as compiled for x86 with
+//   FMA - the one ATen takes for outH + outW > 128, e.g. the reference's fixed 224 x 224; smaller outputs go through its
+//   four-weight kernel, which this one matches to an ulp or two only), the layer
+//   mean is a sum in layer order and an IEEE division, `** alpha` is the identity / x*x / x*x*x for alpha = 1 / 2 / 3 as
+//   torch special-cases them: bit-identical.  alpha = 0.5 is torch.sqrt, which an MKL build of torch evaluates with VML's
+//   vsSqrt - not correctly rounded (0.6 % of values differ from IEEE sqrt by one ulp): here it is the IEEE sqrt, within one
+//   ulp of the reference; other exponents: powf, within a few ulp of torch's Sleef pow.  alpha = 1 is the default and what
+//   every call site of the reference passes (PsuedoMasks.py:27, Abalations.py:88).
+//   The whole file is compiled with floating-point contraction OFF (the __f*_rn intrinsics of this hipcc are plain
+//   operators, and __fsqrt_rn is the approximate native square root): a fused multiply-add appears only where written.
+//
+// Three launches for all images and layers together:
+//   1. layercam_partial : grid (64-channel slices, layers, B).  Level-0 sums of relu(g*a): per main pixel one value per
+//      16 channels, per (tail pixel, stream) one value per 64 channels; consecutive lanes = consecutive pixels of one
 //      channel -> coalesced reads of the NCHW activations/gradients (the 4.8 MB/img that dominate).
-//   2. layercam_normalise: grid (layers, B).  Adds the slices in fixed order, ReLU, per-image min-max
+//   2. layercam_normalise: grid (layers, B).  The upper cascade levels in order, ReLU, per-image min-max
 //      (second min-max after **alpha for the notebook variant) with wave shuffles.
 //   3. layercam_upsample : bilinear to (outH,outW), mean over layers, clamp/pow, threshold -> uint8.
 #include "common.h"
@@ -13,33 +38,108 @@
 #include <algorithm>
 #include <cmath>
 
+#pragma clang fp contract(off)
+
+int wsdl::g_layercam_tail_mod = 32;   // "layercam_tail_mod" option (wsdl_set_option): see above
+
 namespace {
 
 constexpr int kMaxLayers = 8;
-constexpr int kSlices = 16;
+constexpr int kL0 = 16;          // level step of the cascade (channels per level-0 sum)
+constexpr int kSliceC = 64;      // channels per workgroup of the partial kernel = 4 level-0 blocks = one block of each stream
+constexpr int kMaxTail = 32;     // tail pixels per map are < kTailMod <= 32
 
 struct CamLayers {
     const float* act[kMaxLayers];
     const float* grad[kMaxLayers];
     int C[kMaxLayers], h[kMaxLayers], w[kMaxLayers];
-    long long part_off[kMaxLayers];   // float offset of this layer's [B][kSlices][hw] partials
+    int tail0[kMaxLayers];            // first tail pixel (hw when there is none)
+    long long part_off[kMaxLayers];   // float offset of this layer's [B][ceil(C/16)][hw] level-0 sums (main pixels)
+    long long tpart_off[kMaxLayers];  // float offset of this layer's [B][ceil(C/64)][tail pixels][4 streams] level-0 sums
     long long map_off[kMaxLayers];    // float offset of this layer's [B][hw] normalised map
     int n;
 };
 
+// single IEEE operations (contraction is off in this file: the compiler may not fuse them)
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float rn_sub(float a, float b) { return a - b; }
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_div(float a, float b) { return a / b; }
+
+__device__ __forceinline__ float relu_prod(float g, float a) { return fmaxf(rn_mul(g, a), 0.f); }
+
 __global__ void layercam_partial_kernel(CamLayers L, float* __restrict__ ws) {
     const int s = blockIdx.x, l = blockIdx.y, b = blockIdx.z;
     const int C = L.C[l], hw = L.h[l] * L.w[l];
-    const int per = (C + kSlices - 1) / kSlices;
-    const int c0 = s * per, c1 = min(c0 + per, C);
+    const int c0 = s * kSliceC;
+    if (c0 >= C) return;
+    const int tail0 = L.tail0[l], tn = hw - tail0;
+    const int nblk = (C + kL0 - 1) / kL0, ngrp = (C + kSliceC - 1) / kSliceC;
     const float* a = L.act[l] + (long long)b * C * hw;
     const float* g = L.grad[l] + (long long)b * C * hw;
-    float* out = ws + L.part_off[l] + ((long long)b * kSlices + s) * hw;
-    for (int p = threadIdx.x; p < hw; p += blockDim.x) {
-        float acc = 0.f;
-        for (int c = c0; c < c1; ++c) acc += fmaxf(g[(long long)c * hw + p] * a[(long long)c * hw + p], 0.f);
-        out[p] = acc;
+    float* part = ws + L.part_off[l] + (long long)b * nblk * hw;
+    float* tpart = ws + L.tpart_off[l] + ((long long)b * ngrp + s) * tn * 4;
+    const int nstream = C / 4;          // entries per stream of a tail pixel (channels >= 4 * nstream are added later)
+    for (int it = threadIdx.x; it < tail0 + 4 * tn; it += blockDim.x) {
+        if (it < tail0) {
+            const int p = it;
+#pragma unroll
+            for (int q = 0; q < kSliceC / kL0; ++q) {
+                const int cb = c0 + q * kL0;
+                if (cb >= C) break;
+                const int cnt = min(kL0, C - cb);
+                float acc = 0.f;
+                if (cnt == kL0) {
+#pragma unroll
+                    for (int c = 0; c < kL0; ++c)
+                        acc = rn_add(acc, relu_prod(g[(long long)(cb + c) * hw + p], a[(long long)(cb + c) * hw + p]));
+                } else {
+                    for (int c = 0; c < cnt; ++c)
+                        acc = rn_add(acc, relu_prod(g[(long long)(cb + c) * hw + p], a[(long long)(cb + c) * hw + p]));
+                }
+                part[(long long)(cb / kL0) * hw + p] = acc;
+            }
+        } else {
+            const int t = (it - tail0) >> 2, k = (it - tail0) & 3, p = tail0 + t;
+            float acc = 0.f;
+            for (int m = 0; m < kL0; ++m) {
+                const int e = s * kL0 + m;      // entry of stream k
+                if (e >= nstream) break;
+                const long long c = 4LL * e + k;
+                acc = rn_add(acc, relu_prod(g[c * hw + p], a[c * hw + p]));
+            }
+            tpart[t * 4 + k] = acc;
+        }
     }
+}
+
+// upper levels of ATen's cascade over `nfull` level-0 sums read at `stride`, plus the left-over sum (`has_left`)
+__device__ __forceinline__ float cascade_upper(const float* __restrict__ v, long long stride, int nfull, bool has_left) {
+    float acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    for (int q = 0; q < nfull; ++q) {
+        acc1 = rn_add(acc1, v[q * stride]);
+        const int i = (q + 1) * kL0;
+        if ((i & 0xF0) == 0) {
+            acc2 = rn_add(acc2, acc1);
+            acc1 = 0.f;
+            if ((i & 0xF00) == 0) {
+                acc3 = rn_add(acc3, acc2);
+                acc2 = 0.f;
+            }
+        }
+    }
+    const float acc0 = has_left ? v[nfull * stride] : 0.f;
+    return rn_add(rn_add(rn_add(acc0, acc1), acc2), acc3);
+}
+
+// torch's `** alpha` on a non-negative fp32 value (Pow.cpp / PowKernel.cpp special cases)
+__device__ __forceinline__ float pow_like_torch(float v, float alpha) {
+    if (alpha == 1.f) return v;
+    if (alpha == 0.5f) return sqrtf(v);     // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+    if (alpha == 2.f) return rn_mul(v, v);
+    if (alpha == 3.f) return rn_mul(rn_mul(v, v), v);
+    if (alpha == 0.f) return 1.f;
+    return powf(v, alpha);
 }
 
 __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* sm) {
@@ -62,35 +162,56 @@ __device__ __forceinline__ void block_minmax(float& mn, float& mx, float* sm) {
 
 __global__ void layercam_normalise_kernel(CamLayers L, float* __restrict__ ws, float alpha, int variant) {
     __shared__ float sm[32];
+    __shared__ float s_tail[kMaxTail * 4];
     const int l = blockIdx.x, b = blockIdx.y;
-    const int hw = L.h[l] * L.w[l];
-    const float* part = ws + L.part_off[l] + (long long)b * kSlices * hw;
+    const int C = L.C[l], hw = L.h[l] * L.w[l];
+    const int tail0 = L.tail0[l], tn = hw - tail0;
+    const int nblk = (C + kL0 - 1) / kL0, ngrp = (C + kSliceC - 1) / kSliceC;
+    const float* part = ws + L.part_off[l] + (long long)b * nblk * hw;
+    const float* tpart = ws + L.tpart_off[l] + (long long)b * ngrp * tn * 4;
     float* map = ws + L.map_off[l] + (long long)b * hw;
-    // pass 1: slice sum + relu (kept in the map buffer), min / max
+    // pass 1: the cascade's upper levels + relu (kept in the map buffer)
+    const int nstream = C / 4;
+    for (int it = threadIdx.x; it < tail0 + 4 * tn; it += blockDim.x) {
+        if (it < tail0) {
+            map[it] = fmaxf(cascade_upper(part + it, hw, C / kL0, (C % kL0) != 0), 0.f);
+        } else {
+            const int j = it - tail0;   // = 4 * t + k
+            s_tail[j] = cascade_upper(tpart + j, (long long)tn * 4, nstream / kL0, (nstream % kL0) != 0);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < tn) {
+        const int t = threadIdx.x, p = tail0 + t;
+        const float* a = L.act[l] + (long long)b * C * hw;
+        const float* g = L.grad[l] + (long long)b * C * hw;
+        float v = s_tail[4 * t];
+        for (int c = 4 * nstream; c < C; ++c) v = rn_add(v, relu_prod(g[(long long)c * hw + p], a[(long long)c * hw + p]));
+        v = rn_add(rn_add(rn_add(v, s_tail[4 * t + 1]), s_tail[4 * t + 2]), s_tail[4 * t + 3]);
+        map[p] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
     float mn = INFINITY, mx = -INFINITY;
     for (int p = threadIdx.x; p < hw; p += blockDim.x) {
-        float v = 0.f;
-        for (int s = 0; s < kSlices; ++s) v += part[(long long)s * hw + p];
-        v = fmaxf(v, 0.f);
-        map[p] = v;
+        const float v = map[p];
         mn = fminf(mn, v);
         mx = fmaxf(mx, v);
     }
     block_minmax(mn, mx, sm);
-    // c -= min ; c /= (max_after_shift + 1e-8)
-    const float den = (mx - mn) + 1e-8f;
+    // c -= min ; c /= (max_after_shift + 1e-8)      (rounding is monotonic: max(c - min) = fl(max - min))
+    const float den = rn_add(rn_sub(mx, mn), 1e-8f);
     float mn2 = INFINITY, mx2 = -INFINITY;
     for (int p = threadIdx.x; p < hw; p += blockDim.x) {
-        float v = (map[p] - mn) / den;
-        if (variant == 1) v = powf(v, alpha);
+        float v = rn_div(rn_sub(map[p], mn), den);
+        if (variant == 1) v = pow_like_torch(v, alpha);
         map[p] = v;
         mn2 = fminf(mn2, v);
         mx2 = fmaxf(mx2, v);
     }
     if (variant == 1) {
         block_minmax(mn2, mx2, sm);
-        const float den2 = (mx2 - mn2) + 1e-8f;
-        for (int p = threadIdx.x; p < hw; p += blockDim.x) map[p] = (map[p] - mn2) / den2;
+        const float den2 = rn_add(rn_sub(mx2, mn2), 1e-8f);
+        for (int p = threadIdx.x; p < hw; p += blockDim.x) map[p] = rn_div(rn_sub(map[p], mn2), den2);
     }
 }
 
@@ -110,14 +231,19 @@ __global__ void plane_relu_minmax_kernel(const float* __restrict__ x, float* __r
     for (int p = threadIdx.x; p < hw; p += blockDim.x) yp[p] = (fmaxf(xp[p], 0.f) - mn) / den;
 }
 
+// ATen's area_pixel_compute_source_index + guard_index_and_lambda (align_corners=False), as compiled with FMA contraction
 __device__ __forceinline__ void src_index(int o, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
-    float s = scale * ((float)o + 0.5f) - 0.5f;
+    float s = __builtin_fmaf(scale, rn_add((float)o, 0.5f), -0.5f);
     if (s < 0.f) s = 0.f;
     i0 = (int)s;
     if (i0 > in - 1) i0 = in - 1;
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l1 = s - (float)i0;
-    l0 = 1.f - l1;
+    l1 = fminf(fmaxf(rn_sub(s, (float)i0), 0.f), 1.f);
+    l0 = rn_sub(1.f, l1);
+}
+// t0 * w0 + t1 * w1 as the reference's CPU build evaluates it
+__device__ __forceinline__ float lerp_like_torch(float t0, float w0, float t1, float w1) {
+    return __builtin_fmaf(t0, w0, rn_mul(t1, w1));
 }
 
 __global__ void layercam_upsample_kernel(CamLayers L, const float* __restrict__ ws, float* __restrict__ cam,
@@ -130,19 +256,22 @@ __global__ void layercam_upsample_kernel(CamLayers L, const float* __restrict__ 
         for (int l = 0; l < L.n; ++l) {
             const int h = L.h[l], w = L.w[l];
             const float* m = ws + L.map_off[l] + (long long)b * h * w;
-            int y0, y1, x0, x1;
-            float ly0, ly1, lx0, lx1;
-            src_index(oh, (float)h / (float)outH, h, y0, y1, ly0, ly1);
-            src_index(ow, (float)w / (float)outW, w, x0, x1, lx0, lx1);
-            const float top = lx0 * m[y0 * w + x0] + lx1 * m[y0 * w + x1];
-            const float bot = lx0 * m[y1 * w + x0] + lx1 * m[y1 * w + x1];
-            sum += ly0 * top + ly1 * bot;
+            float v;
+            if (h == outH && w == outW) {
+                v = m[oh * w + ow];     // F.interpolate to the same size copies
+            } else {
+                int y0, y1, x0, x1;
+                float ly0, ly1, lx0, lx1;
+                src_index(oh, rn_div((float)h, (float)outH), h, y0, y1, ly0, ly1);
+                src_index(ow, rn_div((float)w, (float)outW), w, x0, x1, lx0, lx1);
+                const float top = lerp_like_torch(m[y0 * w + x0], lx0, m[y0 * w + x1], lx1);
+                const float bot = lerp_like_torch(m[y1 * w + x0], lx0, m[y1 * w + x1], lx1);
+                v = lerp_like_torch(top, ly0, bot, ly1);
+            }
+            sum = rn_add(sum, v);
         }
-        float v = sum / (float)L.n;
-        if (variant == 0) {
-            v = fmaxf(v, 0.f);
-            if (alpha != 1.f) v = powf(v, alpha);
-        }
+        float v = rn_div(sum, (float)L.n);
+        if (variant == 0) v = pow_like_torch(fmaxf(v, 0.f), alpha);
         cam[(long long)b * outH * outW + o] = v;
         if (mask) mask[(long long)b * outH * outW + o] = (v >= thresh && v > 0.f) ? 1 : 0;
     }
@@ -193,17 +322,26 @@ int fill_layers(CamLayers& L, const float* const* act, const float* const* grad,
                 const int* w, int n_layers, int B, size_t* total_floats) {
     WSDL_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers, "layercam: 1..%d layers supported", kMaxLayers);
     WSDL_REQUIRE(B >= 1 && B <= 65535, "layercam: bad batch");
+    const int tail_mod = wsdl::g_layercam_tail_mod;
+    WSDL_REQUIRE(tail_mod >= 0 && tail_mod <= kMaxTail, "layercam: layercam_tail_mod must be 0..%d", kMaxTail);
     size_t off = 0;
     L.n = n_layers;
     for (int l = 0; l < n_layers; ++l) {
-        WSDL_REQUIRE(C[l] > 0 && h[l] > 0 && w[l] > 0 && (long long)h[l] * w[l] < (1 << 24), "layercam: bad layer %d shape", l);
+        // C <= 2^19: the reference's cascade has level step 16 up to there (and so has each of the four streams)
+        WSDL_REQUIRE(C[l] > 0 && C[l] <= (1 << 19) && h[l] > 0 && w[l] > 0 && (long long)h[l] * w[l] < (1 << 24),
+                     "layercam: bad layer %d shape", l);
         L.act[l] = act ? act[l] : nullptr;
         L.grad[l] = grad ? grad[l] : nullptr;
         L.C[l] = C[l]; L.h[l] = h[l]; L.w[l] = w[l];
+        const int hw = h[l] * w[l];
+        L.tail0[l] = tail_mod > 1 ? hw - hw % tail_mod : hw;
+        const size_t nblk = (C[l] + kL0 - 1) / kL0, ngrp = (C[l] + kSliceC - 1) / kSliceC;
         L.part_off[l] = (long long)off;
-        off += (size_t)B * kSlices * h[l] * w[l];
+        off += (size_t)B * nblk * hw;
+        L.tpart_off[l] = (long long)off;
+        off += (size_t)B * ngrp * (hw - L.tail0[l]) * 4;
         L.map_off[l] = (long long)off;
-        off += (size_t)B * h[l] * w[l];
+        off += (size_t)B * hw;
     }
     *total_floats = off;
     return WSDL_OK;
@@ -240,7 +378,9 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
     for (int l = 0; l < n_layers; ++l) bytes += 8.0 * B * C[l] * h[l] * w[l];
     bytes += (double)B * outH * outW * (4.0 + (mask ? 1.0 : 0.0));
     wsdl::ProfScope prof(WSDL_PROF_LAYERCAM, s, bytes);
-    hipLaunchKernelGGL(layercam_partial_kernel, dim3(kSlices, n_layers, B), dim3(256), 0, s, L, wsf);
+    int slices = 1;
+    for (int l = 0; l < n_layers; ++l) slices = std::max(slices, wsdl::cdiv(C[l], kSliceC));
+    hipLaunchKernelGGL(layercam_partial_kernel, dim3(slices, n_layers, B), dim3(256), 0, s, L, wsf);
     hipLaunchKernelGGL(layercam_normalise_kernel, dim3(n_layers, B), dim3(256), 0, s, L, wsf, alpha, variant);
     int gx = wsdl::cdiv(outH * outW, 256);
     if (gx > 1024) gx = 1024;
