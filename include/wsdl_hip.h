@@ -43,7 +43,12 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  * library - calls are re-entrant across streams only for a fixed option set).  Changing "conv_split" /
  * "conv_arith" changes what the weight layout buffers hold: re-run wsdl_conv2d_prep_weights afterwards.
  *   conv_arith     1*  arithmetic of the split kernels: 1 = fp16x2 (three 16-bit MFMAs per fp32 product, per-tensor
- *                      power-of-two scales from the amax arguments), 0 = bf16x3 (six MFMAs, no scales)
+ *                      power-of-two scales from the amax arguments), 0 = bf16x3 (six MFMAs, no scales),
+ *                      2 = fp16x2 with the low piece carried at 2^11 and the cross products in a second accumulator
+ *                      (forward / input gradient; the RANGE GUARD: a region of a tensor keeps 22 bits down to 2^-29 of the
+ *                      tensor's maximum instead of 2^-18 and is exact to 2^-50 of it instead of 2^-39 - same three MFMAs, 64
+ *                      more registers per lane, which ends the co-residency with the weight-gradient workgroups: -6.6 % img/s
+ *                      on the training step, profiles/r04_notes.md; use it when gradients span more than 2^25 inside one tensor)
  *   conv_split     1*  0 = forward / input-gradient convolutions on the exact-fp32 MFMA kernels everywhere
  *   wgrad_split    1*  0 = weight gradients on the exact-fp32 MFMA kernels everywhere
  *   tile256        1*  256x128 workgroup tiles (512 threads) where they still give >= 256 workgroups

@@ -3,7 +3,7 @@
 //
 // Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate.  Every fp32 operand is split EXACTLY into a few
 // 16-bit pieces and a product a*b is evaluated as the partial products that matter, each an exact 16-bit x 16-bit
-// product accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}.  Two arithmetics (template parameter AR):
+// product accumulated in fp32 by v_mfma_f32_32x32x16_{f16,bf16}.  Three arithmetics (template parameter AR):
 //
 //   AR = 1, "fp16x2" (default): x*s = h + l, h = fp16(x*s), l = fp16(x*s - h) - 2 x 11 significant bits, residual
 //       <= 2^-22 |x| - and  a*b ~= ah*bh + (ah*bl + al*bh): THREE MFMAs per fp32 product.  fp16 has a 5-bit exponent, so
@@ -15,6 +15,16 @@
 //       they enter.  Measured against float64 (tools/conv_accuracy.py, tests/test_hip_ops.py): rms error at or below that
 //       of the exact-fp32 MFMA chain for K >= 64 - the representation error (2^-22 per product, random sign) is smaller
 //       than what K fp32 accumulator roundings contribute, and three accumulations per k-step round less than six.
+//   AR = 2, "fp16x2s" (conv_arith = 2, forward / input gradient only - the range guard): the low piece is carried at 2^11
+//       times its value, l' = fp16((x*s - h) * 2^11), which is a normal fp16 number whenever h is one: an element keeps its
+//       22 bits down to 2^-29 of the tensor's maximum and is exact to 2^-50 of it below that.  The cross products then
+//       carry a factor 2^11 and get their own accumulator, folded in by the epilogue: a*b ~= ah*bh + 2^-11 (ah*bl' + al'*bh).
+//       Same three MFMAs; 64 more accumulator registers (183 instead of 119 in the 256x128 form), which is what it costs:
+//       a weight-gradient workgroup no longer fits beside it on the CU (-6.6 % on the training step, +3.7 / 4.9 % on the
+//       isolated forward / input-gradient kernels; profiles/r04_notes.md).  Measured per region against float64
+//       (tests/test_hip_ops.py::test_split_arithmetic_max_norm_per_channel_and_per_block): one 2^30 outlier among unit
+//       activations 9e-7 (AR = 1: 1.3e-3), 2^35: 2.6e-5 (4.8e-2), images graded by 2^30 across the batch 2.8e-6 (5e-3);
+//       on unit data 3.7e-7 against 5.7e-7 - the cross products no longer round into the large accumulator.
 //   AR = 0, "bf16x3": x = h + m + l (3 x 8 bits cover fp32's 24; no scaling: bf16 has fp32's exponent range) and the SIX
 //       products of weight >= 2^-16: ah*bh, ah*bm, am*bh, ah*bl, al*bh, am*bm (dropped terms <= 2^-23 |a*b|).  Round 1's
 //       kernel; kept as wsdl_set_option("conv_arith", 0) and as the A/B partner.
