@@ -340,16 +340,21 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
     out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
            "launch": "hipGraph replay of the batch (LayerCAMGenerator.generate_batch, WSDL_CAM_SELF_GRAPH=0: eager)",
            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
-    # stage 1 as generate_pseudo_masks runs it: three of the loader's batches of 8 in flight on three streams
-    nb, lanes = int(os.environ.get("WSDL_CAM_NB", "6")), int(os.environ.get("WSDL_CAM_LANES", "3"))
-    gen.generate_batches([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes)
+    # stage 1 as generate_pseudo_masks runs it: the loader's batches of 8 merged into device batches of 32 images, three of
+    # those in flight on three streams (WSDL_CAM_DEVICE_BATCH=0: one launch sequence per loader batch, round 3's form)
+    nb, lanes = int(os.environ.get("WSDL_CAM_NB", "12")), int(os.environ.get("WSDL_CAM_LANES", "3"))
+    db = int(os.environ.get("WSDL_CAM_DEVICE_BATCH", "32"))
+    for _ in range(3):
+        gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=db)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
-        gen.generate_batches([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes)
+        gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=db)
     torch.cuda.synchronize()
     out["ms_per_img_pipelined"] = round((time.perf_counter() - t0) / iters * 1e3 / (nb * n_img), 4)
-    out["pipelined"] = f"{nb} batches of {n_img}, {lanes} in flight (LayerCAMGenerator.generate_batches, as generate_pseudo_masks)"
+    out["pipelined"] = (f"{nb} loader batches of {n_img} merged into device batches of {db}, {lanes} in flight "
+                        "(LayerCAMGenerator.generate_coalesced, as generate_pseudo_masks)" if db > 0 else
+                        f"{nb} batches of {n_img}, {lanes} in flight (LayerCAMGenerator.generate_batches)")
     if roofline:
         ops.prof_reset()
         ops.prof_enable(True)

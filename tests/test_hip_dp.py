@@ -225,7 +225,9 @@ def _worker_stage1(rank, world, port, out):
     from weaklysuperviseddl_amd.TraditionalModel import generate_pseudo_masks
     init_distributed()
     gen = _cam_generator(torch.device("cuda:0"))
-    generate_pseudo_masks(_cam_loader(), gen, cam_thresh=0.3, write_png=False, max_images=7, rank=rank, world=world)
+    # device_batch=0: one launch sequence per loader batch, so a rank's results do not depend on which other batches it holds
+    # (merged device batches - the default - carry their own amax scales: equal to fp32 noise only)
+    generate_pseudo_masks(_cam_loader(), gen, cam_thresh=0.3, write_png=False, max_images=7, rank=rank, world=world, device_batch=0)
     mine = (generate_pseudo_masks.last_ids, generate_pseudo_masks.last_masks)
     both = [None] * world
     dist.all_gather_object(both, mine)
@@ -240,7 +242,7 @@ def test_stage1_sharded_over_ranks_equals_single_process(dev, tmp_path):
     out = str(tmp_path / "r0.pt")
     mp.spawn(_worker_stage1, args=(2, _free_port(), out), nprocs=2, join=True)
     both = torch.load(out, weights_only=False)
-    generate_pseudo_masks(_cam_loader(), _cam_generator(dev), cam_thresh=0.3, write_png=False, max_images=7)
+    generate_pseudo_masks(_cam_loader(), _cam_generator(dev), cam_thresh=0.3, write_png=False, max_images=7, device_batch=0)
     ids, masks = generate_pseudo_masks.last_ids, generate_pseudo_masks.last_masks
     assert ids == list(range(7))                                   # the cap cuts the last batch (PsuedoMasks.py:49)
     assert sorted(both[0][0] + both[1][0]) == ids and not set(both[0][0]) & set(both[1][0])

@@ -305,7 +305,9 @@ def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
     loader = [(imgs224[:8], (labels[:8], None)), (imgs224[8:], (labels[8:], None))]
 
     def chain():
-        generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev)
+        # device_batch=0: per loader batch, comparable bit for bit with generate_batch on the same 8 images below (bench.py's cfg4
+        # step merges the 16 images into one device batch - the default)
+        generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev, device_batch=0)
         masks = [m.copy() for m in generate_pseudo_masks.last_masks]
         assert generate_pseudo_masks.last_ids == list(range(16))
         img, m = stage_handoff(imgs224, masks, (256, 256), dev)
@@ -347,7 +349,8 @@ def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
     assert all(np.array_equal(a, b) for a, b in zip(masks, masks2)) and torch.equal(img, img2) and torch.equal(m, m2)
     assert losses == losses2 and torch.equal(p1, p2) and torch.equal(g1, g2)
     # the sync-free form of the chain (bench.py's cfg4 step): masks stay on the device from the CAM to the training step
-    generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev, keep_on_device=True)
+    generate_pseudo_masks(loader, gen, cam_thresh=0.3, keep_largest_masks=True, write_png=False, device=dev, keep_on_device=True,
+                          device_batch=0)
     dmasks = generate_pseudo_masks.last_masks
     assert all(torch.is_tensor(x) and x.is_cuda and x.dtype == torch.uint8 for x in dmasks) and len(dmasks) == 16
     assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(dmasks, masks))

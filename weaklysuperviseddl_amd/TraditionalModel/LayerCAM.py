@@ -150,6 +150,35 @@ class LayerCAMGenerator:
         with ops.prof_range("layercam/epilogue"):
             return ops.layercam_epilogue(acts, grads, self.out_hw, alpha, self.variant, thresh)
 
+    def generate_coalesced(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3, device_batch=32):
+        """The batches of a loader merged into device batches of up to ``device_batch`` images (eval-mode BatchNorm makes images
+        independent of their batch), ``streams`` of those in flight, the results handed back per loader batch.  At B=8 a batch
+        is ~130 launches of 25-200-workgroup grids, 15-25 us each whatever their size: latency-bound; at B=32 the same launches
+        carry four times the pixels (the 14 x 14 layers reach >= 256 workgroups with fewer K slices).  A merged batch has
+        its own per-tensor amax scales, tile shapes and K-slice counts, so its CAMs equal the batch-by-batch ones to the fp32
+        noise of a 50-layer network (~2e-3 of the min-max normalised map's range, as between any two fp32 runs), not bit for
+        bit - the masks agree outside that band (tests/test_hip_models.py::test_cam_batches_in_flight_equal_batch_by_batch)."""
+        if class_idxs is None:
+            class_idxs = [None] * len(batches)
+        if device_batch <= 0 or len(batches) <= 1:
+            return self.generate_batches(batches, alpha, class_idxs, thresh, streams)
+        merged, cls_merged, spans, cur, cur_cls, n = [], [], [], [], [], 0
+        for b, c in zip(batches, class_idxs):
+            if cur and (n + b.shape[0] > device_batch or b.shape[1:] != cur[0].shape[1:] or (c is None) != (cur_cls[0] is None)):
+                merged.append(cur); cls_merged.append(cur_cls); cur, cur_cls, n = [], [], 0
+            spans.append((len(merged), n, b.shape[0]))
+            cur.append(b); cur_cls.append(c); n += b.shape[0]
+        merged.append(cur); cls_merged.append(cur_cls)
+        big = [m[0] if len(m) == 1 else torch.cat(m) for m in merged]
+        big_cls = [None if c[0] is None else (c[0].view(-1) if len(c) == 1 else torch.cat([t.view(-1).to(b.device) for t in c]))
+                   for c, b in zip(cls_merged, big)]
+        outs = self.generate_batches(big, alpha, big_cls, thresh, streams)
+        res = []
+        for j, off, cnt in spans:
+            o = outs[j]
+            res.append(tuple(t[off:off + cnt] for t in o) if isinstance(o, tuple) else o[off:off + cnt])
+        return res
+
     def generate_batches(self, batches, alpha=1.0, class_idxs=None, thresh=None, streams=3, graphs=None):
         """Several independent batches in flight: batch j runs on stream j % ``streams`` with a generator of its own over
         the SAME model.  At B=8 and 224x224 a batch is ~130 launches of 25-100 workgroups - a fraction of the chip, and

@@ -59,7 +59,8 @@ def _to_png_u8(t):
 
 def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_largest_masks=True,
                           run_id="default", out_root="/content", max_images=500, write_png=True,
-                          device="cuda", rank=0, world=1, keep_images=False, streams=3, keep_on_device=False):
+                          device="cuda", rank=0, world=1, keep_images=False, streams=3, keep_on_device=False,
+                          device_batch=32):
     mask_dir = os.path.join(out_root, f"pseudo_masks_{run_id}")
     image_dir = os.path.join(out_root, f"images_{run_id}")
     if write_png:
@@ -79,9 +80,14 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
         """CAM + threshold for the queued batches (``streams`` of them in flight), then the host part per image."""
         if not group:
             return
-        outs = layercam_gen.generate_batches([g[1] for g in group], alpha, [g[2] for g in group], cam_thresh, streams) \
-            if hasattr(layercam_gen, "generate_batches") else \
-            [layercam_gen.generate_batch(g[1], alpha=alpha, class_idx=g[2], thresh=cam_thresh) for g in group]
+        # the loader's batches are merged into device batches of ``device_batch`` images, ``streams`` of them in flight
+        # (0: one launch sequence per loader batch, as round 3)
+        if hasattr(layercam_gen, "generate_coalesced"):
+            outs = layercam_gen.generate_coalesced([g[1] for g in group], alpha, [g[2] for g in group], cam_thresh, streams, device_batch)
+        elif hasattr(layercam_gen, "generate_batches"):
+            outs = layercam_gen.generate_batches([g[1] for g in group], alpha, [g[2] for g in group], cam_thresh, streams)
+        else:
+            outs = [layercam_gen.generate_batch(g[1], alpha=alpha, class_idx=g[2], thresh=cam_thresh) for g in group]
         for (imgs, _d, _l, first_id, take), (_cam, m) in zip(group, outs):
             if keep_largest_masks:
                 m = keep_largest_batched(m)
@@ -112,7 +118,8 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
         labels_d = _to_device_async(torch.as_tensor(labels[:take]), device)
         group.append((imgs, imgs_d, labels_d, img_id, take))
         img_id += take
-        if len(group) >= max(1, streams):
+        queued = sum(g[4] for g in group)
+        if (device_batch > 0 and queued >= device_batch * max(1, streams)) or (device_batch <= 0 and len(group) >= max(1, streams)):
             finish(group)
             group = []
     finish(group)
