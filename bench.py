@@ -561,6 +561,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cam", action="store_true")
+    ap.add_argument("--no-full-width", action="store_true", help="skip the 5-step bf16x3 / fp32-MFMA legs of the default run")
     ap.add_argument("--cam-only", action="store_true", help="only the secondary CAM ms/img measurement (profiling aid)")
     ap.add_argument("--opt", default="", help="library options name=value[,name=value] (A/B experiments, e.g. ksplit_big=0)")
     ap.add_argument("--serial", action="store_true",
@@ -684,6 +685,8 @@ def main():
             ops.prof_reset()
             ops.prof_enable(True)
         for _ in range(args.steps):
+            if world == 1:
+                torch.cuda.synchronize()  # no hand-over from the previous step's side-stream work inside the first kernel's bracket
             eager_step()                  # HIP events around the launches: eager, never the graph replay
         torch.cuda.synchronize()
         ops.prof_enable(False)
@@ -719,6 +722,18 @@ def main():
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"
             result["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(mfma, 3),
                                   "peak": peak, "unit": "TFLOP/s", "frac": round(mfma / peak, 4),
+                                  "frac_is": ("MFMA ISSUE rate: the 16-bit MFMA FLOPs the kernel really executes (3 per fp32 "
+                                              "product, padding-only taps skipped) / the dense 16-bit peak.  The ALGORITHMIC "
+                                              "fraction - SURVEY 8(d)'s fp32 FLOPs of the convolutions launched / time / the same "
+                                              "peak - is frac_algorithmic_nominal (dense, padding taps counted) and "
+                                              "frac_algorithmic_executed") if split else "algorithmic = issued (fp32 MFMA kernel)",
+                                  "frac_algorithmic_nominal": round(nom / peak, 4),
+                                  "frac_algorithmic_executed": round(ach / peak, 4),
+                                  "frac_of_scheme_ceiling": round(ach / (peak / (nprod if split else 1)), 4),
+                                  "static_fields": ["traffic", "traffic_source", "mfma_busy_3x3"],
+                                  "static_note": "static_fields are LOOKUPS in committed rocprofv3 --pmc runs under profiles/ (counter "
+                                                 "passes cannot run inside bench.py); everything else in this object is measured in "
+                                                 "this run",
                                   "achieved_fp32_equivalent": round(ach, 3), "achieved_nominal": round(nom, 3),
                                   "mfma_products_per_fp32_product": (nprod if split else 1),
                                   "traffic": pmc_traffic(top["kernel"]),
@@ -737,6 +752,28 @@ def main():
                                   "tflops_nominal": round(kk["work"] / (kk["total_ms"] * 1e-3) / 1e12, 3)} for kk in kernels]
             result["model_tflops_nominal"] = round(value * GFLOP_PER_IMG_256 * (S / 256) ** 2 / 1e3, 3)
 
+    if world == 1 and cfg == "cfg2" and not args.no_full_width and not args.opt and not use_graph:
+        # the same step at full operand width, timed here (not only in builder runs under profiles/): bf16x3 = all 24 bits
+        # of both operands on the 16-bit matrix core (six MFMAs per product), fp32 = the exact-fp32 MFMA kernels everywhere
+        fw = {}
+        for name, opts in (("bf16x3", {"conv_arith": 0}), ("fp32_mfma", {"conv_split": 0, "wgrad_split": 0})):
+            for k, v in opts.items():
+                ops.set_option(k, v)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t0) / 5
+            fw[name] = {"value": round(B / d, 1), "unit": "img/s", "ms_per_step": round(d * 1e3, 3), "steps": 5, "warmup": 2,
+                        "options": opts}
+            for k in opts:
+                ops.set_option(k, 1)
+        fw["note"] = ("same model / batch / step function as `value`, 2 warm-up + 5 timed steps each; `value` itself uses fp16x2 "
+                      "(22 significant bits per operand, three MFMAs per product)")
+        result["full_width"] = fw
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -115,7 +115,10 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_fast_kernel<128,128,2,16> (
        WSDL_PROF_WGRAD_SPLIT32 = 17,   /* conv_wgrad_split32_kernel<128,128,AR> */
        WSDL_PROF_SPLIT_256x128 = 18,   /* conv_igemm_split_kernel<256,128,4,32|16,512,AR> */
        WSDL_PROF_STEM = 19,            /* stem_conv7x7s2_kernel */
-       WSDL_PROF_NCLASSES = 20 };
+       WSDL_PROF_WGRAD_SPLIT16D = 20,  /* conv_wgrad_split16d_kernel<MODE, DYRAW> (x fragments straight from global memory); class 17 is then
+                                          the LDS-staged conv_wgrad_split16_kernel / conv_wgrad_split32_kernel.  Both brackets include the
+                                          launch's dy_split16 pre-pass where there is one */
+       WSDL_PROF_NCLASSES = 21 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,

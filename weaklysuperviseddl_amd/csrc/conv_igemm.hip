@@ -2026,7 +2026,15 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                             wgrad_executed_fraction(B * OH * bands[i].own, OH, bands[i].ow0, bands[i].own, H, W, kh, kw,
                                                     stride, pad, dil, (chunk32 || g_wgrad_bk == 32) ? 32 : 16);
         }
-        wsdl::ProfScope prof(chunk32 ? WSDL_PROF_WGRAD_SPLIT32
+        // which fp16x2 kernel a chunk32 launch takes (the condition of the dispatch below): the direct-fragment kernel has a
+        // timing class of its own
+        bool taps_aligned = true;
+        for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
+        const bool direct = chunk32 && g_conv_arith && g_wgrad_mfma16 && g_wgrad_direct && (taps_aligned || g_wgrad_direct == 2) &&
+                            stride == 1 && OW % 32 == 0 && W % 4 == 0 && (H * W) % 4 == 0 && p.x_bs % 4 == 0 &&
+                            reinterpret_cast<uintptr_t>(x) % 16 == 0;
+        wsdl::ProfScope prof(direct ? WSDL_PROF_WGRAD_SPLIT16D
+                                    : chunk32 ? WSDL_PROF_WGRAD_SPLIT32
                                      : fast ? WSDL_PROF_WGRAD_FAST_128x128
                                             : (Cout <= 64 ? WSDL_PROF_WGRAD_64x128 : WSDL_PROF_WGRAD_128x128),
                              s, flops, executed,
@@ -2064,17 +2072,9 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                         // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
                         // with a third load for misaligned taps (dilation 1, 2) it is 0-7 % slower than the LDS-staged kernel
                         // (wgrad_direct = 2 forces it for those too)
-                        bool taps_aligned = true, taps_even = true;
-                        for (int kx = 0; kx < kw; ++kx) {
-                            taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
-                            taps_even = taps_even && (((kx * dil - pad) & 1) == 0);
-                        }
                         // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
                         // kernel on l3.conv2: the third load's registers spill; not used)
-                        const bool direct8 = false;
-                        (void)taps_even;
-                        if (g_wgrad_direct && (taps_aligned || direct8 || g_wgrad_direct == 2) && stride == 1 && OW % 32 == 0 && W % 4 == 0 &&
-                            (H * W) % 4 == 0 && p.x_bs % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
+                        if (direct) {
                             // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
                             // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
                             // workgroup splits its slice again; 7-11 % faster there, 7-21 % slower on the 3x3 shapes with 36-72 N tiles)

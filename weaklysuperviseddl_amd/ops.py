@@ -13,8 +13,20 @@ from ._lib import lib, check, WsdlError
 _vp = C.c_void_p
 
 
+# torch.cuda.current_stream() builds a Stream object (and resolves the device twice) per call: ~6.5 us, ~350 times per
+# training step = 2.3 ms of the host's ~13 ms (tools/host_profile.py).  The raw handle is one C call.
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_cur_device = torch._C._cuda_getDevice
+
+
+def raw_stream(device=None):
+    """hipStream_t of the current stream of ``device`` (default: the current device) as an int."""
+    idx = device.index if (device is not None and device.index is not None) else _cur_device()
+    return _raw_stream(idx)
+
+
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    return _vp(_raw_stream(_cur_device()))
 
 
 def _p(t):
@@ -171,7 +183,7 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
 
 def workspace(nbytes, device):
     """Stream-ordered scratch: one growing buffer per (device, stream)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, raw_stream(device))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -193,6 +205,7 @@ def set_option(name, value):
     check(lib().wsdl_set_option(name.encode(), int(value)))
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
+    _both_split_cache.clear()          # what the library answered under the old option set
     LAYOUT_EPOCH[0] += 1
     bump_param_epoch()
 
@@ -215,7 +228,7 @@ def amax_slot(device):
     so a roll-over on one stream (a CAM lane, the side stream's aux head) can neither wipe nor pre-date a slot another
     stream is publishing into.  Consumers on other streams read a slot only behind the stream join that orders them
     after its producer (the weight-gradient kernels on the side stream: ``side.wait_stream(main)``)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, raw_stream(device))
     pool = _amax_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
         buf = torch.zeros(AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32)
@@ -1451,7 +1464,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 20
+PROF_NCLASSES = 21
 
 
 def prof_class_name(cls):
