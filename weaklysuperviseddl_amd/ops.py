@@ -26,11 +26,11 @@ def raw_stream(device=None):
 
 
 def _stream():
-    return _vp(_raw_stream(_cur_device()))
+    return _raw_stream(_cur_device())          # an int: the bound functions declare c_void_p (argtypes), ctypes converts
 
 
 def _p(t):
-    return _vp(t.data_ptr()) if t is not None else _vp(0)
+    return t.data_ptr() if t is not None else None      # int / None -> c_void_p by the declared argtypes (no object per argument)
 
 
 def _req(t, name="tensor", dtype=torch.float32):
@@ -181,14 +181,25 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
     return ev                           # recorded behind the last re-layout (None without events)
 
 
-def workspace(nbytes, device):
-    """Stream-ordered scratch: one growing buffer per (device, stream)."""
-    key = (device, raw_stream(device))
+def workspace(nbytes, device, stream=None):
+    """Stream-ordered scratch: one growing buffer per (device, stream).  ``stream``: a raw handle (default: the current one)."""
+    key = (device, raw_stream(device) if stream is None else stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+_size_cache = {}      # (query, geometry) -> bytes: pure functions of the geometry under a fixed option set (cleared by set_option)
+
+
+def _ws_bytes(query, *geom):
+    key = (query, geom)
+    n = _size_cache.get(key)
+    if n is None:
+        n = _size_cache[key] = getattr(lib(), query)(*geom)
+    return n
 
 
 def conv_out_hw(H, W, k, stride, pad, dil):
@@ -206,6 +217,7 @@ def set_option(name, value):
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
     _both_split_cache.clear()          # what the library answered under the old option set
+    _size_cache.clear()
     LAYOUT_EPOCH[0] += 1
     bump_param_epoch()
 
@@ -438,7 +450,7 @@ def conv2d_fwd(x, wt_fwd, wshape, stride, pad, dil, scale=None, shift=None, resi
         residual, res_bs = _planes(residual, "residual")
         if tuple(residual.shape) != (B, Cout, OH, OW):
             raise WsdlError("conv2d: residual shape mismatch")
-    nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 0)
+    nws = _ws_bytes("wsdl_conv2d_igemm_workspace", B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 0)
     ws = workspace(nws, x.device) if nws else None
     y_amax = amax_slot(x.device) if (want_amax and CONV_ARITH[0] == 1) else None
     check(lib().wsdl_conv2d_fwd(_p(x), _p(wt_fwd), _p(out), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
@@ -461,7 +473,7 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     B, Cin, H, W = xshape
     Cout, _, kh, kw = wshape
     dx = accumulate_into if accumulate_into is not None else torch.empty(xshape, device=dy.device, dtype=torch.float32)
-    nws = lib().wsdl_conv2d_igemm_workspace(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 1)
+    nws = _ws_bytes("wsdl_conv2d_igemm_workspace", B, Cin, H, W, Cout, kh, kw, stride, pad, dil, 1)
     ws = workspace(nws, dy.device) if nws else None
     check(lib().wsdl_conv2d_dgrad(_p(dy), _p(wt_dgrad), _p(dx), B, Cin, H, W, Cout, kh, kw, stride, pad, dil,
                                   int(accumulate_into is not None), _p(acc_mask), dy_bs, _p(dy_amax), _p(ws),
@@ -476,7 +488,10 @@ def _wgrad_split(wshape):
     return CONV_ARITH[0] == 1 and wshape[0] % 128 == 0 and wshape[1] % 128 == 0
 
 
-def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None):
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None, stream=None):
+    """``stream``: raw handle of the stream to launch on (default: the current stream) - the side-stream launches of the
+    training step pass it instead of switching torch's current stream (a ``with torch.cuda.stream()`` costs the host ~20 us,
+    61 times per step)."""
     if x_amax is None:
         x_amax = amax_of(x, _wgrad_split(wshape))
     if dy_amax is None:
@@ -486,15 +501,15 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_
     B, Cin, H, W = x.shape
     Cout, _, kh, kw = wshape
     geom = (B, Cin, H, W, Cout, kh, kw, stride, pad, dil)
-    nbytes = lib().wsdl_conv2d_wgrad_workspace(*geom)
+    nbytes = _ws_bytes("wsdl_conv2d_wgrad_workspace", *geom)
     if nbytes == 0:
         raise WsdlError("conv2d_wgrad: bad geometry " + repr(geom))
-    ws = workspace(nbytes, x.device)
+    ws = workspace(nbytes, x.device, stream)
     if out is None:
         out = torch.empty(wshape, device=x.device, dtype=torch.float32)
         accumulate = False
     check(lib().wsdl_conv2d_wgrad(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
-                                  _p(ws), ws.numel(), _stream()))
+                                  _p(ws), ws.numel(), _stream() if stream is None else stream))
     return out
 
 
@@ -533,9 +548,9 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
         y_bs = Cc * H * W
     else:
         out, y_bs = _planes(out, "out")
-    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
-    invstd = torch.empty_like(mean)
-    ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
+    stats = torch.empty(2, Cc, device=x.device, dtype=torch.float32)      # one allocation for the two saved statistics
+    mean, invstd = stats.unbind(0)
+    ws = workspace(_ws_bytes("wsdl_bn_workspace", Cc), x.device)
     if residual is not None:
         residual = _dense(residual, "residual")
     # amax_into: a slot shared by several producers (the branches of a concatenation: the maximum over all of them)
@@ -578,7 +593,7 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(Cc, device=x.device, dtype=torch.float32)
     dres = torch.empty_like(x) if want_dres else None
-    ws = workspace(lib().wsdl_bn_workspace(Cc), x.device)
+    ws = workspace(_ws_bytes("wsdl_bn_workspace", Cc), x.device)
     dx_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if mode == 1 else None), _p(gamma),
                                   _p(_dense(beta) if mode == 2 else None), _p(mean), _p(invstd), _p(dx),
@@ -651,9 +666,9 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
     if OVERLAP_WGRAD[0] and not (last and LAST_WGRAD_ON_MAIN[0]):
         main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
         side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
-        with torch.cuda.stream(side):
-            conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                         dy_amax=dy_amax)
+        # launched ON the side stream by handle: torch's current stream stays the main one
+        conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
+                     dy_amax=dy_amax, stream=side.cuda_stream)
         x.record_stream(side)                       # keep the caching allocator from recycling them early
         dconv.record_stream(side)
     else:
