@@ -662,11 +662,32 @@ def main():
         "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5), "issue_ms_per_step": round(host_issue_s / args.steps * 1e3, 3),
                  "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
     }
+    # optimiser tail on the main stream (join with the weight-gradient / collective stream + Adam), in a short pass of its
+    # own: two event records per step are kept out of the timed region
+    opt.time_tail = True
+    for _ in range(5):
+        step()
+    opt.time_tail = False
+    tail = opt.tail_ms()
+    issue_by_rank = [round(host_issue_s / args.steps * 1e3, 3)]
+    if dp_on and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, issue_by_rank[0])
+        issue_by_rank = gathered
+    result["host"]["issue_ms_per_step_by_rank"] = issue_by_rank
+    result["optimizer_tail_ms"] = None if tail is None else round(tail, 4)
+    result["streams"] = ops.stream_census(device)
     if dp_on:
         plan = reducer.comm_budget()
         result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches,
                         "control_exchanges": {"blocking": reducer.control_exchanges_blocking,
                                               "asynchronous_one_step_behind": reducer.control_exchanges_async},
+                        "exposed_ms": None if tail is None else round(tail, 4),
+                        "exposed_ms_is": "main-stream time per step from the last backward kernel to the parameters being written "
+                                         "(5 steps after the timed region): the wait for the gradient collectives that did not overlap "
+                                         "backward + the last Adam segment.  The same region of a plain single-process run is its "
+                                         "`optimizer_tail_ms` (join with the weight-gradient stream + one Adam launch, ~0.3 ms): the "
+                                         "difference is the exposed communication",
                         "bucket_plan": plan,
                         "exposed_bucket": plan[0] if plan else None,
                         "note": "bucket_plan: bytes per all-reduce (launch order: last bucket first, from gradient-ready hooks) and "

@@ -148,8 +148,20 @@ def _worker_rccl_single(rank, world, port, out, early):
         early.append(red.last_early_launches)
     average_bn_buffers([model])
     torch.cuda.synchronize()
-    torch.save({"params": opt.flat_param.detach().cpu(), "losses": losses, "early": early,
-                "buckets": len(red.bucket_size)}, out)
+    # a data-parallel process must not keep more streams busy than it has hardware queues (4): main + side + prep + RCCL's own
+    # are four already, so the LayerCAM lanes beyond the second take turns on the side / prep stream instead of a fifth stream
+    from weaklysuperviseddl_amd import ops
+    census_before = ops.stream_census(dev)
+    lanes = [ops.lane_stream(dev, i) for i in range(4)]
+    census = ops.stream_census(dev)
+    params = opt.flat_param.detach().cpu()             # after the three steps the plain process is compared with
+    opt.time_tail = True
+    train_step(model, opt, img, masks)
+    opt.time_tail = False
+    tail = opt.tail_ms()
+    torch.save({"params": params, "losses": losses, "early": early,
+                "buckets": len(red.bucket_size), "census_before": census_before, "census": census,
+                "lane_ids": [st.cuda_stream for st in lanes], "tail_ms": tail}, out)
     dist.destroy_process_group()
 
 
@@ -172,6 +184,16 @@ def test_single_rank_rccl_path_equals_the_plain_step(dev, tmp_path, early):
     assert got["losses"] == losses
     assert torch.equal(got["params"], opt.flat_param.detach().cpu())
     assert got["buckets"] >= 5 and got["early"][-1] == got["buckets"]   # every bucket left from a hook once the aux head was known
+    # streams of the data-parallel process: never more than the hardware queues; lanes 2, 3 reuse the side / prep stream
+    assert got["census_before"]["rccl"] == 1 and got["census_before"]["total"] <= 4, got["census_before"]
+    assert got["census"]["total"] <= got["census"]["hw_queues"] == 4, got["census"]
+    assert got["census"]["lanes"] == 0 and len(set(got["lane_ids"])) == 2, (got["census"], got["lane_ids"])
+    assert got["tail_ms"] is not None and 0.0 < got["tail_ms"] < 50.0
+    # a plain process has room for one lane stream of its own (main + side + prep + one)
+    from weaklysuperviseddl_amd import ops
+    st = [ops.lane_stream(dev, i).cuda_stream for i in range(5)]
+    c = ops.stream_census(dev)
+    assert c["rccl"] == 0 and c["total"] <= 4 and c["lanes"] == 1 and len(set(st)) == 3, (c, st)
 
 
 def test_early_segment_steps_equal_the_single_launch_step(dev):

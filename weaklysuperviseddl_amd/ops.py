@@ -273,8 +273,35 @@ def lane_stream(device, i):
         return prep_stream(device)
     more = _lane_streams.setdefault(device, [])
     while len(more) < i - 1:
+        if stream_census(device)["total"] >= MAX_HW_QUEUES:
+            # no fifth stream: it would share a hardware queue with one of the four (and, in a data-parallel process, slow the
+            # gradient collectives or the weight gradients down with it).  Further lanes take turns on the side / prep stream.
+            return (side_stream(device), prep_stream(device))[i % 2]
         more.append(torch.cuda.Stream(device=device))
     return more[i - 2]
+
+
+MAX_HW_QUEUES = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))     # hardware queues of a ROCm process (the runtime's own switch)
+
+
+def stream_census(device):
+    """The streams this process keeps busy on ``device``: torch's current (default) stream, the library's side / prep / lane
+    streams, and - once a process group with the nccl (RCCL) backend exists - the stream RCCL enqueues its collectives on.
+    A ROCm process has ``MAX_HW_QUEUES`` hardware queues (4); a stream beyond them shares one, i.e. runs behind another
+    stream's work (measured: three LayerCAM lanes 0.185 -> 0.27 ms/img with a fifth stream in use, profiles/r03_notes.md).
+    ``lane_stream`` refuses to create the fifth; tests/test_hip_dp.py checks the count in a data-parallel process."""
+    device = device if isinstance(device, torch.device) else torch.device(device)
+    c = {"main": 1, "side": int(device in _side_streams), "prep": int(device in _prep_streams),
+         "lanes": len(_lane_streams.get(device, [])), "rccl": 0}
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            c["rccl"] = 1
+    except Exception:        # a process group that is being torn down
+        pass
+    c["total"] = sum(c.values())
+    c["hw_queues"] = MAX_HW_QUEUES
+    return c
 
 
 def library_streams(device):

@@ -199,7 +199,30 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
 
+    def tail_ms(self):
+        """Mean main-stream time of the optimiser tail over the steps taken while ``time_tail`` was set: from the entry of
+        ``step()`` (backward's last main-stream kernel is enqueued) to its exit (the parameters are written: the next forward
+        may start).  Single process: the join with the weight-gradient stream + Adam.  Under ``GradBucketReducer``: also what
+        the main stream waits for the gradient collectives - the EXPOSED communication is this figure minus the
+        single-process one."""
+        pairs, self._tail_events = getattr(self, "_tail_events", []), []
+        if not pairs:
+            return None
+        torch.cuda.synchronize(self.flat_param.device)
+        return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
     def step(self):
+        if getattr(self, "time_tail", False) and self.flat_param.is_cuda and not self.capture_mode:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                return self._step()
+            finally:
+                e1.record()
+                self.__dict__.setdefault("_tail_events", []).append((e0, e1))
+        return self._step()
+
+    def _step(self):
         if self.pre_step_hook is not None:
             self.pre_step_hook()
         if self.segments is not None:
