@@ -52,8 +52,6 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   conv_split     1*  0 = forward / input-gradient convolutions on the exact-fp32 MFMA kernels everywhere
  *   wgrad_split    1*  0 = weight gradients on the exact-fp32 MFMA kernels everywhere
  *   tile256        1*  256x128 workgroup tiles (512 threads) where they still give >= 256 workgroups
- *   t256_bk32      0*  K chunks of 32 in the 256x128 form (faster per kernel, 1-2.6 % slower per step: registers / LDS left for
- *                      the weight-gradient workgroups running beside it)
  *   split_bk32     1*  K chunks of 32 in the small-tile split forms;   bk32  1*  same for the fp32 kernels
  *   ksplit_big     1*  128x128 tiles + 2 K slices for grids of 200..399 tiles with K >= 2048
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
@@ -78,7 +76,7 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   wgrad_direct   1*  fp16x2 weight-gradient kernel with the x operand's MFMA fragments loaded straight from global memory (no LDS, no
  *                      lane exchange for x; dY double-buffered in LDS, one barrier per chunk) where OW % 32 == 0, stride 1 and every
  *                      tap's column shift is a multiple of 4 elements (1x1, dilation 4 / 12 / 24 / 36): 7-10 % faster there, bit-identical;
- *                      2 = also for misaligned taps (a third 16-byte load per tile: 0-7 % slower), 0 = the LDS-staged kernel everywhere
+ *                      0 = the LDS-staged kernel everywhere
  *   wgrad_dyraw    1*  the direct-fragment kernel reads dY as fp32 and splits it while staging (no dy_split16 pre-pass) for 1x1 convolutions
  *                      with at most 10 N tiles (7-11 % faster there); 2 = for every launch of that kernel (3x3: 7-21 % slower), 0 = never
  *   stem_kernel    1*  7x7 stride-2 convolution of 3 -> 64 channels (ResNet's conv1) on its own kernel: input patch and all weights
@@ -90,7 +88,9 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      is bit-identical to the reference's torch-CPU arithmetic on identical inputs.  32 = torch built for AVX-512
  *                      (the fixtures, the GPU boxes' hosts), 16 = an AVX2 torch, 0 = the cascade for every pixel
  * (Options measured slower and removed in round 3: conv_glds - weights by LDS-DMA; wgrad_wide - 8-pixel-run staging of x;
- *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.)
+ *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.  Round 4: t256_bk32 - K chunks of 32
+ *  in the 256x128 form (1-2.6 % slower per step); wgrad_direct = 2 - the direct-fragment weight gradient for misaligned taps (0-7 %
+ *  slower, spills).)
  * (* = default). */
 int wsdl_set_option(const char* name, int value);
 

@@ -1307,27 +1307,16 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
 
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
-int g_t256_bk32 = 0;      // K chunks of 32 in the 256x128 form: +3.5 % per kernel on the bf16x3 kernel, but with fp16x2 the 16-deep
-                          // form (119 registers, 61 KB of LDS against 169 / 99-111 KB) wins 1-2.6 % on the STEP (818.6 -> 828.2,
-                          // 824 -> 845 img/s on two boxes): it leaves room for the weight-gradient workgroups beside it
+// (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
+// alone (+3.5 % per kernel), 1-2.6 % slower on the STEP, where it leaves no room for the weight-gradient workgroups beside it
+// (818.6 -> 828.2, 824 -> 845 img/s on two boxes with the 16-deep form, profiles/r02_notes.md).  Removed.)
 int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    // bit 0: forward launches (p.bh > 0), bit 1: input-gradient launches (tap step negated)
-    const bool bk32 = (g_t256_bk32 & (p.bh < 0 ? 2 : 1)) && p.Cin % 32 == 0;
-    if (g_conv_arith == 2) {
-        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 2, true>), grid, dim3(512), 0, s, p);
-        else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 2>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2>), grid, dim3(512), 0, s, p);
-    } else if (g_conv_arith) {
-        if (bk32 && g_conv_mfma16) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1, true>), grid, dim3(512), 0, s, p);
-        else if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 1>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
-    } else {
-        if (bk32) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 32, 512, 0>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
-    }
+    if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2>), grid, dim3(512), 0, s, p);
+    else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -1752,7 +1741,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
-    if (!strcmp(name, "t256_bk32")) { g_t256_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "conv_mfma16")) { g_conv_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
@@ -2030,7 +2018,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         // timing class of its own
         bool taps_aligned = true;
         for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
-        const bool direct = chunk32 && g_conv_arith && g_wgrad_mfma16 && g_wgrad_direct && (taps_aligned || g_wgrad_direct == 2) &&
+        const bool direct = chunk32 && g_conv_arith && g_wgrad_mfma16 && g_wgrad_direct && taps_aligned &&
                             stride == 1 && OW % 32 == 0 && W % 4 == 0 && (H * W) % 4 == 0 && p.x_bs % 4 == 0 &&
                             reinterpret_cast<uintptr_t>(x) % 16 == 0;
         wsdl::ProfScope prof(direct ? WSDL_PROF_WGRAD_SPLIT16D
@@ -2070,8 +2058,8 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     if (g_wgrad_mfma16) {
                         // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
                         // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
-                        // with a third load for misaligned taps (dilation 1, 2) it is 0-7 % slower than the LDS-staged kernel
-                        // (wgrad_direct = 2 forces it for those too)
+                        // with a third load for misaligned taps (dilation 1, 2) it was 0-7 % slower than the LDS-staged kernel (256
+                        // registers + spills): that instantiation was removed in round 4
                         // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
                         // kernel on l3.conv2: the third load's registers spill; not used)
                         if (direct) {
@@ -2088,11 +2076,8 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                             if (dyraw)
                                 hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true>), grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
-                            else if (taps_aligned)
-                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
-                                                   (unsigned)dys_bytes, dy_amax);
                             else
-                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<3>, grid, dim3(kThreads), 0, s, p, dys,
+                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                    (unsigned)dys_bytes, dy_amax);
                         } else {
                             hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);

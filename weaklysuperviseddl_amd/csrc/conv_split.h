@@ -1227,9 +1227,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 // goes through LDS, now double-buffered with ONE barrier per chunk.  Per chunk and thread: 8 vector loads instead of 20,
 // 4 LDS stores instead of 20.  Elements whose input column lies outside the image are zeroed by selects (the loads
 // themselves cannot fault: buffer descriptor).
-// MODE (checked by the host): 0 - every tap's column shift is a multiple of 4 elements, only the aligned loop is compiled in (237
-// registers); 3 - any shift (four loops: 256 registers and spills - the A/B partner of the LDS-staged kernel for dilation 1 and
-// 2, not the default anywhere; a two-loop form for dilation 2 spilled as well: 128 us against 112 on l3.conv2).
+// MODE 0 (checked by the host): every tap's column shift is a multiple of 4 elements - the aligned loop, 237 registers.  (A form
+// for any shift - a third 16-byte load per tile and one loop instance per shift, 256 registers and spills - was 0-7 % slower than
+// the LDS-staged kernel on the dilation-1 / 2 shapes it was for and was removed in round 4; the SH template plumbing of `run`
+// is what is left of it.)
 // DYRAW: dY is read as fp32 from the tensor itself (p.dy) and split by the staging threads on its way into LDS - no
 // dy_split16_kernel pre-pass for the launch (it re-reads and re-writes dY once per layer; here every N tile's workgroup
 // splits its 128 x 32 slice again: 8 splits per thread and chunk).
@@ -1454,16 +1455,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
             step(S1{});
         }
     };
-    if constexpr (MODE == 0) {
-        run(std::integral_constant<int, 0>{});
-    } else {
-        switch (t_dw & 3) {
-            case 0: run(std::integral_constant<int, 0>{}); break;
-            case 1: run(std::integral_constant<int, 1>{}); break;
-            case 2: run(std::integral_constant<int, 2>{}); break;
-            default: run(std::integral_constant<int, 3>{}); break;
-        }
-    }
+    static_assert(MODE == 0, "only the aligned loop is instantiated (the misaligned-tap loops were removed in round 4)");
+    run(std::integral_constant<int, 0>{});
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
 #pragma unroll
