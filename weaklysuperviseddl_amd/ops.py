@@ -291,6 +291,8 @@ def stream_census(device):
     stream's work (measured: three LayerCAM lanes 0.185 -> 0.27 ms/img with a fifth stream in use, profiles/r03_notes.md).
     ``lane_stream`` refuses to create the fifth; tests/test_hip_dp.py checks the count in a data-parallel process."""
     device = device if isinstance(device, torch.device) else torch.device(device)
+    if device.index is None:
+        device = torch.device(device.type, _cur_device())
     c = {"main": 1, "side": int(device in _side_streams), "prep": int(device in _prep_streams),
          "lanes": len(_lane_streams.get(device, [])), "rccl": 0}
     try:
@@ -691,6 +693,9 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
     x_amax = x_amax if x_amax is not None else amax_of(x, split)       # resolved on the MAIN stream (may launch a pass)
     dy_amax = amax_of(dconv, split)
     if OVERLAP_WGRAD[0] and not (last and LAST_WGRAD_ON_MAIN[0]):
+        # a densifying copy (never needed by the training step's own tensors) would be enqueued on the CURRENT stream: make it
+        # happen before the side stream's wait, not inside conv2d_wgrad behind it
+        x, dconv = _planes(x, "x")[0], _planes(dconv, "dy")[0]
         main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
         side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
         # launched ON the side stream by handle: torch's current stream stays the main one
