@@ -113,22 +113,28 @@ __global__ void layercam_partial_kernel(CamLayers L, float* __restrict__ ws) {
     }
 }
 
-// upper levels of ATen's cascade over `nfull` level-0 sums read at `stride`, plus the left-over sum (`has_left`)
+// upper levels of ATen's cascade over `nfull` level-0 sums read at `stride`, plus the left-over sum (`has_left`).  Level 1 takes 16
+// level-0 sums and is flushed into level 2 exactly every 16 of them (i = 256, 512, ...), so the loop runs over whole level-1
+// blocks: 16 independent loads in flight, then the 16 ordered additions (a load per addition made the kernel latency-bound:
+// 35 us for sixteen workgroups).
 __device__ __forceinline__ float cascade_upper(const float* __restrict__ v, long long stride, int nfull, bool has_left) {
     float acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
-    for (int q = 0; q < nfull; ++q) {
-        acc1 = rn_add(acc1, v[q * stride]);
-        const int i = (q + 1) * kL0;
-        if ((i & 0xF0) == 0) {
-            acc2 = rn_add(acc2, acc1);
-            acc1 = 0.f;
-            if ((i & 0xF00) == 0) {
-                acc3 = rn_add(acc3, acc2);
-                acc2 = 0.f;
-            }
+    int q = 0;
+    for (; q + kL0 <= nfull; q += kL0) {
+        float t[kL0];
+#pragma unroll
+        for (int j = 0; j < kL0; ++j) t[j] = v[(long long)(q + j) * stride];
+#pragma unroll
+        for (int j = 0; j < kL0; ++j) acc1 = rn_add(acc1, t[j]);
+        acc2 = rn_add(acc2, acc1);                 // i = 16 (q + 16) is a multiple of 256
+        acc1 = 0.f;
+        if ((((q + kL0) * kL0) & 0xF00) == 0) {    // ... and of 4096
+            acc3 = rn_add(acc3, acc2);
+            acc2 = 0.f;
         }
     }
-    const float acc0 = has_left ? v[nfull * stride] : 0.f;
+    for (; q < nfull; ++q) acc1 = rn_add(acc1, v[(long long)q * stride]);      // < 16 sums: no flush falls in here
+    const float acc0 = has_left ? v[(long long)nfull * stride] : 0.f;
     return rn_add(rn_add(rn_add(acc0, acc1), acc2), acc3);
 }
 
