@@ -222,3 +222,53 @@ def test_bench_wait_ranks_stops_everyone_when_one_rank_fails():
     # deadline: ranks still running are stopped and reported as failed
     procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(60)"], stdout=subprocess.PIPE)]
     assert bench.wait_ranks(procs, timeout_s=1.0)[0] != 0
+
+
+def test_generate_coalesced_merges_and_splits_batches_on_the_host():
+    """``LayerCAMGenerator.generate_coalesced`` (the loop of ``generate_pseudo_masks``): loader batches are merged into device
+    batches of at most ``device_batch`` images - never across different image shapes or across a batch with / without class
+    indices - and the results come back per loader batch, in order.  Host logic only: the device work is replaced by a stub
+    that returns each image's first pixel and class index."""
+    import torch
+    from weaklysuperviseddl_amd.TraditionalModel.LayerCAM import LayerCAMGenerator
+    gen = object.__new__(LayerCAMGenerator)
+    seen = []
+
+    def fake_batches(batches, alpha, class_idxs, thresh, streams):
+        outs = []
+        for b, c in zip(batches, class_idxs):
+            seen.append((b.shape[0], tuple(b.shape[1:]), None if c is None else c.numel()))
+            tag = b.flatten(1)[:, 0]
+            cam = tag.view(-1, 1, 1).expand(-1, 2, 2).clone()
+            mask = (c.view(-1, 1, 1).expand(-1, 2, 2).to(torch.uint8) if c is not None else torch.zeros(b.shape[0], 2, 2, dtype=torch.uint8))
+            outs.append((cam, mask))
+        return outs
+
+    gen.generate_batches = fake_batches
+    sizes = [3, 3, 2, 5, 1, 4, 4]
+    batches, classes, k = [], [], 0
+    for n in sizes:
+        batches.append(torch.arange(k, k + n, dtype=torch.float32).view(n, 1, 1, 1).expand(n, 3, 4, 4).contiguous())
+        classes.append(torch.arange(k, k + n) % 7)
+        k += n
+    # greedy, in order; a loader batch larger than the device batch still travels whole (db = 4: the batch of 5)
+    for db, want in ((8, [8, 6, 8]), (32, [22]), (4, [3, 3, 2, 5, 1, 4, 4]), (5, [3, 5, 5, 5, 4])):
+        seen.clear()
+        outs = gen.generate_coalesced(batches, 1.0, classes, 0.3, streams=3, device_batch=db)
+        assert [s[0] for s in seen] == want, (db, seen)
+        assert len(outs) == len(sizes)
+        k = 0
+        for n, (cam, mask) in zip(sizes, outs):
+            assert cam.shape == (n, 2, 2) and mask.shape == (n, 2, 2)
+            assert cam[:, 0, 0].tolist() == list(range(k, k + n))                  # every image came back in its place
+            assert mask[:, 0, 0].tolist() == [(k + i) % 7 for i in range(n)]         # ... with its own class index
+            k += n
+    # different shapes / missing class indices are never merged; device_batch=0 and a single batch fall through
+    seen.clear()
+    mixed = [torch.zeros(2, 3, 4, 4), torch.zeros(2, 3, 8, 8), torch.zeros(2, 3, 8, 8), torch.zeros(1, 3, 8, 8)]
+    cls = [torch.zeros(2, dtype=torch.long), torch.zeros(2, dtype=torch.long), None, None]
+    outs = gen.generate_coalesced(mixed, 1.0, cls, None, streams=2, device_batch=32)
+    assert [(s[0], s[1][-1], s[2]) for s in seen] == [(2, 4, 2), (2, 8, 2), (3, 8, None)] and [o[0].shape[0] for o in outs] == [2, 2, 2, 1]
+    seen.clear()
+    gen.generate_coalesced(batches, 1.0, classes, 0.3, streams=3, device_batch=0)
+    assert [s[0] for s in seen] == sizes
