@@ -174,6 +174,40 @@ def test_full_size_training_steps(dev):
     assert l1 == l2 and torch.equal(g1, g2) and torch.equal(p1, p2)     # no atomics anywhere: bitwise reproducible
 
 
+def test_training_steps_under_the_range_guard(dev):
+    """`conv_arith = 2` (the fp16x2 range guard: forward / input gradient with the low piece at 2^11) through the whole training
+    step - weight layouts from the multi-launch re-layout, four steps at B=8, 256x256: finite, bitwise reproducible, and on
+    ordinary data the same training as the default arithmetic to fp32 noise (the first loss within 1e-5 relative)."""
+    import bench
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    from weaklysuperviseddl_amd import nn as wnn
+
+    def run():
+        torch.manual_seed(0)
+        model = build_segmentation_model().to(dev).train()
+        for m in model.modules():
+            if isinstance(m, wnn.Dropout):
+                m.p = 0.0
+        opt = make_optimizer(model, lr=1e-4)
+        img, masks = bench.synthetic_batch(8, 256, 256, dev, 1)
+        losses = [train_step(model, opt, img, masks).item() for _ in range(4)]
+        return losses, opt.flat_param.clone()
+
+    base, _ = run()
+    ops.set_option("conv_arith", 2)
+    try:
+        l1, p1 = run()
+        l2, p2 = run()
+    finally:
+        ops.set_option("conv_arith", 1)
+    assert all(np.isfinite(l1)) and torch.isfinite(p1).all()
+    assert l1 == l2 and torch.equal(p1, p2)
+    assert abs(l1[0] - base[0]) <= 1e-5 * abs(base[0]), (l1, base)
+    assert abs(l1[-1] - base[-1]) <= 2e-2 * abs(base[-1]), (l1, base)     # four Adam sign-steps later: same trajectory
+
+
 def _run_config(dev, B, S, extra_of, steps=8):
     import bench
     from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
