@@ -677,6 +677,9 @@ def main():
     result["host"]["issue_ms_per_step_by_rank"] = issue_by_rank
     result["optimizer_tail_ms"] = None if tail is None else round(tail, 4)
     result["streams"] = ops.stream_census(device)
+    if dp_on and dist.get_backend() != "nccl":
+        result["config"]["rehearsal"] = ("ranks share the GPU(s) and the gradients travel over gloo through host memory: a rehearsal "
+                                         "of the data-parallel code path, not a performance figure")
     if dp_on:
         plan = reducer.comm_budget()
         result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches,
