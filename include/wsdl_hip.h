@@ -57,11 +57,6 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
  *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
- *   wgrad_mfma16   1*  fp16x2 weight-gradient kernel on v_mfma_f32_16x16x32_f16 (swizzled 128-byte LDS rows): -6 % on the
- *                      kernel sweep, +2 % img/s against the 32x32x16 form (0); same accuracy against float64
- *   conv_mfma16    1*  the same MFMA shape in the forward / input-gradient kernels (K chunk 32): neutral on the isolated kernel
- *                      sweep (-2..-3.6 % on the layer4 shapes, +1.6 % on layer3 3x3 and ASPP d12), +2.2 % img/s on the step
- *                      (784.7 -> 802.1, three same-box pairs) - under the power limit it leaves more to the kernels beside it
  *   wgrad_min_tiles 6*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles on (1: the layer2 1x1
  *                      kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches)
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
@@ -90,7 +85,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  * (Options measured slower and removed in round 3: conv_glds - weights by LDS-DMA; wgrad_wide - 8-pixel-run staging of x;
  *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.  Round 4: t256_bk32 - K chunks of 32
  *  in the 256x128 form (1-2.6 % slower per step); wgrad_direct = 2 - the direct-fragment weight gradient for misaligned taps (0-7 %
- *  slower, spills).)
+ *  slower, spills); conv_mfma16 / wgrad_mfma16 = 0 - the 32x32x16 MFMA shape in the K-chunk-32 forward forms and in the fp16x2 weight
+ *  gradient (2.2 % / 2 % slower on the step; v_mfma_f32_16x16x32_f16 is what those kernels run on).)
  * (* = default). */
 int wsdl_set_option(const char* name, int value);
 

@@ -8,8 +8,7 @@ from weaklysuperviseddl_amd import ops
 from test_hip_ops import _region_maxnorm_ratio, MODES
 dev = torch.device("cuda:0")
 MODES = dict(MODES)
-MODES["fp16x2s"] = dict(conv_split=1, wgrad_split=1, conv_arith=2, conv_mfma16=1, wgrad_mfma16=1)
-MODES["fp16x2s-32"] = dict(conv_split=1, wgrad_split=1, conv_arith=2, conv_mfma16=0, wgrad_mfma16=1)
+MODES["fp16x2s"] = dict(conv_split=1, wgrad_split=1, conv_arith=2)
 g = torch.Generator().manual_seed(78)
 for data in ("unit", "outlier20", "outlier30", "outlier35", "outlier40", "graded30", "graded40"):
     for Cin, Cout, k, s, d, H, B in [(256, 256, 3, 1, 2, 32, 4), (1024, 256, 1, 1, 1, 16, 4)]:
@@ -27,7 +26,7 @@ for data in ("unit", "outlier20", "outlier30", "outlier35", "outlier40", "graded
         ref = F.conv2d(x.double(), w.double(), None, s, pad, d)
         ref_dx = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), s, pad, d)
         ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), s, pad, d)
-        for mode in ("fp32", "bf16x3", "fp16x2", "fp16x2s", "fp16x2s-32"):
+        for mode in ("fp32", "bf16x3", "fp16x2", "fp16x2s"):
             for o, v in MODES[mode].items():
                 ops.set_option(o, v)
             wf, wdg = ops.prep_weights(w)

@@ -1256,7 +1256,6 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
-int g_conv_mfma16 = 1;    // fp16x2 forward / input-gradient kernels with K chunk 32 on v_mfma_f32_16x16x32_f16
 int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
@@ -1276,30 +1275,19 @@ int choose_xcd_py(const ConvP& p, int gx, int gy) {
     return best;
 }
 
+// fp16x2 with K chunks of 32 runs on v_mfma_f32_16x16x32_f16 (MF): the 32x32x16 form of those small-tile configurations was an
+// A/B option until round 4 ("conv_mfma16 = 0": neutral alone, 2.2 % slower on the step) and is no longer compiled.
 template <int BM, int BN, int WM, int BK>
 int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    if (g_conv_arith == 2) {
-        if constexpr (BK == 32) {
-            if (g_conv_mfma16) {
-                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2, true>), grid, dim3(kThreads), 0, s, p);
-                WSDL_LAUNCH_CHECK();
-                return WSDL_OK;
-            }
-        }
-        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2>), grid, dim3(kThreads), 0, s, p);
-    } else if (g_conv_arith) {
-        if constexpr (BK == 32) {
-            if (g_conv_mfma16) {
-                hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, true>), grid, dim3(kThreads), 0, s, p);
-                WSDL_LAUNCH_CHECK();
-                return WSDL_OK;
-            }
-        }
-        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1>), grid, dim3(kThreads), 0, s, p);
-    } else
+    constexpr bool MF = BK == 32;
+    if (g_conv_arith == 2)
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2, MF>), grid, dim3(kThreads), 0, s, p);
+    else if (g_conv_arith)
+        hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 1, MF>), grid, dim3(kThreads), 0, s, p);
+    else
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 0>), grid, dim3(kThreads), 0, s, p);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -1625,7 +1613,8 @@ int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-ch
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
 int g_wgrad_dyraw = 1;       // direct-fragment kernel: dY read as fp32 and split while staged (no dy_split16_kernel pass)
 int g_wgrad_direct = 1;      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
-int g_wgrad_mfma16 = 1;      // split weight-gradient kernel on v_mfma_f32_16x16x32_f16 (fp16x2 arithmetic only)
+// (fp16x2: the split weight-gradient kernels run on v_mfma_f32_16x16x32_f16; the 32x32x16 form - "wgrad_mfma16 = 0", 2 % slower on
+// the step - was an A/B option until round 4.  conv_wgrad_split32_kernel remains as the bf16x3 path.)
 int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
@@ -1635,7 +1624,7 @@ int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradien
 int g_wgrad_min_tiles = 6;     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
 bool wgrad_chunk32(int Cout, int Cin, int N) {
     if (!g_wgrad_split || Cout % 128 != 0 || Cin % 128 != 0) return false;
-    return N / 128 >= ((g_conv_arith && g_wgrad_mfma16) ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
+    return N / 128 >= (g_conv_arith ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
 }
 
 // taps that read at least one in-range input pixel for some output pixel (bit t of the result); the others (dilation
@@ -1742,7 +1731,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
-    if (!strcmp(name, "conv_mfma16")) { g_conv_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_min_chunks")) { g_ksplit_min_chunks = value > 0 ? value : 1; return WSDL_OK; }
@@ -1761,7 +1749,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "wgrad_force_s")) { g_wgrad_force_s = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_split")) { g_wgrad_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_xcd")) { g_wgrad_xcd = value; return WSDL_OK; }
-    if (!strcmp(name, "wgrad_mfma16")) { g_wgrad_mfma16 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_min_tiles")) { g_wgrad_min_tiles = value > 0 ? value : 1; return WSDL_OK; }
     if (!strcmp(name, "wgrad_blocks")) { g_wgrad_blocks = value > 0 ? value : 768; return WSDL_OK; }
     if (!strcmp(name, "wgrad_bk")) { g_wgrad_bk = value == 32 ? 32 : 16; return WSDL_OK; }
@@ -2018,7 +2005,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         // timing class of its own
         bool taps_aligned = true;
         for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
-        const bool direct = chunk32 && g_conv_arith && g_wgrad_mfma16 && g_wgrad_direct && taps_aligned &&
+        const bool direct = chunk32 && g_conv_arith && g_wgrad_direct && taps_aligned &&
                             stride == 1 && OW % 32 == 0 && W % 4 == 0 && (H * W) % 4 == 0 && p.x_bs % 4 == 0 &&
                             reinterpret_cast<uintptr_t>(x) % 16 == 0;
         wsdl::ProfScope prof(direct ? WSDL_PROF_WGRAD_SPLIT16D
@@ -2055,40 +2042,33 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
-                    if (g_wgrad_mfma16) {
-                        // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
-                        // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
-                        // with a third load for misaligned taps (dilation 1, 2) it was 0-7 % slower than the LDS-staged kernel (256
-                        // registers + spills): that instantiation was removed in round 4
-                        // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
-                        // kernel on l3.conv2: the third load's registers spill; not used)
-                        if (direct) {
-                            // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
-                            // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
-                            // workgroup splits its slice again; 7-11 % faster there, 7-21 % slower on the 3x3 shapes with 36-72 N tiles)
-                            const bool dyraw = taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
-                                               (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
-                                               reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
-                            if (!dyraw) {
-                                hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
-                                WSDL_LAUNCH_CHECK();
-                            }
-                            if (dyraw)
-                                hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true>), grid, dim3(kThreads), 0, s, p, dys,
-                                                   (unsigned)dys_bytes, dy_amax);
-                            else
-                                hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
-                                                   (unsigned)dys_bytes, dy_amax);
-                        } else {
+                    // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
+                    // 16-byte loads per tile are then aligned): 1x1 and dilation 4 / 12 / 24 / 36 - 7-10 % faster there;
+                    // with a third load for misaligned taps (dilation 1, 2) it was 0-7 % slower than the LDS-staged kernel (256
+                    // registers + spills): that instantiation was removed in round 4
+                    // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
+                    // kernel on l3.conv2: the third load's registers spill; not used)
+                    if (direct) {
+                        // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
+                        // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
+                        // workgroup splits its slice again; 7-11 % faster there, 7-21 % slower on the 3x3 shapes with 36-72 N tiles)
+                        const bool dyraw = taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
+                                           (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
+                                           reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
+                        if (!dyraw) {
                             hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                             WSDL_LAUNCH_CHECK();
-                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
-                                               (unsigned)dys_bytes, dy_amax);
                         }
+                        if (dyraw)
+                            hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else
+                            hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
                     } else {
-                        hipLaunchKernelGGL(dy_split_kernel<1>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
                         WSDL_LAUNCH_CHECK();
-                        hipLaunchKernelGGL((conv_wgrad_split32_kernel<128, 128, 1>), grid, dim3(kThreads), 0, s, p, dys,
+                        hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
                                            (unsigned)dys_bytes, dy_amax);
                     }
                 } else {
