@@ -12,7 +12,8 @@ from weaklysuperviseddl_amd.optim import FlatAdam  # noqa: E402
 
 
 def timeit(fn, reps=20):
-    fn()
+    for _ in range(3):          # allocator growth at a new size costs milliseconds: not inside the timed calls
+        fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
