@@ -509,10 +509,12 @@ def build_workload(cfg, B, S, device, rank, graph=False):
     if cfg in ("cfg3", "cfg5"):
         ncut = LocalNormalizedCutLoss(0.1, 5)
         if cfg == "cfg3":
-            extra = lambda o, i: 0.1 * ncut(o, i)                                                        # noqa: E731
+            # (ops.scale_mean(x, w) = w * x.mean() as a launch of the library, so that the step's launch plan sees it)
+            extra = lambda o, i: ops.scale_mean(ncut(o, i), 0.1)                                         # noqa: E731
         else:
             bnd = ConstrainToBoundaryLossSingle(0.1, 5, 5)
-            extra = lambda o, i: 0.1 * ncut(o, i) + 0.1 * bnd(ops.softmax_channels(o), i).mean()         # noqa: E731
+            extra = lambda o, i: ops.add_scalars(ops.scale_mean(ncut(o, i), 0.1),                        # noqa: E731
+                                                 ops.scale_mean(bnd(ops.softmax_channels(o), i), 0.1))
     if cfg == "cfg4":
         from weaklysuperviseddl_amd.TraditionalModel import generate_pseudo_masks, stage_handoff
         gen, _, _ = cam_setup(device, 1)
@@ -550,6 +552,11 @@ def build_workload(cfg, B, S, device, rank, graph=False):
     return model, opt, step, step
 
 
+def _plan_on(opt):
+    pst = next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
+    return pst is not None and pst.plan is not None and pst.replays > 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -568,6 +575,7 @@ def main():
                     help="no side-stream overlap anywhere: every kernel has the chip to itself (profiling aid; the "
                          "roofline pass always runs like this)")
     ap.add_argument("--graph", type=int, default=None, help="1/0: force hipGraph replay of the training step on/off")
+    ap.add_argument("--plan", type=int, default=None, help="0: every step eager (no launch-plan replay; the A/B partner)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -580,6 +588,9 @@ def main():
         ops.set_option(k, int(v))
     from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
 
+    if args.plan is not None:
+        from weaklysuperviseddl_amd import plan as _p
+        _p.PLAN_STEP[0] = bool(args.plan)
     if args.cam_only:
         print(json.dumps({"cam": cam_bench(torch.device("cuda", 0), iters=10)}), flush=True)
         return
@@ -657,11 +668,39 @@ def main():
                                  "(tools/conv_accuracy.py); stem / classifier convs on fp32 MFMA",
                    "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
                    "backend": (dist.get_backend() if dp_on else None),
-                   "launch": "hipGraph replay (one host call per step)" if use_graph else "eager (one host call per kernel)",
+                   "launch": ("hipGraph replay (one host call per step)" if use_graph else
+                              "launch-plan replay (one host call per step; see host.launch_plan)" if _plan_on(opt) else
+                              "eager (one host call per kernel)"),
                    "final_loss": round(loss_val, 5)},
-        "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5), "issue_ms_per_step": round(host_issue_s / args.steps * 1e3, 3),
-                 "note": "rank-0 process CPU time and host enqueue time per step (launch overhead; ranks share host cores)"},
+        "host": {"cpu_s_per_step": round(cpu_s / args.steps, 5),
+                 "enqueue_wall_ms_per_step": round(host_issue_s / args.steps * 1e3, 3)},
     }
+    # What the host needs to ISSUE one step: a step call into an EMPTY queue (synchronise, time the call alone), median of 7.
+    # The wall time until K back-to-back steps are enqueued (enqueue_wall_ms_per_step, the figure of earlier rounds) also
+    # contains the runtime's back-pressure: once the host is a few steps ahead, launches block until the GPU has drained
+    # the queue, so a host that issues a step in 2.5 ms reads ~9 ms there (tools/plan_probe.py).
+    singles = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        singles.append(time.perf_counter() - t1)
+    sync_all(world)
+    singles.sort()
+    result["host"]["issue_ms_per_step"] = round(singles[len(singles) // 2] * 1e3, 3)
+    result["host"]["note"] = ("issue_ms_per_step: host time of one step call issued into an empty queue (median of 7, after the timed "
+                              "region); enqueue_wall_ms_per_step: wall time until the K timed steps were enqueued / K - includes the "
+                              "runtime's back-pressure once the host runs ahead of the GPU; cpu_s_per_step: process CPU time of all "
+                              "threads (the runtime's helper threads included)")
+    from weaklysuperviseddl_amd import plan as _plan
+    pst = next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None) if not use_graph else None
+    result["host"]["launch_plan"] = (None if pst is None else
+                                     {"replays": pst.replays, "records": pst.records, "disabled": pst.disabled,
+                                      "ops": None if pst.plan is None else pst.plan.stats,
+                                      "verified": pst.plan is not None,
+                                      "what": "steps after the second are ONE host call: the launches of an eager step recorded behind "
+                                              "the C ABI (wsdl_plan_*), verified bit for bit against an eager step on a probe batch, "
+                                              "then replayed from a C loop (weaklysuperviseddl_amd/plan.py)"})
     # optimiser tail on the main stream (join with the weight-gradient / collective stream + Adam), in a short pass of its
     # own: two event records per step are kept out of the timed region
     opt.time_tail = True
@@ -669,7 +708,7 @@ def main():
         step()
     opt.time_tail = False
     tail = opt.tail_ms()
-    issue_by_rank = [round(host_issue_s / args.steps * 1e3, 3)]
+    issue_by_rank = [result["host"]["issue_ms_per_step"]]
     if dp_on and world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, issue_by_rank[0])

@@ -396,6 +396,57 @@ int wsdl_refine_combine(const float* dkl, const float* dnc, const float* kl, con
 int wsdl_softmax_fwd(const float* x, float* y, int B, int C, int HW, wsdl_stream_t stream);
 int wsdl_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, int HW, wsdl_stream_t stream);
 
+/* ---- launch plans: the reference's training / CAM loops as one host call per iteration ------------------------------
+ * The reference runs its loops statement by statement from Python (one training iteration:
+ * TraditionalModel/AlternatingDirectionCutLoss.py:693-703 = SegmentationModel.py:96-113; one CAM batch:
+ * TraditionalModel/PsuedoMasks.py:47-62); on this path an iteration is ~520 kernel launches on three streams, 10-14 ms of
+ * host time through Python + ctypes against 18.7 ms on the GPU.  A plan records the launches of ANY sequence of the calls of
+ * this header once - function, grid, block, LDS bytes, stream and a private copy of every argument value, plus the
+ * cross-stream dependencies made through the wsdl_event_* / wsdl_stream_wait_* calls below - while the sequence runs in the
+ * ordinary way, and wsdl_plan_replay issues them again from one C loop (csrc/plan.hip).  Same kernels, same arguments,
+ * same order per stream: the results are the recorded sequence's, bit for bit.
+ *   - one recording at a time, process-wide; the recording thread is the only one that may call into the library meanwhile;
+ *   - the caller keeps every buffer the sequence touched alive and at its address for the plan's lifetime, and anything
+ *     that varies from replay to replay on the device (wsdl_adam_step's step_dev, wsdl_dropout_fwd's counter);
+ *   - wsdl_lovasz_softmax_fwd_bwd (rocPRIM launches kernels of its own) poisons a recording: wsdl_plan_end fails;
+ *   - wsdl_plan_mark(tag) cuts the plan into segments: wsdl_plan_replay_segment(plan, k) replays segment k (0 .. marks),
+ *     so the host can do its own work (a gradient collective) at the places it did while recording. */
+int wsdl_plan_begin(void);
+int wsdl_plan_recording(void);                       /* 1 between begin and end */
+int wsdl_plan_end(void** plan_out);                  /* error (and no plan) if the sequence cannot be replayed */
+int wsdl_plan_abort(void);                           /* drop the recording in progress */
+int wsdl_plan_mark(long long tag);
+int wsdl_plan_poison(const char* why);               /* the caller did something between begin and end that a replay would miss */
+int wsdl_plan_replay(void* plan);
+int wsdl_plan_replay_segment(void* plan, int segment);
+/* diagnostic twin of wsdl_plan_replay: host microseconds inside the runtime and the count per kind of operation, six
+ * entries each (0 kernel launch, 1 memset, 2 stream-waits-for-stream, 3 event record, 4 event wait, 5 mark) */
+int wsdl_plan_replay_timed(void* plan, double* us_by_kind, long long* n_by_kind);
+int wsdl_plan_stats(void* plan, long long* kernels, long long* memsets, long long* stream_waits, long long* events,
+                    long long* marks);
+long long wsdl_plan_mark_tag(void* plan, int i);
+int wsdl_plan_destroy(void* plan);
+/* Stream ordering through the library, so that a plan sees it: events (no timing), "stream waits for event", and
+ * "waiter waits for everything enqueued on waited so far".  Outside a recording they are the plain runtime calls. */
+int wsdl_event_create(void** ev);
+int wsdl_event_destroy(void* ev);
+int wsdl_event_record(void* ev, wsdl_stream_t stream);
+int wsdl_stream_wait_event(wsdl_stream_t stream, void* ev);
+int wsdl_stream_wait_stream(wsdl_stream_t waiter, wsdl_stream_t waited);
+/* The few stream-ordered helpers a training step used the tensor library's own kernels for (a plan records launches of
+ * THIS library only): memset, *p += delta for a device int32 / int64 (Adam's step number, the dropout call counters),
+ * out[i] = a[i] * b[i] (the loss scale of the cross-entropy backward), y = min(x, hi) for int64 labels
+ * (torch.clamp(masks, max=1), reference SegmentationModel.py:100). */
+int wsdl_memset_async(void* dst, int value, size_t bytes, wsdl_stream_t stream);
+int wsdl_add_int(void* p, int is64, long long delta, wsdl_stream_t stream);
+int wsdl_mul(const float* a, const float* b, float* out, int n, wsdl_stream_t stream);
+int wsdl_clamp_max_i64(const long long* x, long long* y, long long n, long long hi, wsdl_stream_t stream);
+/* Weighted loss terms without the tensor library: out[0] = w * mean(x[0..n)) (the "0.1 * ncut" / "0.1 * boundary.mean()" of the
+ * reference's combined losses, AlternatingDirectionBoundaryLoss.py:196-200; fixed summation order) and its gradient
+ * out[i] = g[0] * c (c = w / n).  The sum of terms is wsdl_add. */
+int wsdl_scale_mean(const float* x, int n, float w, float* out, wsdl_stream_t stream);
+int wsdl_scale_fill(const float* g, float c, float* out, int n, wsdl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

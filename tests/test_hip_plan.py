@@ -1,0 +1,261 @@
+"""Launch plans (include/wsdl_hip.h "launch plans", weaklysuperviseddl_amd/plan.py): a recorded launch sequence replayed
+from one C loop must reproduce the eager path bit for bit - kernel for kernel the same launches - and a training step
+that contains work a plan cannot see must be detected and stay eager."""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _batch(B, S, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(B, 3, S, S, generator=g)
+    masks = (torch.rand(B, S, S, generator=g) > 0.5).long() * 255          # the reference's PNG masks: {0, 255}, clamped to {0, 1}
+    return img.to(dev), masks.to(dev)
+
+
+def _model_and_opt(dev, seed=0):
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    torch.manual_seed(seed)
+    model = build_segmentation_model().to(dev).train()
+    return model, make_optimizer(model, lr=1e-4)
+
+
+def _state(model, opt):
+    return [opt.flat_param.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()] + [b.clone() for b in model.buffers()]
+
+
+def _run(dev, planned, steps, batches, seed=0, **kw):
+    from weaklysuperviseddl_amd import plan
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    old = plan.PLAN_STEP[0]
+    plan.PLAN_STEP[0] = planned
+    try:
+        model, opt = _model_and_opt(dev, seed)
+        # identical dropout draws in both runs: the host seed of a Dropout module is drawn from torch's generator
+        torch.manual_seed(1234)
+        losses = []
+        for i in range(steps):
+            img, m = batches[i % len(batches)]
+            losses.append(train_step(model, opt, img, m, **kw))
+        torch.cuda.synchronize()
+        st = next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
+        return model, opt, [float(l) for l in losses], st
+    finally:
+        plan.PLAN_STEP[0] = old
+
+
+def test_record_and_replay_a_small_sequence(dev):
+    """conv -> BatchNorm(train) -> conv weight gradient on the side stream: the replay writes what the recording wrote."""
+    from weaklysuperviseddl_amd import ops, plan
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(4, 64, 32, 32, device=dev, generator=g)
+    w = torch.randn(128, 64, 3, 3, device=dev, generator=g) * 0.05
+    gamma, beta = torch.rand(128, device=dev, generator=g) + 0.5, torch.randn(128, device=dev, generator=g)
+    rm, rv = torch.zeros(128, device=dev), torch.ones(128, device=dev)
+    wf, _ = ops.prep_weights(w, True, False)
+    dw = torch.zeros_like(w)
+
+    def seq():
+        y = ops.conv2d_fwd(x, wf, w.shape, 1, 1, 1)
+        out, mean, invstd = ops.bn_train_fwd(y, gamma, beta, rm, rv, 0.1, 1e-5, relu=True)
+        side = ops.side_stream(dev)
+        ops.stream_wait(side, ops.raw_stream(dev))
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(x, out, w.shape, 1, 1, 1, out=dw)
+        ops.stream_wait(ops.raw_stream(dev), side)
+        return out
+
+    ops.reset_amax_pool(dev)
+    p, out = plan.record(seq)
+    ops.reset_amax_pool(dev)
+    torch.cuda.synchronize()
+    assert p.stats["kernels"] >= 3 and p.stats["stream_waits"] == 2
+    ref_out, ref_dw, ref_rm = out.clone(), dw.clone(), rm.clone()
+    out.zero_()
+    dw.zero_()
+    rm.zero_()
+    rv.fill_(1.0)
+    p.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref_out) and torch.equal(dw, ref_dw) and torch.equal(rm, ref_rm)
+    # new input values at the recorded address are what the replay computes on
+    x.mul_(0.5)
+    ref2 = ops.bn_train_fwd(ops.conv2d_fwd(x, wf, w.shape, 1, 1, 1), gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, relu=True)[0]
+    p.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref2)
+
+
+def test_planned_train_step_is_bit_identical_to_the_eager_path(dev):
+    """Six steps on changing batches: parameters, Adam moments, BatchNorm statistics and every loss value equal the eager
+    run's bit for bit; the planned run really replayed (and verified) a plan."""
+    batches = [_batch(4, 64, dev, s) for s in (1, 2, 3)]
+    m0, o0, l0, _ = _run(dev, False, 6, batches)
+    m1, o1, l1, st = _run(dev, True, 6, batches)
+    assert st is not None and st.disabled is None, getattr(st, "disabled", "no planned step")
+    assert st.records == 1 and st.replays == 3, (st.records, st.replays)
+    assert st.plan.stats["kernels"] > 400
+    assert l0 == l1
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+    assert o0.step_count == o1.step_count == 6
+    sd0, sd1 = m0.state_dict(), m1.state_dict()
+    assert all(torch.equal(sd0[k], sd1[k]) for k in sd0)              # num_batches_tracked included (host-side twin)
+
+
+def test_planned_step_interleaved_with_eval_and_eager_steps(dev):
+    """An evaluation forward between replays reads the layouts the replay wrote; an eager step in between (parameters
+    changed behind the plan's back) makes the next call record again instead of replaying stale layouts."""
+    from weaklysuperviseddl_amd import plan
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import _train_step_eager
+    batches = [_batch(4, 64, dev, s) for s in (4, 5)]
+
+    def run(planned):
+        old = plan.PLAN_STEP[0]
+        plan.PLAN_STEP[0] = planned
+        try:
+            model, opt = _model_and_opt(dev, 7)
+            torch.manual_seed(99)
+            outs = []
+            for i in range(4):
+                train_step(model, opt, *batches[i % 2])
+            model.eval()
+            with torch.no_grad():
+                outs.append(model(batches[0][0])["out"].clone())
+            model.train()
+            train_step(model, opt, *batches[0])
+            _train_step_eager(model, opt, *batches[1])                 # behind the plan's back
+            train_step(model, opt, *batches[0])
+            train_step(model, opt, *batches[1])
+            torch.cuda.synchronize()
+            return model, opt, outs, next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
+        finally:
+            plan.PLAN_STEP[0] = old
+
+    m0, o0, e0, _ = run(False)
+    m1, o1, e1, st = run(True)
+    assert st.disabled is None and st.records == 2 and st.replays >= 2, (st.disabled, st.records, st.replays)
+    assert torch.equal(e0[0], e1[0])
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+
+
+def test_a_step_with_work_a_plan_cannot_see_stays_eager(dev):
+    """``extra_loss`` built from the tensor library's own kernels: the verification replay does not reproduce the eager
+    step's loss, the step is disabled with a reason and the results stay the eager path's."""
+    batches = [_batch(2, 64, dev, 8)]
+    extra = lambda out, img: 0.01 * (out * out).mean()                              # noqa: E731  torch kernels only
+    m0, o0, l0, _ = _run(dev, False, 5, batches, extra_loss=extra)
+    m1, o1, l1, st = _run(dev, True, 5, batches, extra_loss=extra)
+    assert st.disabled is not None and "verification failed" in st.disabled and st.replays == 0
+    assert l0 == l1
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+
+
+def test_weighted_pairwise_losses_through_the_library_are_plannable(dev):
+    """cfg3 / cfg5's combined losses written with ops.scale_mean / ops.add_scalars (launches of the library) replay bit for
+    bit; the helpers equal ``w * x.mean()`` and its gradient."""
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import LocalNormalizedCutLoss, ConstrainToBoundaryLossSingle
+    x = torch.randn(37, device=dev, requires_grad=True)
+    y = ops.scale_mean(x, 0.3)
+    y.backward()
+    assert abs(y.item() - 0.3 * x.detach().double().mean().item()) < 1e-6
+    assert torch.allclose(x.grad, torch.full_like(x, 0.3 / 37), rtol=1e-6, atol=0)
+    ncut, bnd = LocalNormalizedCutLoss(0.1, 5), ConstrainToBoundaryLossSingle(0.1, 5, 5)
+    extra = lambda o, i: ops.add_scalars(ops.scale_mean(ncut(o, i), 0.1),             # noqa: E731
+                                         ops.scale_mean(bnd(ops.softmax_channels(o), i), 0.1))
+    g = torch.Generator().manual_seed(21)
+    img = torch.rand(4, 3, 64, 64, generator=g).to(dev)
+    masks = (torch.rand(4, 64, 64, generator=g) > 0.5).long().to(dev)
+    batches = [(img, masks), (img.flip(0).contiguous(), masks.flip(0).contiguous())]
+    m0, o0, l0, _ = _run(dev, False, 6, batches, extra_loss=extra)
+    m1, o1, l1, st = _run(dev, True, 6, batches, extra_loss=extra)
+    assert st.disabled is None and st.replays == 3, (st.disabled, st.replays)
+    assert l0 == l1
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+
+
+def test_lovasz_step_poisons_the_recording(dev):
+    batches = [_batch(2, 64, dev, 9)]
+    m0, o0, l0, _ = _run(dev, False, 4, batches, loss_fn="lovasz_softmax")
+    m1, o1, l1, st = _run(dev, True, 4, batches, loss_fn="lovasz_softmax")
+    assert st.disabled is not None and "recording failed" in st.disabled and "rocPRIM" in st.disabled
+    assert l0 == l1
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+
+
+def test_side_stream_workspace_growth_while_a_weight_gradient_is_in_flight(dev):
+    """a side-stream workspace replaced by a larger one while earlier side-stream kernels still write the old
+    block must not hand that block to the main stream's next allocation.  Small then large weight gradients on the side
+    stream with main-stream allocations in between equal the serial results."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    shapes = [(8, 128, 128, 16), (8, 256, 256, 32), (8, 512, 512, 32)]
+    data = []
+    for B, Ci, Co, H in shapes:
+        x = torch.randn(B, Ci, H, H, device=dev, generator=g)
+        dy = torch.randn(B, Co, H, H, device=dev, generator=g)
+        data.append((x, dy, (Co, Ci, 3, 3)))
+    serial = [ops.conv2d_wgrad(x, dy, ws, 1, 1, 1) for x, dy, ws in data]
+    torch.cuda.synchronize()
+    ops._ws_cache.clear()
+    side = ops.side_stream(dev)
+    outs, junk = [], []
+    for x, dy, ws in data:
+        out = torch.empty(ws, device=dev)
+        xa, da = ops.amax_of(x), ops.amax_of(dy)
+        ops.stream_wait(side, ops.raw_stream(dev))
+        ops.conv2d_wgrad(x, dy, ws, 1, 1, 1, out=out, x_amax=xa, dy_amax=da, stream=side.cuda_stream)
+        junk.append(torch.full((1 << 22,), 7.0, device=dev))           # main-stream allocations + writes right behind it
+        outs.append(out)
+    ops.stream_wait(ops.raw_stream(dev), side)
+    torch.cuda.synchronize()
+    for a, b in zip(serial, outs):
+        assert torch.equal(a, b)
+    with pytest.raises(ops.WsdlError):
+        ops.conv2d_wgrad(data[0][0], data[0][1], data[0][2], 1, 1, 1, stream=side.cuda_stream)     # unresolved operands
+
+
+def test_host_issue_time_of_a_replayed_step(dev):
+    """Not a parity test: prints what the host pays per step, eager against replay, at the bench's size."""
+    from conftest import report_line
+    from weaklysuperviseddl_amd import plan
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    batches = [_batch(16, 256, dev, 1)]
+    res = {}
+    for planned in (False, True):
+        old = plan.PLAN_STEP[0]
+        plan.PLAN_STEP[0] = planned
+        try:
+            model, opt = _model_and_opt(dev, 0)
+            for _ in range(4):
+                train_step(model, opt, *batches[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                train_step(model, opt, *batches[0])
+            issue = (time.perf_counter() - t0) / 10 * 1e3
+            torch.cuda.synchronize()
+            total = (time.perf_counter() - t0) / 10 * 1e3
+            res[planned] = (issue, total)
+        finally:
+            plan.PLAN_STEP[0] = old
+    report_line(f"train step B=16 256x256: host issue eager {res[False][0]:.2f} ms (step {res[False][1]:.2f}), "
+                f"plan replay {res[True][0]:.2f} ms (step {res[True][1]:.2f})")
+    assert res[True][0] < res[False][0]

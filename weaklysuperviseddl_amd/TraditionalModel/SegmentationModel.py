@@ -26,6 +26,7 @@ import torch.nn as nn
 
 from .. import nn as wnn
 from .. import ops
+from .. import plan
 from ..optim import FlatAdam
 from .ExtraUtilities import compute_iou_and_acc
 
@@ -207,7 +208,7 @@ class SegmentationModel(nn.Module):
         if ev is not None:
             self.__dict__["_aux_event"] = None
             if not torch.cuda.is_current_stream_capturing():
-                torch.cuda.current_stream().wait_event(ev)      # the event sits right behind the aux head: not the whole side stream
+                ev.wait()      # the event sits right behind the aux head: not the whole side stream
 
     def train(self, mode=True):
         self._join_aux()
@@ -232,17 +233,19 @@ class SegmentationModel(nn.Module):
             # no loss of the reference reads it: it runs on the side stream - idle during forward - beside the main head
             # instead of after it; whoever does look at ['aux'] joins first.
             f3 = feats["aux"]
-            main, side = torch.cuda.current_stream(x.device), ops.side_stream(x.device)
-            side.wait_stream(main)
-            f3.record_stream(side)
+            side = ops.side_stream(x.device)
+            ops.stream_wait(side, ops.raw_stream(x.device))
+            ops.cross_stream_use(f3, side)
             with torch.cuda.stream(side):
                 aux_out = ops.bilinear_resize(self.aux_classifier(f3), size)
-            ev = torch.cuda.Event()
+            ev = self.__dict__.get("_aux_event_obj")        # one event, re-recorded by every forward (part of a launch plan)
+            if ev is None:
+                ev = self.__dict__["_aux_event_obj"] = ops.Event()
             ev.record(side)
             self.__dict__["_aux_event"] = ev
 
             def joined():
-                torch.cuda.current_stream(x.device).wait_stream(side)
+                ops.stream_wait(ops.raw_stream(x.device), side)
                 return aux_out
             res["out"] = ops.bilinear_resize(self.classifier(feats["out"]), size)
             res._lazy["aux"] = joined
@@ -285,11 +288,36 @@ def resolve_criterion(criterion):
     raise TypeError(f"criterion: expected nn.CrossEntropyLoss, a callable or None, got {type(criterion).__name__}")
 
 
+_ONES = {}
+
+
+def _one(device):
+    """The gradient of the loss with respect to itself, allocated once (``loss.backward()`` fills a new tensor with a kernel
+    of the tensor library on every call - which a launch plan would not see)."""
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), device=device, dtype=torch.float32)
+    return t
+
+
 def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_entropy", criterion=None):
     """One training iteration; returns the (device) loss tensor, no host synchronisation.  ``loss_fn``: 'cross_entropy' or
     'lovasz_softmax' (reference SegmentationModel.py:65,103-107); ``criterion``: a reference-style loss object instead
-    (``resolve_criterion``)."""
-    masks = torch.clamp(masks, max=1)
+    (``resolve_criterion``).
+
+    On the device, in train mode and outside data parallelism the iteration is issued as ONE host call from its third
+    occurrence on (``plan.PlannedTrainStep``: the launches of an eager iteration recorded behind the C ABI, verified to
+    reproduce it bit for bit, then replayed); WSDL_PLAN_STEP=0 keeps every iteration eager."""
+    if isinstance(optimizer, FlatAdam) and images.is_cuda and plan.PLAN_STEP[0]:
+        tag = (id(extra_loss) if extra_loss is not None else None, loss_fn, id(criterion) if criterion is not None else None)
+        st = plan.planned_step_for(model, optimizer,
+                                   lambda i, m: _train_step_eager(model, optimizer, i, m, extra_loss, loss_fn, criterion), tag)
+        return st(images, masks)
+    return _train_step_eager(model, optimizer, images, masks, extra_loss, loss_fn, criterion)
+
+
+def _train_step_eager(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_entropy", criterion=None):
+    masks = ops.clamp_max_labels(masks, 1)
     with ops.prof_range("train_step/forward"):
         outputs = model(images)["out"]
     with ops.prof_range("train_step/loss"):
@@ -302,10 +330,14 @@ def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_
         else:
             raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
         if extra_loss is not None:
-            loss = loss + extra_loss(outputs, images)
+            extra = extra_loss(outputs, images)
+            if torch.is_tensor(extra) and extra.is_cuda and extra.dim() == 0 and loss.dim() == 0 and extra.dtype == loss.dtype:
+                loss = ops.add_scalars(loss, extra)      # a launch of the library (visible to a launch plan)
+            else:
+                loss = loss + extra
     with ops.prof_range("train_step/backward"):
         optimizer.zero_grad()
-        loss.backward()
+        loss.backward(_one(loss.device) if (loss.dim() == 0 and loss.dtype == torch.float32 and loss.is_cuda) else None)
     with ops.prof_range("train_step/optimizer"):
         optimizer.step()
     return loss.detach()

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libwsdl_hip.so")
 ARCH = "gfx950"
-SOURCES = ["common.hip", "conv_igemm.hip", "norm_pool.hip", "resample_loss.hip", "layercam_optim.hip", "lovasz.hip", "components.hip"]
+SOURCES = ["common.hip", "plan.hip", "conv_igemm.hip", "norm_pool.hip", "resample_loss.hip", "layercam_optim.hip", "lovasz.hip", "components.hip"]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
 

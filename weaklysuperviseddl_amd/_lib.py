@@ -77,6 +77,30 @@ SIGNATURES = {
     "wsdl_refine_combine": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _sz, _vp]),
     "wsdl_softmax_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "wsdl_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    # launch plans + the stream ordering / small helpers a plan needs to see (csrc/plan.hip)
+    "wsdl_plan_begin": (_i, []),
+    "wsdl_plan_recording": (_i, []),
+    "wsdl_plan_end": (_i, [C.POINTER(_vp)]),
+    "wsdl_plan_abort": (_i, []),
+    "wsdl_plan_mark": (_i, [_ll]),
+    "wsdl_plan_poison": (_i, [C.c_char_p]),
+    "wsdl_plan_replay": (_i, [_vp]),
+    "wsdl_plan_replay_segment": (_i, [_vp, _i]),
+    "wsdl_plan_replay_timed": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_ll)]),
+    "wsdl_plan_stats": (_i, [_vp] + [C.POINTER(_ll)] * 5),
+    "wsdl_plan_mark_tag": (_ll, [_vp, _i]),
+    "wsdl_plan_destroy": (_i, [_vp]),
+    "wsdl_event_create": (_i, [C.POINTER(_vp)]),
+    "wsdl_event_destroy": (_i, [_vp]),
+    "wsdl_event_record": (_i, [_vp, _vp]),
+    "wsdl_stream_wait_event": (_i, [_vp, _vp]),
+    "wsdl_stream_wait_stream": (_i, [_vp, _vp]),
+    "wsdl_memset_async": (_i, [_vp, _i, _sz, _vp]),
+    "wsdl_add_int": (_i, [_vp, _i, _ll, _vp]),
+    "wsdl_mul": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "wsdl_clamp_max_i64": (_i, [_vp, _vp, _ll, _ll, _vp]),
+    "wsdl_scale_mean": (_i, [_vp, _i, _f, _vp, _vp]),
+    "wsdl_scale_fill": (_i, [_vp, _f, _vp, _i, _vp]),
 }
 
 _lib = None

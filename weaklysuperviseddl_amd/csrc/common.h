@@ -5,6 +5,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <tuple>
+#include <utility>
 
 #include "../../include/wsdl_hip.h"
 
@@ -60,7 +63,45 @@ extern int g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
 constexpr int kReduceSlots = 4096;
 
+// ---- launch plans (plan.hip; include/wsdl_hip.h "launch plans") ---------------------------------------------------
+// Every kernel launch and stream-ordered memset of the library goes through the two functions below.  Outside a
+// recording they are the plain runtime calls.  Between wsdl_plan_begin and wsdl_plan_end each launch is ALSO appended
+// to the plan being recorded - function address, grid, block, dynamic LDS, stream and a private copy of the argument
+// values - so that wsdl_plan_replay can issue the same sequence again from one C loop, without the host logic of the
+// entry points (tile choice, workspace carving, option look-ups) and without the caller's per-call overhead.
+struct Plan;
+extern Plan* g_plan_rec;            // the plan being recorded (one at a time, process-wide), else nullptr
+void plan_add_kernel(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, std::shared_ptr<void> storage,
+                     void* const* argv, int argc);
+void plan_poison(const char* why);  // an entry point that cannot be replayed (library code launching kernels of its own)
+hipError_t memset_async(void* dst, int value, size_t bytes, hipStream_t s);
+
+template <typename... K, typename... A, size_t... I>
+inline void launch_recorded(void (*kernel)(K...), dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                            std::index_sequence<I...>, A&&... a) {
+    using Tup = std::tuple<std::remove_cv_t<std::remove_reference_t<K>>...>;
+    auto heap = std::make_shared<Tup>(static_cast<K>(std::forward<A>(a))...);
+    void* argv[] = {static_cast<void*>(&std::get<I>(*heap))...};
+    plan_add_kernel(reinterpret_cast<const void*>(kernel), grid, block, shmem, s, heap, argv, (int)sizeof...(K));
+    (void)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, argv, shmem, s);
+}
+
+template <typename... K, typename... A>
+inline void launch(void (*kernel)(K...), dim3 grid, dim3 block, size_t shmem, hipStream_t s, A&&... a) {
+    static_assert(sizeof...(K) == sizeof...(A), "kernel launch: argument count does not match the kernel's parameters");
+    if (__builtin_expect(g_plan_rec != nullptr, 0))
+        launch_recorded(kernel, grid, block, shmem, s, std::index_sequence_for<K...>{}, std::forward<A>(a)...);
+    else
+        kernel<<<grid, block, shmem, s>>>(std::forward<A>(a)...);
+}
+
 }  // namespace wsdl
+
+// every launch site of the library is written as hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...) \
+    ::wsdl::launch(kernelName, dim3(numBlocks), dim3(numThreads), (size_t)(memPerBlock), (streamId), __VA_ARGS__)
+#define hipMemsetAsync(dst, value, bytes, stream) ::wsdl::memset_async((dst), (value), (bytes), (stream))
 
 // ------------------------------------------------------------------ device helpers
 // Barrier for LDS hand-offs inside K loops.  __syncthreads() carries a workgroup-scope fence that is address-space

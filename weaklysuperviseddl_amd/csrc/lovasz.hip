@@ -224,6 +224,7 @@ int wsdl_lovasz_softmax_fwd_bwd(const float* probas, const int64_t* labels, floa
     const int blocks = (int)std::min<long long>((P + kThreadsL - 1) / kThreadsL, 4096);
     const int ablocks = (int)std::min<long long>((P + kThreadsL - 1) / kThreadsL, kParts);
 
+    wsdl::plan_poison("wsdl_lovasz_softmax_fwd_bwd sorts and scans through rocPRIM, whose launches a plan does not see");
     WSDL_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)C * sizeof(int), s));
     WSDL_HIP_CHECK(hipMemsetAsync(loss, 0, sizeof(float), s));
     if (dprobas) WSDL_HIP_CHECK(hipMemsetAsync(dprobas, 0, (size_t)P * C * sizeof(float), s));

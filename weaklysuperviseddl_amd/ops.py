@@ -29,8 +29,99 @@ def _stream():
     return _raw_stream(_cur_device())          # an int: the bound functions declare c_void_p (argtypes), ctypes converts
 
 
+# ---- launch plans (plan.py; include/wsdl_hip.h "launch plans") ---------------------------------------------------------
+# While a plan is being recorded, PLAN_REC[0] is the recording.  Everything the recorded launches touch must outlive the
+# plan AT ITS ADDRESS: every tensor whose pointer is handed to the library meanwhile is kept by the recording (``_p``), so
+# the caching allocator can never give its block to anybody else - no private memory pool needed.
+PLAN_REC = [None]
+
+
 def _p(t):
-    return t.data_ptr() if t is not None else None      # int / None -> c_void_p by the declared argtypes (no object per argument)
+    if t is None:
+        return None
+    rec = PLAN_REC[0]
+    if rec is not None:
+        rec.keep.append(t)
+    return t.data_ptr()                                 # int -> c_void_p by the declared argtypes (no object per argument)
+
+
+def _h(stream):
+    """Raw hipStream_t (an int) of a torch stream object / of a raw handle."""
+    return stream if isinstance(stream, int) else stream.cuda_stream
+
+
+def stream_wait(waiter, waited):
+    """``waiter`` waits for everything enqueued on ``waited`` so far (torch stream objects or raw handles).  Through the
+    library (one event record + one stream wait), so that a plan being recorded sees the dependency."""
+    check(lib().wsdl_stream_wait_stream(_h(waiter), _h(waited)))
+
+
+class Event:
+    """An event of the library (no timing).  ``record`` / ``wait`` default to torch's current stream; both are part of a plan
+    being recorded (which then keeps the event alive)."""
+    __slots__ = ("h", "__weakref__")
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().wsdl_event_create(C.byref(h)))
+        self.h = h.value
+
+    def record(self, stream=None):
+        if PLAN_REC[0] is not None:
+            PLAN_REC[0].keep.append(self)
+        check(lib().wsdl_event_record(self.h, _stream() if stream is None else _h(stream)))
+
+    def wait(self, stream=None):
+        if PLAN_REC[0] is not None:
+            PLAN_REC[0].keep.append(self)
+        check(lib().wsdl_stream_wait_event(_stream() if stream is None else _h(stream), self.h))
+
+    def __del__(self):
+        h, self.h = self.h, None
+        if h:
+            try:
+                lib().wsdl_event_destroy(h)
+            except Exception:       # interpreter shutdown
+                pass
+
+
+def cross_stream_use(t, stream):
+    """``t`` lives on another stream's allocator pool and is used by work enqueued on ``stream`` (a torch stream object):
+    keep the caching allocator from recycling it before that work has run."""
+    t.record_stream(stream)
+    if PLAN_REC[0] is not None:
+        PLAN_REC[0].keep.append(t)
+
+
+def memset_zero(t):
+    """t.zero_() as a stream-ordered memset of the library (seen by a plan; ``t`` dense)."""
+    if not t.is_contiguous():
+        raise WsdlError("memset_zero: tensor is not dense")
+    if torch.cuda.is_current_stream_capturing():
+        return t.zero_()        # inside a hipGraph capture: the tensor library's fill kernel, as the captured graphs always had
+    check(lib().wsdl_memset_async(_p(t), 0, t.numel() * t.element_size(), _stream()))
+    return t
+
+
+def add_int(t, delta=1):
+    """t += delta for a one-element device int32 / int64 (Adam's step number, a dropout call counter) - a launch of the
+    library instead of torch's ``add_`` (a plan records launches of this library only)."""
+    if t.numel() != 1 or t.dtype not in (torch.int32, torch.int64):
+        raise WsdlError("add_int: a one-element int32 / int64 device tensor")
+    check(lib().wsdl_add_int(_p(t), int(t.dtype == torch.int64), int(delta), _stream()))
+    return t
+
+
+def clamp_max_labels(labels, hi=1):
+    """torch.clamp(labels, max=hi) for int64 device labels (reference SegmentationModel.py:100); other dtypes / host
+    tensors take torch's own clamp."""
+    if not labels.is_cuda or labels.dtype != torch.int64:
+        return torch.clamp(labels, max=hi)
+    labels = labels.contiguous()
+    out = torch.empty_like(labels)
+    if labels.numel():
+        check(lib().wsdl_clamp_max_i64(_p(labels), _p(out), labels.numel(), int(hi), _stream()))
+    return out
 
 
 def _req(t, name="tensor", dtype=torch.float32):
@@ -91,7 +182,9 @@ def _cached_prep(cache, weight, need_dx):
     if cache is not None and cache.get("prep_key") == _weight_key(weight) and (cache["prep"][1] is not None or not need_dx):
         ev = cache.get("prep_event")
         if ev is not None:
-            torch.cuda.current_stream(weight.device).wait_event(ev)
+            ev.wait()
+        if PLAN_REC[0] is not None:
+            PLAN_REC[0].keep.append(cache["prep"])
         return cache["prep"]
     wf, wd = prep_weights(weight, True, need_dx)
     if cache is not None:
@@ -106,9 +199,20 @@ LAYOUT_EPOCH = [0]     # bumped by options that change what a layout buffer hold
 _prep_streams = {}
 
 
+def _norm_device(device):
+    """torch.device with an explicit index: the stream tables and the census must agree on the key (an index-less
+    ``torch.device('cuda')`` used to create streams the census did not count)."""
+    device = device if isinstance(device, torch.device) else torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", _cur_device())
+    return device
+
+
 def prep_stream(device):
     """Third stream: re-layouts that follow an early segment step must not sit in the side stream in front of the weight
     gradients (and the Adam launches) still to come."""
+    if device.index is None:
+        device = _norm_device(device)
     st = _prep_streams.get(device)
     if st is None:
         st = _prep_streams[device] = torch.cuda.Stream(device=device)
@@ -126,7 +230,7 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
     if not convs:
         return
     dev = convs[0].weight.device
-    main, side = torch.cuda.current_stream(dev), side_stream(dev)
+    main, side = _stream(), side_stream(dev)
     if _head and _PREFETCH_HEAD > 0 and len(convs) > 2 * _PREFETCH_HEAD:
         # the forward that follows waits for its FIRST layers' layouts: give those their own (small) amax launch instead of
         # queueing them behind the amax pass over all 158 MB of weights (105 us before the next step could start)
@@ -134,10 +238,11 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
         return prefetch_weight_layouts(convs[_PREFETCH_HEAD:], use_events, epoch_ahead, pingpong, after, False)
     if after is not None and use_events:
         side = prep_stream(dev)
-        side.wait_event(after)
+        after.wait(side)
     else:
-        side.wait_stream(main)
+        stream_wait(side, main)
     ev = None
+    cache0 = convs[0].__dict__.setdefault("_wsdl_cache", {})
     with torch.cuda.stream(side):
         amaxes = multi_amax([m.weight for m in convs], persistent=True) if CONV_ARITH[0] == 1 else None
         batch = []          # convolutions whose existing split layouts are rewritten by ONE launch (after the loop)
@@ -156,7 +261,9 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
             else:
                 wf, wd = prep_weights(w, True, True, amaxes[i:i + 1] if amaxes is not None else None, reuse=target)
                 if use_events:
-                    ev = torch.cuda.Event()
+                    ev = cache.get("own_event")         # one event per site, re-recorded step after step
+                    if ev is None:
+                        ev = cache["own_event"] = Event()
                     ev.record(side)
             cache["prep_key"] = (PARAM_EPOCH[0] + epoch_ahead, w._version, w.data_ptr())
             cache["prep"], cache["prep_event"] = (wf, wd), ev
@@ -170,23 +277,46 @@ def prefetch_weight_layouts(convs, use_events=True, epoch_ahead=0, pingpong=Fals
         if batch:
             prep_weights_multi([b[:4] for b in batch])
             if use_events:
-                ev = torch.cuda.Event()
+                ev = cache0.get("batch_event")
+                if ev is None:
+                    ev = cache0["batch_event"] = Event()
                 ev.record(side)
                 for b in batch:
                     b[4]["prep_event"] = ev
             else:
                 ev = None
     if not use_events:
-        main.wait_stream(side)          # graph capture: no cross-replay events - the step ends with the layouts complete
+        stream_wait(main, side)         # graph capture: no cross-replay events - the step ends with the layouts complete
     return ev                           # recorded behind the last re-layout (None without events)
 
 
+def _stream_object(device, handle):
+    """The torch stream object behind a raw handle of one of the library's streams (None: not one of them)."""
+    for st in library_streams(device):
+        if st.cuda_stream == handle:
+            return st
+    return None
+
+
 def workspace(nbytes, device, stream=None):
-    """Stream-ordered scratch: one growing buffer per (device, stream).  ``stream``: a raw handle (default: the current one)."""
-    key = (device, raw_stream(device) if stream is None else stream)
+    """Stream-ordered scratch: one growing buffer per (device, stream).  ``stream``: a raw handle (default: the current one).
+    A buffer is allocated with ITS stream current, so that the caching allocator files it under that stream's pool: when a
+    larger geometry replaces it, the old block can only be handed to later allocations of the same stream - behind the
+    kernels still queued there that write it (a side-stream workspace allocated from the main stream's pool could be given
+    to the next main-stream tensor while side-stream weight gradients were still filling it)."""
+    cur = raw_stream(device)
+    key = (device, cur if stream is None else stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        n = max(int(nbytes), 1 << 20)
+        if stream is None or stream == cur:
+            buf = torch.empty(n, dtype=torch.uint8, device=device)
+        else:
+            obj = _stream_object(device, stream)
+            if obj is None:
+                raise WsdlError("workspace: a stream handle that is not one of the library's streams")
+            with torch.cuda.stream(obj):
+                buf = torch.empty(n, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 
@@ -243,7 +373,7 @@ def amax_slot(device):
     key = (device, raw_stream(device))
     pool = _amax_pools.get(key)
     if pool is None or pool[1] >= pool[0].numel():
-        buf = torch.zeros(AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32)
+        buf = memset_zero(torch.empty(AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32))
         if not torch.cuda.is_current_stream_capturing():
             # slots are read by kernels on the other streams of this library (weight gradients on the side stream, the
             # main stream joining a CAM lane): keep the caching allocator from recycling a retired pool under them
@@ -266,7 +396,7 @@ def lane_stream(device, i):
     holds the side stream (and possibly the prep stream), so LayerCAM lanes with streams of their own made three batches in
     flight take 0.27 ms/img instead of 0.185.  Lanes 0 and 1 therefore ARE the side and the prep stream; only further
     lanes create streams, once per device whatever the number of generators."""
-    device = device if isinstance(device, torch.device) else torch.device(device)
+    device = _norm_device(device)
     if i == 0:
         return side_stream(device)
     if i == 1:
@@ -290,9 +420,7 @@ def stream_census(device):
     A ROCm process has ``MAX_HW_QUEUES`` hardware queues (4); a stream beyond them shares one, i.e. runs behind another
     stream's work (measured: three LayerCAM lanes 0.185 -> 0.27 ms/img with a fifth stream in use, profiles/r03_notes.md).
     ``lane_stream`` refuses to create the fifth; tests/test_hip_dp.py checks the count in a data-parallel process."""
-    device = device if isinstance(device, torch.device) else torch.device(device)
-    if device.index is None:
-        device = torch.device(device.type, _cur_device())
+    device = _norm_device(device)
     c = {"main": 1, "side": int(device in _side_streams), "prep": int(device in _prep_streams),
          "lanes": len(_lane_streams.get(device, [])), "rccl": 0}
     try:
@@ -308,6 +436,7 @@ def stream_census(device):
 
 def library_streams(device):
     """Every stream this library has created on ``device`` (amax slots may be read on any of them)."""
+    device = _norm_device(device)
     return [st for st in (_side_streams.get(device), _prep_streams.get(device)) if st is not None] + list(_lane_streams.get(device, []))
 
 
@@ -521,6 +650,14 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_
     """``stream``: raw handle of the stream to launch on (default: the current stream) - the side-stream launches of the
     training step pass it instead of switching torch's current stream (a ``with torch.cuda.stream()`` costs the host ~20 us,
     61 times per step)."""
+    if stream is not None and stream != _stream():
+        # everything this function would otherwise enqueue on the CURRENT stream (amax passes, densifying copies) must have
+        # been resolved by the caller, in front of the wait that orders ``stream`` behind the current one (_wgrad_into)
+        split = _wgrad_split(wshape)
+        if out is None or (split and (x_amax is None or dy_amax is None)):
+            raise WsdlError("conv2d_wgrad(stream=): pass out, x_amax and dy_amax (resolved on the current stream)")
+        if _planes(x, "x")[0] is not x or _planes(dy, "dy")[0] is not dy:
+            raise WsdlError("conv2d_wgrad(stream=): operands must already be dense planes")
     if x_amax is None:
         x_amax = amax_of(x, _wgrad_split(wshape))
     if dy_amax is None:
@@ -670,6 +807,8 @@ _side_streams = {}
 
 
 def side_stream(device):
+    if device.index is None:
+        device = _norm_device(device)
     st = _side_streams.get(device)
     if st is None:
         st = _side_streams[device] = torch.cuda.Stream(device=device)
@@ -679,9 +818,9 @@ def side_stream(device):
 def join_side_stream(device):
     """Make the current stream wait for everything queued on the side stream (before the optimiser step / a
     gradient all-reduce reads the flat gradient buffer)."""
-    st = _side_streams.get(device)
+    st = _side_streams.get(_norm_device(device))
     if st is not None:
-        torch.cuda.current_stream(device).wait_stream(st)
+        stream_wait(raw_stream(device), st)
 
 
 def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, last=False):
@@ -696,11 +835,12 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
         # a densifying copy (never needed by the training step's own tensors) would be enqueued on the CURRENT stream: make it
         # happen before the side stream's wait, not inside conv2d_wgrad behind it
         x, dconv = _planes(x, "x")[0], _planes(dconv, "dy")[0]
-        main, side = torch.cuda.current_stream(x.device), side_stream(x.device)
-        side.wait_stream(main)                      # dconv / x (and the zero_grad memset) are ready
+        side = side_stream(x.device)
+        hside = side.cuda_stream
+        stream_wait(hside, _stream())               # dconv / x (and the zero_grad memset) are ready
         # launched ON the side stream by handle: torch's current stream stays the main one
         conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                     dy_amax=dy_amax, stream=side.cuda_stream)
+                     dy_amax=dy_amax, stream=hside)
         x.record_stream(side)                       # keep the caching allocator from recycling them early
         dconv.record_stream(side)
     else:
@@ -1050,7 +1190,7 @@ class _Dropout(torch.autograd.Function):
         check(lib().wsdl_dropout_fwd(_p(x), _p(y), _p(mask), x.numel(), float(p), int(seed), int(gen), _p(counter),
                                      _stream()))
         if counter is not None and gen:
-            counter.add_(1)             # on the stream, behind the kernel that read it (a node of a captured graph too)
+            add_int(counter, 1)         # on the stream, behind the kernel that read it (a node of a captured graph / a plan too)
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         return y
@@ -1076,7 +1216,7 @@ class _ConcatChannels(torch.autograd.Function):
         for t, c in zip(xs, Cs):
             t = _dense(t, "cat input")
             dst = out[:, off:off + c]
-            check(lib().wsdl_copy_planes(_p(t), _vp(dst.data_ptr()), B, c, H * W, 0, tot, _stream()))
+            check(lib().wsdl_copy_planes(_p(t), _p(dst), B, c, H * W, 0, tot, _stream()))
             off += c
         ctx.Cs = Cs
         return out
@@ -1107,7 +1247,7 @@ class _ConcatInto(torch.autograd.Function):
             in_place = (t.data_ptr() == dst.data_ptr() and tuple(t.shape) == tuple(dst.shape) and t.stride() == dst.stride())
             if not in_place:
                 t = _dense(t, "cat input")
-                check(lib().wsdl_copy_planes(_p(t), _vp(dst.data_ptr()), B, c, H * W, 0, tot, _stream()))
+                check(lib().wsdl_copy_planes(_p(t), _p(dst), B, c, H * W, 0, tot, _stream()))
                 if slot is not None:      # this input's maximum joins the slot the in-place producers published into
                     check(lib().wsdl_amax(_p(t), B, c * H * W, c * H * W, _p(slot), 0, _stream()))
             off += c
@@ -1179,7 +1319,9 @@ class _SoftmaxCE(torch.autograd.Function):
     def backward(ctx, g):
         dl, inv = ctx.saved_tensors
         out = torch.empty_like(dl)
-        check(lib().wsdl_scale_by_device_scalar(_p(dl), _p(_dense(g.reshape(1)) * inv), _p(out), dl.numel(), _stream()))
+        sc = torch.empty_like(inv)
+        check(lib().wsdl_mul(_p(_dense(g.reshape(1))), _p(inv), _p(sc), 1, _stream()))      # upstream gradient x 1 / #pixels
+        check(lib().wsdl_scale_by_device_scalar(_p(dl), _p(sc), _p(out), dl.numel(), _stream()))
         return out, None, None
 
 
@@ -1211,8 +1353,7 @@ class _PairwiseAffinityLoss(torch.autograd.Function):
             g = _dense(g.reshape(-1))
             n = dp[0].numel()
             for b in range(dp.shape[0]):
-                check(lib().wsdl_scale_by_device_scalar(_vp(dp[b].data_ptr()), _vp(g[b:b + 1].data_ptr()),
-                                                        _vp(out[b].data_ptr()), n, _stream()))
+                check(lib().wsdl_scale_by_device_scalar(_p(dp[b]), _p(g[b:b + 1]), _p(out[b]), n, _stream()))
         else:
             out = torch.empty_like(dp)
             check(lib().wsdl_scale_by_device_scalar(_p(dp), _p(_dense(g.reshape(1))), _p(out), dp.numel(), _stream()))
@@ -1364,7 +1505,7 @@ def layercam_epilogue(acts, grads, out_hw=(224, 224), alpha=1.0, variant="modula
     IA = C.c_int * n
     Cs, hs, ws_ = IA(*[a.shape[1] for a in acts]), IA(*[a.shape[2] for a in acts]), IA(*[a.shape[3] for a in acts])
     PA = _vp * n
-    pa, pg = PA(*[a.data_ptr() for a in acts]), PA(*[g.data_ptr() for g in grads])
+    pa, pg = PA(*[_p(a) for a in acts]), PA(*[_p(g) for g in grads])
     dev = acts[0].device
     cam = torch.empty(B, out_hw[0], out_hw[1], device=dev, dtype=torch.float32)
     mask = torch.empty(B, out_hw[0], out_hw[1], device=dev, dtype=torch.uint8) if thresh is not None else None
@@ -1465,6 +1606,38 @@ class _KLDivBatchMean(torch.autograd.Function):
         return out, None
 
 
+class _ScaleMean(torch.autograd.Function):
+    """w * mean(x) of a device scalar / vector as launches of the library (a launch plan sees them; ``0.1 * loss`` and
+    ``.mean()`` are kernels of the tensor library)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xs = _dense(x, "x")
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        check(lib().wsdl_scale_mean(_p(xs), xs.numel(), float(w), _p(out), _stream()))
+        ctx.w, ctx.shape = float(w), tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n = 1
+        for d in ctx.shape:
+            n *= d
+        dx = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        check(lib().wsdl_scale_fill(_p(_dense(g.reshape(1))), ctx.w / n, _p(dx), n, _stream()))
+        return dx, None
+
+
+def scale_mean(x, w=1.0):
+    """``w * x.mean()`` (``w * x`` for a scalar) -> 0-dim tensor."""
+    return _ScaleMean.apply(x, float(w))
+
+
+def add_scalars(a, b):
+    """a + b for two 0-dim device tensors through the library's add kernel."""
+    return _AddAct.apply(a.reshape(1), b.reshape(1), False).reshape(())
+
+
 def kl_div_batchmean(xn, s):
     return _KLDivBatchMean.apply(xn, s)
 
@@ -1503,8 +1676,12 @@ if os.environ.get("WSDL_ROCTX") == "1":
         RANGES[0] = False
 
 
+PROF_ON = [False]      # per-launch event brackets are being recorded (bench.py's roofline pass): a plan replay has none
+
+
 def prof_enable(on):
     check(lib().wsdl_prof_enable(int(on)))
+    PROF_ON[0] = bool(on)
 
 
 def prof_reset():

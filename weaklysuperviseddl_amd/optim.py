@@ -92,6 +92,7 @@ class FlatAdam:
         self._accumulating = False
         self._adam_event = None
         self._prep_done = [None] * len(self.segments)     # per segment: event behind its last re-layout
+        self._seg_events = [None] * len(self.segments)    # per segment: event behind its Adam launch
         self._hooked = False
         return self
 
@@ -142,22 +143,25 @@ class FlatAdam:
         (a collective's work handle)."""
         dev = self.flat_param.device
         lo, hi = self.segments[k]
-        main, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
-        side.wait_stream(main)
+        side = ops.side_stream(dev)
+        ops.stream_wait(side, ops.raw_stream(dev))
         if not self.capture_mode and self._prep_done[k] is not None:
-            side.wait_event(self._prep_done[k])        # last step's re-layouts of THIS segment read the parameters overwritten now
+            self._prep_done[k].wait(side)              # last step's re-layouts of THIS segment read the parameters overwritten now
         ev = None
         with torch.cuda.stream(side):
             if after is not None:
                 after.wait()
             if not any(self._stepped):
                 self.step_count += 1
-                self.step_dev.add_(1)
+                ops.add_int(self.step_dev, 1)
             ops.adam_step_flat(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                                self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
                                step_dev=self.step_dev)
             if not self.capture_mode:
-                ev = self._adam_event = torch.cuda.Event()
+                ev = self._seg_events[k]               # one event per segment, re-recorded step after step
+                if ev is None:
+                    ev = self._seg_events[k] = ops.Event()
+                self._adam_event = ev
                 ev.record(side)
         self._stepped[k] = True
         if self.segment_hook is not None:
@@ -168,11 +172,10 @@ class FlatAdam:
         for k in range(len(self.segments) - 1, -1, -1):
             if not self._stepped[k]:
                 self.step_segment(k)
-        main = torch.cuda.current_stream(dev)
         if self.capture_mode or self._adam_event is None:
-            main.wait_stream(ops.side_stream(dev))
+            ops.stream_wait(ops.raw_stream(dev), ops.side_stream(dev))
         else:
-            main.wait_event(self._adam_event)        # the parameters, not the re-layouts behind them on the side stream
+            self._adam_event.wait(ops.raw_stream(dev))   # the parameters, not the re-layouts behind them on the side stream
         self._expected = set(self._fired)
         self._fired = set()
         self._stepped = [False] * len(self.segments)
@@ -192,7 +195,10 @@ class FlatAdam:
     def zero_grad(self, set_to_none=False):
         if self.flat_grad.is_cuda and getattr(self, "_dirty", True):
             ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:
+            ops.memset_zero(self.flat_grad)         # a launch of the library: part of a recorded plan
+        else:
+            self.flat_grad.zero_()
         for k in self._fresh:
             self._fresh[k] = True
         for p, off in zip(self.params, self.offsets):
@@ -238,7 +244,7 @@ class FlatAdam:
         ops.bump_param_epoch()          # parameters change behind torch's version counters
         if self.flat_param.is_cuda:
             # the kernel reads the step number from the device: a captured (hipGraph) step replays correctly
-            self.step_dev.add_(1)
+            ops.add_int(self.step_dev, 1)
             ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
                                step_dev=self.step_dev)

@@ -1,0 +1,261 @@
+"""Launch plans: one host call per training iteration.
+
+One iteration of the reference's training loop (TraditionalModel/AlternatingDirectionCutLoss.py:693-703 =
+SegmentationModel.py:96-113) is ~520 kernel launches on three streams on this path.  Issued statement by statement from
+Python - module call, autograd node, ctypes call, the entry point's tile choice - they cost the host 10-14 ms of an 18.7 ms
+step; hipGraph replay on this ROCm costs 9.5 ms and runs slower on the GPU.  ``record`` runs a callable once in the
+ordinary way while the library notes every launch it makes (function, grid, block, LDS, stream, argument values) and every
+cross-stream dependency (``ops.stream_wait`` / ``ops.Event``) - ``include/wsdl_hip.h`` "launch plans", ``csrc/plan.hip`` -
+and ``LaunchPlan.replay`` issues the same sequence again from one C loop.
+
+``PlannedTrainStep`` is ``train_step`` on top of it: the first calls run eagerly, the next one is recorded, and - before a
+single replay is trusted - VERIFIED: the model / optimiser state from before the recorded step is restored, the plan is
+replayed on it, and parameters, both Adam moments, every module buffer, the device counters and the loss must come out
+bit-identical to what the eager step left.  A step that contains anything a plan cannot see (kernels of the tensor library
+in a user's ``extra_loss``, rocPRIM inside the Lovasz loss) fails that check, or the recording itself, and the step simply
+stays eager (``PlannedTrainStep.disabled`` says why).
+
+What a replay relies on: the recording keeps every tensor whose pointer went to the library alive, so no address is
+ever handed to anybody else; whatever changes from step to step lives on the device (Adam's step number, the dropout call
+counters, the amax slots' memset) or is an input copied into the plan's own input buffers; host-side twins (``step_count``,
+BatchNorm's pending step counts, the cache epochs) are advanced by the wrapper.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import ops
+from ._lib import lib, check, WsdlError
+
+
+class PlanError(WsdlError):
+    pass
+
+
+class _Recording:
+    __slots__ = ("keep",)
+
+    def __init__(self):
+        self.keep = []
+
+
+class LaunchPlan:
+    """A recorded launch sequence (``record``).  ``keep``: everything the launches touch."""
+
+    def __init__(self, handle, keep):
+        self.handle, self.keep = handle, keep
+        k, m, w, e, mk = (C.c_longlong(0) for _ in range(5))
+        check(lib().wsdl_plan_stats(handle, C.byref(k), C.byref(m), C.byref(w), C.byref(e), C.byref(mk)))
+        self.stats = {"kernels": k.value, "memsets": m.value, "stream_waits": w.value, "event_ops": e.value, "marks": mk.value}
+
+    def replay(self):
+        check(lib().wsdl_plan_replay(self.handle))
+
+    def replay_segment(self, k):
+        check(lib().wsdl_plan_replay_segment(self.handle, int(k)))
+
+    @property
+    def segments(self):
+        return self.stats["marks"] + 1
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                lib().wsdl_plan_destroy(h)
+            except Exception:           # interpreter shutdown
+                pass
+
+
+def recording():
+    return ops.PLAN_REC[0] is not None
+
+
+def record(fn, *args, **kwargs):
+    """Run ``fn(*args, **kwargs)`` once, recording every launch of the library -> (LaunchPlan, fn's result).  Raises
+    ``PlanError`` when the sequence cannot be replayed (the recorded call itself has run normally by then)."""
+    if ops.PLAN_REC[0] is not None:
+        raise PlanError("record: a plan is already being recorded")
+    rec = _Recording()
+    check(lib().wsdl_plan_begin())
+    ops.PLAN_REC[0] = rec
+    try:
+        out = fn(*args, **kwargs)
+    except BaseException:
+        ops.PLAN_REC[0] = None
+        lib().wsdl_plan_abort()
+        raise
+    ops.PLAN_REC[0] = None
+    h = C.c_void_p()
+    if lib().wsdl_plan_end(C.byref(h)) != 0:
+        err = PlanError(lib().wsdl_last_error().decode())
+        err.result = out                # the call has run: its result is valid, only the plan is not
+        raise err
+    return LaunchPlan(h.value, rec.keep), out
+
+
+PLAN_STEP = [os.environ.get("WSDL_PLAN_STEP", "1") != "0"]      # train_step replays a plan where it can (0: always eager)
+PLAN_WARMUP = int(os.environ.get("WSDL_PLAN_WARMUP", "2"))      # eager calls before the recorded one
+
+
+def _hook_tables(model):
+    out = []
+    for m in model.modules():
+        for name in ("_forward_hooks", "_forward_pre_hooks", "_backward_hooks", "_backward_pre_hooks"):
+            d = getattr(m, name, None)
+            if d is not None:
+                out.append(d)
+    return out
+
+
+class PlannedTrainStep:
+    """``train_step(model, optimizer, images, masks, ...)`` as a verified plan replay (module docstring)."""
+
+    def __init__(self, model, optimizer, eager, warmup=None):
+        from . import nn as wnn
+        self.model, self.opt, self.eager = model, optimizer, eager
+        self.warmup = PLAN_WARMUP if warmup is None else int(warmup)
+        self.calls = 0
+        self.plan = None
+        self.key = None
+        self.disabled = None            # why this step stays eager, once it does
+        self.replays = 0
+        self.records = 0
+        self._bns = [m for m in model.modules() if isinstance(m, wnn.BatchNorm2d)]
+        self._convs = [m for m in model.modules() if isinstance(m, wnn.Conv2d)]
+        self._dropouts = [m for m in model.modules() if isinstance(m, wnn.Dropout)]
+        self._hooks = _hook_tables(model)
+
+    # -- what must be equal for a recorded plan to stand for the call
+    def _key(self, images, masks):
+        opt = self.opt
+        return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device, float(opt.lr),
+                tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params),
+                tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale), ops.LAYOUT_EPOCH[0],
+                ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0],
+                ops.raw_stream(images.device))
+
+    def usable(self, images, masks):
+        opt = self.opt
+        return (self.disabled is None and PLAN_STEP[0] and images.is_cuda and masks.is_cuda and self.model.training
+                and torch.is_grad_enabled() and ops.PLAN_REC[0] is None and not ops.PROF_ON[0]
+                and opt.pre_step_hook is None and not opt.grad_ready_hooks and not getattr(opt, "time_tail", False)
+                and not getattr(opt, "capture_mode", False) and not any(map(len, self._hooks))
+                and not torch.cuda.is_current_stream_capturing())
+
+    def _state(self):
+        """Every device tensor a training step changes in place (what the verification compares and restores)."""
+        opt = self.opt
+        ts = [opt.flat_param, opt.exp_avg, opt.exp_avg_sq, opt.step_dev]
+        ts += [b for b in self.model.buffers() if b.is_cuda and b.dim() > 0]
+        ts += [m._counter for m in self._dropouts if m._counter is not None]
+        return ts
+
+    def _record(self, images, masks):
+        dev = images.device
+        opt = self.opt
+        self.records += 1
+        self.s_images = images.detach().clone()
+        self.s_masks = masks.detach().to(torch.int64).clone()
+        state = self._state()
+        before = [t.clone() for t in state]
+        pend0 = [b._pending_steps for b in self._bns]
+        torch.cuda.synchronize(dev)
+        ops.reset_amax_pool(dev)            # the first slot request inside the recording allocates a pool and memsets it there
+        try:
+            plan, loss = record(self.eager, self.s_images, self.s_masks)
+        except PlanError as e:              # (the recorded call itself ran normally: a real training step was taken)
+            self.disabled = f"recording failed: {e}"
+            return e.result
+        finally:
+            ops.reset_amax_pool(dev)        # eager code must not hand out the plan's slots
+        self._bn_delta = [(b, b._pending_steps - p0) for b, p0 in zip(self._bns, pend0) if b._pending_steps != p0]
+        # the state tensors a step touches may have grown (a dropout counter created by this very call)
+        if len(self._state()) != len(state):
+            return loss                     # (a dropout counter created by this very call) plan dropped: the next call records again
+        # ---- verification (bit for bit), on a PROBE batch: with the recorded inputs a kernel the plan did not see would go
+        # unnoticed - its output from the recorded run is still in memory and still right.  So: (1) back to the state before
+        # the step, one EAGER step on a different batch -> reference; (2) back again, the same batch through the REPLAY ->
+        # must equal the reference; (3) forward to the state the real step left.
+        after = [t.clone() for t in state]
+        loss_real = loss.detach().clone()
+        host1 = (opt.step_count, [b._pending_steps for b in self._bns])
+
+        def restore(snap):
+            for t, b in zip(state, snap):
+                t.copy_(b)
+            self._relayout()                # the layouts the step's forward reads belong to the restored parameters
+
+        probe_img = self.s_images * 0.75 + 0.1
+        probe_masks = 1 - torch.clamp(self.s_masks, max=1)
+        restore(before)
+        ref_loss = self.eager(probe_img, probe_masks).clone()
+        ref = [t.clone() for t in state]
+        restore(before)
+        self.s_images.copy_(probe_img)
+        self.s_masks.copy_(probe_masks)
+        plan.replay()
+        bad = [i for i, (t, a) in enumerate(zip(state, ref)) if not torch.equal(t, a)]
+        loss_same = torch.equal(loss.detach(), ref_loss)
+        restore(after)
+        opt.step_count = host1[0]
+        for b, p1 in zip(self._bns, host1[1]):
+            b._pending_steps = p1
+        if bad or not loss_same:
+            self.disabled = ("verification failed: the replayed step differs from the eager one ("
+                             + (f"{len(bad)} of {len(state)} state tensors" if bad else "the loss value")
+                             + ") - the step contains work a plan does not see (kernels of the tensor library in a custom loss?)")
+            return loss_real
+        self.plan, self.s_loss = plan, loss.detach()
+        self._layout_sites = [(m.__dict__["_wsdl_cache"], m.weight) for m in self._convs
+                              if m.__dict__.get("_wsdl_cache", {}).get("prep") is not None and m.weight.requires_grad]
+        self._epoch_after = ops.PARAM_EPOCH[0]
+        return loss_real                    # (``loss`` itself lives in the plan: the next replay overwrites it)
+
+    def _relayout(self):
+        """Weight layouts of the CURRENT parameters, in place (what the optimiser does after its step)."""
+        if self.opt.post_step_hook is not None:
+            self.opt.post_step_hook()
+
+    def __call__(self, images, masks):
+        self.calls += 1
+        if self.calls <= self.warmup or not self.usable(images, masks):
+            return self.eager(images, masks)
+        key = self._key(images, masks)
+        if self.plan is None or key != self.key or ops.PARAM_EPOCH[0] != self._epoch_after:
+            # (last condition: the parameters changed behind the plan's back - an eager step, load_state_dict - so the weight
+            # layouts the plan's forward reads are stale: record again, one eager step, rather than reason about who owns
+            # which layout buffer)
+            self.plan, self.key = None, key
+            return self._record(images, masks)
+        if images.data_ptr() != self.s_images.data_ptr():
+            self.s_images.copy_(images)
+        if masks.data_ptr() != self.s_masks.data_ptr():
+            self.s_masks.copy_(masks)
+        self.plan.replay()
+        self.replays += 1
+        # host-side twins of what the replayed kernels did
+        self.opt.step_count += 1
+        for b, d in self._bn_delta:
+            b._pending_steps += d
+        ops.bump_param_epoch()
+        ops.bump_stats_epoch()
+        ep = ops.PARAM_EPOCH[0]
+        for cache, w in self._layout_sites:         # the replay re-laid the weights out in place: the caches stay valid
+            cache["prep_key"] = (ep, w._version, w.data_ptr())
+        self._epoch_after = ep
+        return self.s_loss.clone()
+
+
+
+def planned_step_for(model, optimizer, eager, tag):
+    """The PlannedTrainStep of (model, optimizer, tag) - kept on the optimizer; ``eager(images, masks)`` is the step."""
+    table = optimizer.__dict__.setdefault("_wsdl_planned", {})
+    key = (id(model), tag)
+    st = table.get(key)
+    if st is None:
+        if len(table) >= 4:
+            table.pop(next(iter(table)))
+        st = table[key] = PlannedTrainStep(model, optimizer, eager)
+    return st
