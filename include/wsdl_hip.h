@@ -81,7 +81,12 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   layercam_tail_mod 32*  LayerCAM epilogue: the last hw % n pixels of a map are summed over the channels the way ATen's CPU sum
  *                      handles its scalar columns (four interleaved streams), all others by its four-level cascade - the epilogue
  *                      is bit-identical to the reference's torch-CPU arithmetic on identical inputs.  32 = torch built for AVX-512
- *                      (the fixtures, the GPU boxes' hosts), 16 = an AVX2 torch, 0 = the cascade for every pixel
+ *                      run on 1-12, 24 or 32 threads (the fixtures: torch.set_num_threads(4)), 16 = an AVX2 torch, 0 = the
+ *                      cascade for every pixel.  torch-CPU's own result depends on its THREAD COUNT: ATen splits the
+ *                      columns of the sum over its threads and the thread left with fewer than a vector's worth takes the
+ *                      scalar path, so no single setting reproduces every reference run - with 16 threads (the GPU boxes'
+ *                      default) 32 leaves 2 of 196 values of a 1024 x 14 x 14 sum one ulp off and 0 leaves 6 of 784 (28 x 28) and 9
+ *                      of 49 (7 x 7); pin the reference's thread count (1-12) when bit-exact CAM values are compared
  * (Options measured slower and removed in round 3: conv_glds - weights by LDS-DMA; wgrad_wide - 8-pixel-run staging of x;
  *  wgrad_tile64 - 64-row weight-gradient tiles; occupancy_cap.  Figures: profiles/r02_notes.md.  Round 4: t256_bk32 - K chunks of 32
  *  in the 256x128 form (1-2.6 % slower per step); wgrad_direct = 2 - the direct-fragment weight gradient for misaligned taps (0-7 %

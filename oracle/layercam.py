@@ -91,6 +91,16 @@ class LayerCAMGenerator:
 
     __call__ = generate
 
+    def generate_bg_cam(self, image_tensor, valid_class_indices, alpha=2.0):
+        """Notebook class only - reference AlternatingDirectionCutLoss.py:296-318: the LayerCAM of ``valid_class_indices``
+        (``generate(image, valid_class_indices)`` = notebook order, alpha 1.0), maximum over its leading axis,
+        ``1 - clamp(1 - max, 0) ** alpha`` as the background map, both bilinearly resized to 224 x 224."""
+        all_cams = self.generate(image_tensor, 1.0, class_idx=torch.as_tensor(valid_class_indices))
+        max_obj = all_cams.max(dim=0).values
+        m_bg = 1.0 - ((1.0 - max_obj).clamp(min=0.0) ** alpha)
+        up = lambda t: F.interpolate(t[None, None], size=(224, 224), mode="bilinear", align_corners=False).squeeze()
+        return up(m_bg), up(max_obj)
+
 
 class CAMGenerator:
     """Classic fc-weight CAM for every class - reference AlternatingDirectionCutLoss.py:320-403

@@ -165,6 +165,28 @@ def gen_layercam():
     print("classic_cam.npz", len(co))
 
 
+def gen_layercam_bg():
+    """``generate_bg_cam`` of the notebook LayerCAMGenerator (AlternatingDirectionCutLoss.py:296-318) on the fixture net."""
+    nb = lift(f"{REF}/AlternatingDirectionCutLoss.py", {"LayerCAMGenerator"})["LayerCAMGenerator"]
+    torch.manual_seed(7)
+    net = ToyCAMNet()
+    g = torch.Generator().manual_seed(8)
+    imgs = torch.rand(2, 3, 112, 112, generator=g)
+    out = {"state/" + k: v.numpy() for k, v in net.state_dict().items()}
+    out["image"] = imgs[1].numpy()
+    out["class_idx"] = np.array([4])
+    gen = nb(net, ["layer3", "layer4"])
+    out["all_cams"] = gen.generate(imgs[1].clone(), torch.tensor([4])).numpy()           # (1,224,224), alpha 1.0
+    for n in ("layer3", "layer4"):
+        out[f"act_{n}"] = gen.activations[n].detach().numpy()
+        out[f"grad_{n}"] = gen.gradients[n].detach().numpy()
+    for alpha in (2.0, 0.5):
+        m_bg, max_obj = gen.generate_bg_cam(imgs[1].clone(), torch.tensor([4]), alpha=alpha)
+        out[f"m_bg_a{alpha}"], out[f"max_obj_a{alpha}"] = m_bg.numpy(), max_obj.numpy()   # (224,224) each
+    np.savez_compressed(f"{HERE}/layercam_bg.npz", **out)
+    print("layercam_bg.npz", len(out))
+
+
 def gen_layercam_wide():
     """Channel counts that exercise every level of torch's cascade summation (300 = 256 + 2 x 16 + 12 left over, 600 = 2 x 256 +
     5 x 16 + 8) on 14 x 14 maps (192 vectorised pixels + 4 scalar-column pixels): the reference's own bodies pin the ORDER
@@ -408,7 +430,7 @@ def gen_keep_largest():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gens = dict(losses=gen_losses, layercam=gen_layercam, layercam_wide=gen_layercam_wide, refine=gen_refine_and_metrics, lovasz=gen_lovasz,
+    gens = dict(losses=gen_losses, layercam=gen_layercam, layercam_bg=gen_layercam_bg, layercam_wide=gen_layercam_wide, refine=gen_refine_and_metrics, lovasz=gen_lovasz,
                 bottleneck=gen_bottleneck, eval_helpers=gen_eval_helpers, keep_largest=gen_keep_largest)
     for name in (sys.argv[1:] or list(gens)):        # python make_golden.py [losses layercam ...]: only those
         gens[name]()

@@ -232,6 +232,7 @@ def test_generate_coalesced_merges_and_splits_batches_on_the_host():
     import torch
     from weaklysuperviseddl_amd.TraditionalModel.LayerCAM import LayerCAMGenerator
     gen = object.__new__(LayerCAMGenerator)
+    gen.model = torch.nn.Identity().eval()          # merging asserts eval mode
     seen = []
 
     def fake_batches(batches, alpha, class_idxs, thresh, streams):
@@ -272,3 +273,6 @@ def test_generate_coalesced_merges_and_splits_batches_on_the_host():
     seen.clear()
     gen.generate_coalesced(batches, 1.0, classes, 0.3, streams=3, device_batch=0)
     assert [s[0] for s in seen] == sizes
+    gen.model.train()
+    with pytest.raises(RuntimeError):
+        gen.generate_coalesced(batches, 1.0, classes, 0.3, streams=3, device_batch=8)

@@ -149,6 +149,34 @@ def test_pairwise_loss_properties_full_size(dev, shape):
     assert (p1.grad.sum(1).abs().max() / p1.grad.abs().max()).item() < 1e-4
 
 
+@pytest.mark.parametrize("shape,boundary", [((32, 2, 256, 256), False), ((8, 2, 512, 512), False), ((8, 2, 512, 512), True)])
+def test_pairwise_loss_vs_oracle_full_size(dev, shape, boundary):
+    """BASELINE configs[2] / configs[4] sizes DIRECTLY against the oracle (reference AlternatingDirectionCutLoss.py:65-105,
+    AlternatingDirectionBoundaryLoss.py:12-44), not only through properties: NCut at (32,2,256,256) and (8,2,512,512), the
+    boundary loss (probabilities in, colour + spatial affinity, per-image values) at (8,2,512,512).  The oracle runs in
+    float64 on the host (a few seconds); loss within 1e-5, gradient within 1e-3 of its maximum (north_star's tolerances)."""
+    import oracle
+    from conftest import smooth_image
+    from weaklysuperviseddl_amd import ops
+    B, C, H, W = shape
+    img = smooth_image(B, H, W, 31)
+    preds = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(32))
+    if boundary:
+        preds = torch.softmax(preds, 1)
+    args = (5, 0.1, 5.0, False, 1) if boundary else (5, 0.1, 0.0, True, 0)
+    p64 = preds.double().requires_grad_()
+    l64 = oracle.pairwise_affinity_loss(p64, img.double(), *args)
+    wts = torch.linspace(0.5, 1.5, B, dtype=torch.float64) if boundary else None        # distinct upstream gradients per image
+    (l64 * wts).sum().backward() if boundary else l64.backward()
+    ph = preds.to(dev).requires_grad_()
+    lh = ops.pairwise_affinity_loss(ph, img.to(dev), *args)
+    (lh * wts.float().to(dev)).sum().backward() if boundary else lh.backward()
+    rel = ((lh.detach().cpu().double() - l64.detach()).abs() / l64.detach().abs()).max().item()
+    gerr = ((ph.grad.cpu().double() - p64.grad).abs().max() / p64.grad.abs().max()).item()
+    assert rel < 1e-5, rel
+    assert gerr < 1e-3, gerr
+
+
 def test_full_size_training_steps(dev):
     """BASELINE configs[1]: B=16, 256x256, fwd + CE + bwd + Adam; finite, deterministic, loss goes down."""
     import bench

@@ -176,8 +176,11 @@ def test_weighted_pairwise_losses_through_the_library_are_plannable(dev):
     assert abs(y.item() - 0.3 * x.detach().double().mean().item()) < 1e-6
     assert torch.allclose(x.grad, torch.full_like(x, 0.3 / 37), rtol=1e-6, atol=0)
     ncut, bnd = LocalNormalizedCutLoss(0.1, 5), ConstrainToBoundaryLossSingle(0.1, 5, 5)
-    extra = lambda o, i: ops.add_scalars(ops.scale_mean(ncut(o, i), 0.1),             # noqa: E731
-                                         ops.scale_mean(bnd(ops.softmax_channels(o), i), 0.1))
+
+    def extra(o, i):
+        o1, o2 = ops.fanout(o, 2)
+        return ops.add_scalars(ops.scale_mean(ncut(o1, i), 0.1), ops.scale_mean(bnd(ops.softmax_channels(o2), i), 0.1))
+
     g = torch.Generator().manual_seed(21)
     img = torch.rand(4, 3, 64, 64, generator=g).to(dev)
     masks = (torch.rand(4, 64, 64, generator=g) > 0.5).long().to(dev)
@@ -246,16 +249,21 @@ def test_host_issue_time_of_a_replayed_step(dev):
             model, opt = _model_and_opt(dev, 0)
             for _ in range(4):
                 train_step(model, opt, *batches[0])
+            singles = []
+            for _ in range(7):                      # one step issued into an EMPTY queue: no back-pressure from the runtime
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                train_step(model, opt, *batches[0])
+                singles.append(time.perf_counter() - t0)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(10):
                 train_step(model, opt, *batches[0])
-            issue = (time.perf_counter() - t0) / 10 * 1e3
             torch.cuda.synchronize()
             total = (time.perf_counter() - t0) / 10 * 1e3
-            res[planned] = (issue, total)
+            res[planned] = (sorted(singles)[3] * 1e3, total)
         finally:
             plan.PLAN_STEP[0] = old
     report_line(f"train step B=16 256x256: host issue eager {res[False][0]:.2f} ms (step {res[False][1]:.2f}), "
                 f"plan replay {res[True][0]:.2f} ms (step {res[True][1]:.2f})")
-    assert res[True][0] < res[False][0]
+    assert res[True][0] < 0.6 * res[False][0]

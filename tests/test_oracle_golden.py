@@ -177,6 +177,22 @@ def test_layercam_generator_hooks(golden):
     _close(gen(imgs[1], class_idx=torch.tensor([4]), alpha=0.5), g["notebook_cam_1_a0.5"], rel=1e-4)
 
 
+def test_layercam_generate_bg_cam(golden):
+    """``generate_bg_cam`` of the notebook LayerCAMGenerator (reference AlternatingDirectionCutLoss.py:296-318): the oracle's
+    restatement against the vectors the reference's own body produced."""
+    g = golden("layercam_bg")
+    net = _Toy()
+    net.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("state/")})
+    gen = oracle.LayerCAMGenerator(net, ["layer3", "layer4"], variant="notebook")
+    img, ci = T(g["image"]), torch.tensor(g["class_idx"])
+    _close(gen.generate(img, ci), g["all_cams"], rel=1e-5)                     # notebook order (image, class_idx), alpha 1.0
+    for alpha in (2.0, 0.5):
+        m_bg, max_obj = gen.generate_bg_cam(img, ci, alpha=alpha)
+        assert tuple(m_bg.shape) == tuple(max_obj.shape) == (224, 224)
+        _close(m_bg, g[f"m_bg_a{alpha}"], rel=1e-5)
+        _close(max_obj, g[f"max_obj_a{alpha}"], rel=1e-5)
+
+
 def test_classic_cam(golden):
     g, gl = golden("classic_cam"), golden("layercam")
     net = _Toy()

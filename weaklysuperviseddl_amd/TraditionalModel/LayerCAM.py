@@ -162,6 +162,9 @@ class LayerCAMGenerator:
             class_idxs = [None] * len(batches)
         if device_batch <= 0 or len(batches) <= 1:
             return self.generate_batches(batches, alpha, class_idxs, thresh, streams)
+        if self.model.training or any(getattr(m, "training", False) for m in self.model.modules()):
+            raise RuntimeError("generate_coalesced(device_batch > 0): the model must be in eval mode - train-mode BatchNorm makes "
+                               "an image's CAM depend on the batch it is merged into")
         merged, cls_merged, spans, cur, cur_cls, n = [], [], [], [], [], 0
         for b, c in zip(batches, class_idxs):
             if cur and (n + b.shape[0] > device_batch or b.shape[1:] != cur[0].shape[1:] or (c is None) != (cur_cls[0] is None)):
@@ -275,6 +278,26 @@ class LayerCAMGenerator:
         return self.generate_batch(x, float(alpha), class_idx)
 
     __call__ = generate
+
+    @staticmethod
+    def bg_from_cams(all_cams, alpha=2.0, out_hw=(224, 224)):
+        """(n, H, W) maps -> (m_bg, max_obj): maximum over the leading axis, ``1 - clamp(1 - max, 0) ** alpha``, both
+        bilinearly resized to ``out_hw`` (reference AlternatingDirectionCutLoss.py:304-318)."""
+        max_obj = all_cams.max(dim=0).values
+        m_bg = 1.0 - ((1.0 - max_obj).clamp(min=0.0) ** alpha)
+        both = ops.bilinear_resize(torch.stack([m_bg, max_obj]).unsqueeze(0).contiguous(), out_hw)[0]
+        return both[0], both[1]
+
+    def generate_bg_cam(self, image_tensor, valid_class_indices, alpha=2.0):
+        """``LayerCAMGenerator.generate_bg_cam`` of the notebook class (reference
+        TraditionalModel/AlternatingDirectionCutLoss.py:296-318; "mimics CAMGenerator's bg+fg map output"):
+        ``generate(image, valid_class_indices)`` - the notebook argument order, alpha 1.0 - then the maximum over the map's
+        leading axis, the background map ``1 - (1 - max)**alpha`` and the resize of both to 224 x 224.  As in the
+        reference, the class-score gather accepts ONE valid class per image (more raise there too)."""
+        idx = torch.as_tensor(valid_class_indices, device=image_tensor.device)
+        with torch.no_grad():
+            all_cams = self.generate(image_tensor, 1.0, class_idx=idx)
+            return self.bg_from_cams(all_cams, alpha, (224, 224))
 
 
 @torch.no_grad()

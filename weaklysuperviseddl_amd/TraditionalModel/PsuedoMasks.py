@@ -60,7 +60,7 @@ def _to_png_u8(t):
 def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_largest_masks=True,
                           run_id="default", out_root="/content", max_images=500, write_png=True,
                           device="cuda", rank=0, world=1, keep_images=False, streams=3, keep_on_device=False,
-                          device_batch=32):
+                          device_batch=0):
     mask_dir = os.path.join(out_root, f"pseudo_masks_{run_id}")
     image_dir = os.path.join(out_root, f"images_{run_id}")
     if write_png:
@@ -80,8 +80,12 @@ def generate_pseudo_masks(loader, layercam_gen, cam_thresh=0.3, alpha=1.0, keep_
         """CAM + threshold for the queued batches (``streams`` of them in flight), then the host part per image."""
         if not group:
             return
-        # the loader's batches are merged into device batches of ``device_batch`` images, ``streams`` of them in flight
-        # (0: one launch sequence per loader batch, as round 3)
+        # device_batch = 0 (the default): one launch sequence per loader batch - the masks depend on the loader's batches
+        # only, not on ``streams``, on how batches are dealt to ranks or on what else was queued (bit-reproducible).
+        # device_batch = n > 0 (throughput option, 0.135 instead of 0.182 ms/img at n = 32): the loader's batches are merged
+        # into device batches of n images.  A merged batch has its own per-tensor amax scales, tile and K-split choices, so
+        # its masks equal the per-batch ones only outside the fp32 band of the network (~4e-3 of the CAM's range) and DO
+        # depend on the flush threshold and the sharding - not for runs that must be reproducible
         if hasattr(layercam_gen, "generate_coalesced"):
             outs = layercam_gen.generate_coalesced([g[1] for g in group], alpha, [g[2] for g in group], cam_thresh, streams, device_batch)
         elif hasattr(layercam_gen, "generate_batches"):

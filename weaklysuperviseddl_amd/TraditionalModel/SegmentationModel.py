@@ -321,6 +321,11 @@ def _train_step_eager(model, optimizer, images, masks, extra_loss=None, loss_fn=
     with ops.prof_range("train_step/forward"):
         outputs = model(images)["out"]
     with ops.prof_range("train_step/loss"):
+        outputs_x = outputs
+        if extra_loss is not None and outputs.is_cuda:
+            # two consumers of the logits: their gradients are summed by the library (ops.fanout), not by the autograd
+            # engine's own add kernel - which a launch plan would not see
+            outputs, outputs_x = ops.fanout(outputs, 2)
         if criterion is not None:
             loss = resolve_criterion(criterion)(outputs, masks)
         elif loss_fn == "lovasz_softmax":
@@ -330,7 +335,7 @@ def _train_step_eager(model, optimizer, images, masks, extra_loss=None, loss_fn=
         else:
             raise ValueError(f"loss_fn {loss_fn!r}: 'cross_entropy' or 'lovasz_softmax'")
         if extra_loss is not None:
-            extra = extra_loss(outputs, images)
+            extra = extra_loss(outputs_x, images)
             if torch.is_tensor(extra) and extra.is_cuda and extra.dim() == 0 and loss.dim() == 0 and extra.dtype == loss.dtype:
                 loss = ops.add_scalars(loss, extra)      # a launch of the library (visible to a launch plan)
             else:

@@ -1633,6 +1633,42 @@ def scale_mean(x, w=1.0):
     return _ScaleMean.apply(x, float(w))
 
 
+class _Fanout(torch.autograd.Function):
+    """n handles on one tensor whose gradients are summed by the library's add kernel, in the order of the handles.  A tensor
+    consumed twice has its gradients added by the autograd engine with a kernel of the tensor library - which a launch plan
+    does not see (the logits feeding the cross-entropy AND a pairwise loss)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        outs = tuple(_alias(x) for _ in range(n))
+        a = getattr(x, "_wsdl_amax", None)
+        if a is not None and getattr(x, "_wsdl_amax_version", x._version) == x._version:
+            for o in outs:
+                _publish_amax(o, a)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_dense(g, "gradient") for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        acc = torch.empty_like(gs[0])
+        check(lib().wsdl_add(_p(gs[0]), _p(gs[1]), _p(acc), acc.numel(), 0, _stream()))
+        for g in gs[2:]:
+            check(lib().wsdl_add(_p(acc), _p(g), _p(acc), acc.numel(), 0, _stream()))
+        return acc, None
+
+
+def fanout(x, n=2):
+    """``n`` handles on ``x`` for ``n`` consumers (see _Fanout); without autograd just ``x`` n times."""
+    if not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda):
+        return (x,) * n
+    return _Fanout.apply(x, int(n))
+
+
 def add_scalars(a, b):
     """a + b for two 0-dim device tensors through the library's add kernel."""
     return _AddAct.apply(a.reshape(1), b.reshape(1), False).reshape(())
