@@ -196,6 +196,40 @@ def mfma_busy_3x3():
     return out if len(out) > 1 else None
 
 
+def rocprof_avg_us(kernel):
+    """Average duration of `kernel` in the committed ``rocprofv3 --kernel-trace --stats`` run of this command with the streams
+    serialised (profiles/r*_bench_n1_serial_kernel_stats.csv) - the figure the HIP-event average of the run must agree
+    with.  -> (us, calls, file) or (None, None, None)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_serial_kernel_stats.csv")))
+    if not files:
+        return None, None, None
+    from weaklysuperviseddl_amd import ops
+    base = kernel.split("<")[0]
+    targs = kernel[len(base):].strip("<>").split(",") if "<" in kernel else []
+    targs = [t.strip() for t in targs]
+    best = None
+    for row in csv.DictReader(open(files[-1])):
+        name = row["Name"]
+        if f"::{base}<" not in name and f" {base}<" not in name and not name.startswith(base + "<") and f"::{base}(" not in name \
+                and not name.startswith(base + "("):
+            continue
+        got = name.split(base, 1)[1]
+        got = [t.strip() for t in got[1:got.index(">")].split(",")] if got.startswith("<") else []
+        ok = True
+        for i, t in enumerate(targs):          # class names carry placeholders (AR, BK, MODE, DYRAW) where instantiations differ
+            if t == "AR":
+                ok &= i < len(got) and got[i] == str(ops.CONV_ARITH[0])
+            elif t.isdigit():
+                ok &= i < len(got) and got[i] == t
+        if ok and (best is None or int(row["Calls"]) > int(best["Calls"])):
+            best = row
+    if best is None:
+        return None, None, os.path.relpath(files[-1], ROOT)
+    return round(float(best["AverageNs"]) / 1e3, 3), int(best["Calls"]), os.path.relpath(files[-1], ROOT)
+
+
 # ------------------------------------------------------------------------------------------ CPU baselines (oracle)
 def _timed(fn, warm, steps, what):
     for _ in range(warm):
@@ -369,8 +403,8 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
         conv_tf = exe / (kms * 1e-3) / 1e12 if kms else 0.0
         nprod = 3.0 if ops.CONV_ARITH[0] == 1 else 6.0
         out["roofline"] = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "achieved": round(nprod * leg_tf, 3), "frac": round(nprod * leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
-                           "achieved_fp32_equivalent": round(leg_tf, 3),
+                           "achieved": round(leg_tf, 3), "frac": round(leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
+                           "achieved_mfma_issue": round(nprod * leg_tf, 3), "frac_mfma_issue": round(nprod * leg_tf / BF16_MFMA_PEAK_TFLOPS, 4),
                            "conv_kernels_fp32_equivalent": round(conv_tf, 3),
                            "conv_kernels_frac": round(nprod * conv_tf / BF16_MFMA_PEAK_TFLOPS, 4),
                            "mfma_products_per_fp32_product": nprod,
@@ -379,8 +413,9 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
                            "traffic": pmc_traffic("conv_igemm_split_kernel<128, 64, 2, 32, 256, AR>"),
                            "traffic_layercam_partial_kernel": pmc_traffic("layercam_partial_kernel"),
                            "traffic_source": pmc_traffic("layercam_partial_kernel", with_source=True)[1],
-                           "note": "needed-only FLOPs (forward 12.4 + backward to layer3's output 5.9 GFLOP/img) x the 16-bit MFMA "
-                                   "products per fp32 product / wall time of the whole leg, against the dense 16-bit MFMA peak; "
+                           "note": "achieved / frac: needed-only fp32-equivalent FLOPs (forward 12.4 + backward to layer3's output 5.9 "
+                                   "GFLOP/img) / wall time of the whole leg, against the dense 16-bit MFMA peak (*_mfma_issue: x the 16-bit "
+                                   "MFMA products per fp32 product); "
                                    "conv_kernels_* = executed FLOPs of the instrumented conv launches / their HIP-event time"}
     return out
 
@@ -431,7 +466,7 @@ def rank_environments(n, ndev, base_env, port=None):
         if n > 6 * max(ndev, 1):
             raise SystemExit(f"--gpus {n}: only {ndev} GPU(s) here and at most 6 processes may share one")
         env.setdefault("WSDL_DIST_BACKEND", "gloo")
-    return [dict(env, RANK=str(r), LOCAL_RANK=str(r)) for r in range(n)]
+    return [rccl_debug_env(dict(env, RANK=str(r), LOCAL_RANK=str(r)), r) for r in range(n)]
 
 
 def spawn_ranks(args, argv):
@@ -494,6 +529,66 @@ def wait_ranks(procs, timeout_s=3000.0, poll_s=0.2):
     if failed == -1:
         rcs = [rc if rc else -9 for rc in rcs]
     return rcs
+
+
+# ------------------------------------------------------------------------------------------ self-description of a data-parallel run
+RCCL_ALGOS = {0: "Tree", 1: "Ring", 2: "CollnetDirect", 3: "CollnetChain", 4: "NVLS", 5: "NVLSTree"}
+RCCL_PROTOS = {0: "LL", 1: "LL128", 2: "Simple"}
+
+
+def rccl_debug_env(env, rank, log_dir="/tmp"):
+    """Rank 0 of a multi-rank run asks RCCL to say what it does (topology at init, algorithm / protocol per collective size)
+    into a file bench.py parses afterwards (``dp.rccl``); the caller's own NCCL_DEBUG settings win."""
+    if int(rank) != 0 or "NCCL_DEBUG" in env:
+        return env
+    env = dict(env)
+    env["NCCL_DEBUG"] = "INFO"
+    env["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
+    env["NCCL_DEBUG_FILE"] = os.path.join(log_dir, "wsdl_rccl_rank0_%p.log")
+    return env
+
+
+def parse_rccl_log(text, keep=24):
+    """What RCCL reported: per (bytes, algorithm, protocol) how many collectives took it (NCCL_DEBUG_SUBSYS=TUNING lines
+    "<Coll>: <n> Bytes -> Algo <a> proto <p> time <t>"), the topology lines of the communicator's set-up, and whether every
+    collective ran on rings only ("verify it is not ring-only")."""
+    import re
+    choices, topo, version = {}, [], None
+    pat = re.compile(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)(?: time ([0-9.eE+-]+))?")
+    for line in text.splitlines():
+        msg = line.split("NCCL INFO", 1)[1].strip() if "NCCL INFO" in line else line.strip()
+        m = pat.search(msg)
+        if m:
+            key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))
+            ent = choices.setdefault(key, {"collective": key[0], "bytes": key[1], "algo": RCCL_ALGOS.get(key[2], str(key[2])),
+                                           "proto": RCCL_PROTOS.get(key[3], str(key[3])), "calls": 0, "model_time_us": None})
+            ent["calls"] += 1
+            if m.group(5):
+                ent["model_time_us"] = float(m.group(5))
+            continue
+        if re.search(r"(RCCL|NCCL) version", msg) and version is None:
+            version = msg
+        if re.search(r"^(Channel|Ring|Trees|Connected all|\d+ coll channels|comm 0x|Using network|P2P|Setting affinity)", msg) \
+                and len(topo) < keep:
+            topo.append(msg[:200])
+    chosen = sorted(choices.values(), key=lambda e: -e["bytes"])
+    algos = sorted({e["algo"] for e in chosen})
+    return {"version_line": version, "choices": chosen[:keep], "algorithms_used": algos,
+            "ring_only": (algos == ["Ring"]) if algos else None, "topology_lines": topo}
+
+
+def dp_self_description(world, backend, rccl_version, per_rank_ms, bucket_ms, n1_reference, rccl_log_text):
+    """The ``dp`` fields that let the first run on a real node be read without the builder present."""
+    return {"rccl": {"nranks": int(world), "backend": backend, "rccl_version": rccl_version,
+                     "debug": parse_rccl_log(rccl_log_text) if rccl_log_text else None,
+                     "debug_note": "rank 0 ran with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,TUNING into a file; `choices` = the "
+                                   "(algorithm, protocol) RCCL picked per collective size, `ring_only` answers SURVEY section 5"},
+            "ms_per_step_by_rank": [None if v is None else round(float(v), 3) for v in per_rank_ms],
+            "bucket_allreduce_ms": bucket_ms,
+            "bucket_allreduce_ms_is": "per bucket (launch order): side-stream time from the point the bucket's all-reduce was enqueued to "
+                                      "its completion on that stream (HIP events, 5 steps after the timed region, mean) - queueing behind "
+                                      "earlier collectives included",
+            "n1_reference": n1_reference}
 
 
 def build_workload(cfg, B, S, device, rank, graph=False):
@@ -602,6 +697,9 @@ def main():
     if os.environ.get("WSDL_DUMP_AFTER"):            # debugging aid: where is every thread N seconds from now?
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["WSDL_DUMP_AFTER"]), repeat=False, file=sys.stderr)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSDL_FORCE_DIST") == "1":
+        # (under torchrun the driver's environment arrives here unchanged: rank 0 turns RCCL's own report on before the init)
+        os.environ.update(rccl_debug_env(dict(os.environ), os.environ.get("RANK", "0")))
     with stdout_to_stderr():
         rank, local, world = init_distributed()
     if world != args.gpus:
@@ -621,6 +719,23 @@ def main():
     # WSDL_FORCE_DIST=1 puts the data-parallel machinery (RCCL broadcasts / bucketed all-reduces, control exchange) on a
     # single rank as well: the one-GPU rehearsal of the code path the 8-GPU run takes
     dp_on = world > 1 or (dist.is_available() and dist.is_initialized())
+    n1_reference = None
+    if dp_on and cfg != "cfg4":
+        # the same process layout WITHOUT data parallelism: every rank steps its own replica on its own GPU, no collective
+        # (the reducer, built right after, broadcasts rank 0's state over whatever these steps did) - the N = 1 figure this
+        # run's scaling should be read against, measured on this node, in these processes
+        for _ in range(max(args.warmup, 3)):
+            step()
+        sync_all(world)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all(world)
+        d1 = (time.perf_counter() - t1) / args.steps
+        n1_reference = {"ms_per_step": round(d1 * 1e3, 3), "img_s_per_gpu": round(B / d1, 2), "steps": args.steps,
+                        "what": "every rank stepping its own replica with no gradient exchange (same processes, same node, all GPUs "
+                                "busy at once): what N x this figure would be is perfect scaling"}
+        opt.__dict__.pop("_wsdl_planned", None)          # (plans recorded without the reducer's hooks are not this run's)
     with stdout_to_stderr():
         reducer = GradBucketReducer(opt, modules=[model]) if dp_on else None   # noqa: F841  (hooks live on the optimizer)
 
@@ -642,6 +757,7 @@ def main():
     sync_all(world)
     dt = time.perf_counter() - t0
     cpu_s = time.process_time() - cpu0
+    dt_local = dt
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -721,8 +837,29 @@ def main():
         result["config"]["rehearsal"] = ("ranks share the GPU(s) and the gradients travel over gloo through host memory: a rehearsal "
                                          "of the data-parallel code path, not a performance figure")
     if dp_on:
+        per_rank = [dt_local / args.steps * 1e3]
+        if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, dt_local / args.steps * 1e3)
+        reducer.time_buckets = True
+        for _ in range(5):
+            step()
+        reducer.time_buckets = False
+        bucket_ms = reducer.bucket_times_ms()
+        log_text = None
+        if rank == 0 and os.environ.get("NCCL_DEBUG_FILE"):
+            path = os.environ["NCCL_DEBUG_FILE"].replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)
+            try:
+                log_text = open(path, errors="replace").read()
+            except OSError:
+                log_text = None
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            rccl_version = None
         plan = reducer.comm_budget()
-        result["dp"] = {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches,
+        result["dp"] = dp_self_description(world, dist.get_backend(), rccl_version, per_rank, bucket_ms, n1_reference, log_text)
+        result["dp"] |= {"buckets": len(reducer.bucket_size), "early_launches_last_step": reducer.last_early_launches,
                         "control_exchanges": {"blocking": reducer.control_exchanges_blocking,
                                               "asynchronous_one_step_behind": reducer.control_exchanges_async},
                         "exposed_ms": None if tail is None else round(tail, 4),
@@ -784,29 +921,40 @@ def main():
             else:
                 mfma, peak = ach, FP32_MFMA_PEAK_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"
-            result["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(mfma, 3),
-                                  "peak": peak, "unit": "TFLOP/s", "frac": round(mfma / peak, 4),
-                                  "frac_is": ("MFMA ISSUE rate: the 16-bit MFMA FLOPs the kernel really executes (3 per fp32 "
-                                              "product, padding-only taps skipped) / the dense 16-bit peak.  The ALGORITHMIC "
-                                              "fraction - SURVEY 8(d)'s fp32 FLOPs of the convolutions launched / time / the same "
-                                              "peak - is frac_algorithmic_nominal (dense, padding taps counted) and "
-                                              "frac_algorithmic_executed") if split else "algorithmic = issued (fp32 MFMA kernel)",
-                                  "frac_algorithmic_nominal": round(nom / peak, 4),
+            rp_us, rp_calls, rp_file = rocprof_avg_us(top["kernel"])
+            step_tf = value / world * GFLOP_PER_IMG_256 * (S / 256) ** 2 / 1e3          # per GPU, nominal dense fp32-equivalent
+            result["roofline"] = {"bound": "mfma", "kernel": top["kernel"],
+                                  # ALGORITHMIC flops per launch (2 * P * Cout * K dense fp32-equivalent, padding taps
+                                  # counted) / the kernel's average launch duration (HIP events of this run) / the peak of the pipe
+                                  # the kernel runs on
+                                  "achieved": round(nom, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(nom / peak, 4),
+                                  "frac_is": ("SURVEY 8(d)'s fraction: nominal algorithmic fp32-equivalent FLOPs of the launches of this "
+                                              "kernel / their HIP-event time / the dense peak of the matrix pipe it runs on"
+                                              + (" (16-bit MFMA: each fp32 product is evaluated as 3 fp16 MFMAs on exact 2-way splits, so "
+                                                 "the scheme's own ceiling is peak / 3; against the fp32-input MFMA peak of 157.3 TFLOP/s "
+                                                 "the same rate would read > 1).  frac_mfma_issue is the rate of 16-bit MFMA work really "
+                                                 "ISSUED (3 per product, padding-only taps skipped) over the same peak" if split else "")),
                                   "frac_algorithmic_executed": round(ach / peak, 4),
+                                  "frac_mfma_issue": round(mfma / peak, 4), "achieved_mfma_issue": round(mfma, 3),
                                   "frac_of_scheme_ceiling": round(ach / (peak / (nprod if split else 1)), 4),
-                                  "static_fields": ["traffic", "traffic_source", "mfma_busy_3x3"],
-                                  "static_note": "static_fields are LOOKUPS in committed rocprofv3 --pmc runs under profiles/ (counter "
-                                                 "passes cannot run inside bench.py); everything else in this object is measured in "
+                                  "step_frac": round(step_tf / peak, 4), "step_tflops_nominal": round(step_tf, 3),
+                                  "step_frac_is": f"whole step: {GFLOP_PER_IMG_256 * (S / 256) ** 2 * B / 1e3:.3f} TFLOP nominal (fwd + bwd, "
+                                                  "BASELINE.md section 3) / ms_per_step / the same peak",
+                                  "static_fields": ["traffic", "traffic_source", "mfma_busy_3x3", "avg_launch_us_rocprof",
+                                                    "rocprof_calls", "rocprof_source"],
+                                  "static_note": "static_fields are LOOKUPS in committed rocprofv3 runs under profiles/ (counter passes and "
+                                                 "the profiler cannot run inside bench.py); everything else in this object is measured in "
                                                  "this run",
-                                  "achieved_fp32_equivalent": round(ach, 3), "achieved_nominal": round(nom, 3),
+                                  "achieved_fp32_equivalent_executed": round(ach, 3),
                                   "mfma_products_per_fp32_product": (nprod if split else 1),
                                   "traffic": pmc_traffic(top["kernel"]),
                                   "traffic_source": pmc_traffic(top["kernel"], with_source=True)[1],
                                   "mfma_busy_3x3": mfma_busy_3x3(),
                                   "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
                                   "launches": top["launches"], "avg_launch_us": top["avg_us"],
-                                  "flop_per_launch_avg": top["executed"] / top["launches"],
-                                  "flop_per_launch_avg_nominal": top["work"] / top["launches"],
+                                  "avg_launch_us_rocprof": rp_us, "rocprof_calls": rp_calls, "rocprof_source": rp_file,
+                                  "flop_per_launch_avg": top["work"] / top["launches"],
+                                  "flop_per_launch_avg_executed": top["executed"] / top["launches"],
                                   "method": "second pass of the same steps, HIP events around every launch, wgrad side stream "
                                             "serialised (the timed region overlaps it with the main chain)",
                                   "peak_note": note}

@@ -197,6 +197,38 @@ def test_bench_spawn_logic_dry_run_for_8_ranks():
     # an existing MASTER_PORT / backend choice of the caller is kept
     e = bench.rank_environments(2, 2, {"MASTER_PORT": "1234", "WSDL_DIST_BACKEND": "gloo"})[1]
     assert e["MASTER_PORT"] == "1234" and e["WSDL_DIST_BACKEND"] == "gloo"
+    # rank 0 (and only rank 0) asks RCCL to report its topology and its algorithm / protocol choices into a file
+    assert envs[0]["NCCL_DEBUG"] == "INFO" and "TUNING" in envs[0]["NCCL_DEBUG_SUBSYS"] and "%p" in envs[0]["NCCL_DEBUG_FILE"]
+    assert all("NCCL_DEBUG" not in e for e in envs[1:])
+    assert bench.rank_environments(2, 2, {"NCCL_DEBUG": "WARN"})[0]["NCCL_DEBUG"] == "WARN"        # the caller's setting wins
+
+
+def test_bench_dp_self_description_fields():
+    """What the first run on a real 8-GPU node must say about itself: RCCL's own report parsed into
+    (size -> algorithm, protocol), per-rank step times, measured per-bucket all-reduce times, the N = 1 reference."""
+    import bench
+    log = "\n".join([
+        "node:1:2 [0] NCCL INFO RCCL version 2.22.3+hip7.0",
+        "node:1:2 [0] NCCL INFO Channel 00/32 :    0   1   2   3   4   5   6   7",
+        "node:1:2 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1",
+        "node:1:2 [0] NCCL INFO Ring 00 : 7 -> 0 -> 1",
+        "node:1:2 [0] NCCL INFO Connected all rings",
+        "node:1:2 [0] NCCL INFO AllReduce: 50331648 Bytes -> Algo 1 proto 2 time 812.5",
+        "node:1:2 [0] NCCL INFO AllReduce: 50331648 Bytes -> Algo 1 proto 2 time 812.5",
+        "node:1:2 [0] NCCL INFO AllReduce: 1048576 Bytes -> Algo 0 proto 0 time 31.0",
+        "node:1:2 [0] NCCL INFO Broadcast: 158500000 Bytes -> Algo 1 proto 2 time 2000.0"])
+    d = bench.parse_rccl_log(log)
+    assert d["version_line"].startswith("RCCL version") and d["ring_only"] is False and d["algorithms_used"] == ["Ring", "Tree"]
+    big = [c for c in d["choices"] if c["collective"] == "AllReduce" and c["bytes"] == 50331648][0]
+    assert (big["algo"], big["proto"], big["calls"], big["model_time_us"]) == ("Ring", "Simple", 2, 812.5)
+    assert any(l.startswith("Ring 00") for l in d["topology_lines"]) and any(l.startswith("Channel 00") for l in d["topology_lines"])
+    assert bench.parse_rccl_log("AllReduce: 64 Bytes -> Algo 1 proto 0")["ring_only"] is True
+    dp = bench.dp_self_description(8, "nccl", "2.22.3", [18.9, 19.1, None], [{"bytes": 4096, "ms": 0.02, "samples": 5}],
+                                   {"ms_per_step": 18.4, "img_s_per_gpu": 869.0}, log)
+    assert dp["rccl"]["nranks"] == 8 and dp["rccl"]["backend"] == "nccl" and dp["rccl"]["debug"]["choices"]
+    assert dp["ms_per_step_by_rank"] == [18.9, 19.1, None] and dp["bucket_allreduce_ms"][0]["bytes"] == 4096
+    assert dp["n1_reference"]["img_s_per_gpu"] == 869.0
+    assert bench.dp_self_description(1, "gloo", None, [1.0], None, None, None)["rccl"]["debug"] is None
 
 
 def test_bench_wait_ranks_stops_everyone_when_one_rank_fails():

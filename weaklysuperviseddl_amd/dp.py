@@ -270,10 +270,20 @@ class GradBucketReducer:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
             from . import ops
-            main, side = torch.cuda.current_stream(view.device), ops.side_stream(view.device)
-            side.wait_stream(main)
+            side = ops.side_stream(view.device)
+            ops.stream_wait(side, ops.raw_stream(view.device))
             with torch.cuda.stream(side):
+                timed = getattr(self, "time_buckets", False)
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if timed:
+                    # measurement steps only (bench.py, after the timed region): the side stream waits for the collective
+                    # right here, so that the second event marks its completion
+                    work.wait()
+                    e1.record()
+                    self.__dict__.setdefault("_bucket_events", []).append((view.numel() * 4, e0, e1))
             self._pending.append(work)
             return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -392,6 +402,21 @@ class GradBucketReducer:
         self._fired = {}
         self._launched = [False] * len(self.bucket_size)
         self.last_early_launches, self.early_launches = self.early_launches, 0
+
+    def bucket_times_ms(self):
+        """Mean measured all-reduce time per collective size over the steps taken while ``time_buckets`` was set
+        (``_all_reduce``): [{"bytes", "ms", "samples"}] in launch order of one step."""
+        evs, self._bucket_events = self.__dict__.get("_bucket_events", []), []
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        order, acc = [], {}
+        for nbytes, e0, e1 in evs:
+            if nbytes not in acc:
+                order.append(nbytes)
+                acc[nbytes] = []
+            acc[nbytes].append(e0.elapsed_time(e1))
+        return [{"bytes": nb, "ms": round(sum(acc[nb]) / len(acc[nb]), 4), "samples": len(acc[nb])} for nb in order]
 
     def comm_budget(self, link_gbs=153.0):
         """Per bucket: bytes and the time its all-reduce needs on the node's xGMI mesh (each GPU has one link of
