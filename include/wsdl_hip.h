@@ -207,6 +207,30 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx,
                       int B, int Cin, int H, int W, int Cout, int kh, int kw,
                       int stride, int pad, int dil, int accumulate, const uint8_t* acc_mask,
                       long long dy_bs, const float* dy_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* The input gradient of n (2..4) convolutions that read the SAME input, in one launch:
+ *   dx = [accumulate: dx +] sum_i dgrad(dy[i], wt_dgrad[i])      (1x1 / 3x3, stride 1, padding dil*(k-1)/2: 'same')
+ * - the ASPP head of DeepLabV3, whose 2048-channel input feeds a 1x1 and three dilated 3x3 branches (torchvision's
+ * ASPP.forward; reference TraditionalModel/SegmentationModel.py:85 builds it) and whose input gradient the reference
+ * obtains as four conv-backward calls and three tensor adds.  The output tile accumulates over all sources' taps in
+ * registers (per-source power-of-two scales, the accumulators are moved between them exactly) and is stored once.
+ * dy / wt_dgrad / dy_amax / k / dil / dy_bs are HOST arrays of n entries (dy_bs may be NULL: dense).  Source 0 decides the
+ * output-column bands of the tap skipping: pass the smallest dilation > 1 first.  wsdl_conv2d_dgrad_multi_ok says whether a
+ * geometry is served (else: chain wsdl_conv2d_dgrad calls with accumulate = 1). */
+/* n (2..4) forward convolutions of ONE input in one launch - ASPP's 1x1 and three dilated 3x3 branches (torchvision's
+ * ASPP.forward, built by reference TraditionalModel/SegmentationModel.py:85): y[i] = conv(x, w[i]), 1x1 / 3x3, stride 1, 'same'
+ * padding, raw outputs (the BatchNorm kernels follow).  The branches execute 1..9 taps per pixel tile (padding taps are
+ * skipped): launched one by one each ends with idle CUs behind its longest tiles; here the workgroups of all problems form
+ * one grid, heaviest problem first, tiles of more than two taps cut into K slices (slabs in the workspace + the fixed-order
+ * reduce).  wt_fwd / y / k / dil / y_bs: HOST arrays of n entries (y_bs may be NULL: dense). */
+int wsdl_conv2d_fwd_group_ok(int n, int B, int Cin, int H, int W, int Cout);
+size_t wsdl_conv2d_fwd_group_workspace(int n, const int* k, const int* dil, int B, int Cin, int H, int W, int Cout);
+int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, float* const* y, const int* k, const int* dil,
+                          int B, int Cin, int H, int W, int Cout, long long x_bs, const long long* y_bs,
+                          const float* x_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream);
+int wsdl_conv2d_dgrad_multi_ok(int n, int B, int Cin, int H, int W, int Cout);
+int wsdl_conv2d_dgrad_multi(int n, const float* const* dy, const void* const* wt_dgrad, const float* const* dy_amax,
+                            const int* k, const int* dil, const long long* dy_bs, float* dx, int B, int Cin, int H, int W,
+                            int Cout, int accumulate, wsdl_stream_t stream);
 
 /* dw[Cout][Cin][kh][kw] = sum_{b,oh,ow} dy * x_shifted  (+ dw if accumulate).  Split over pixel
  * ranges into fp32 slabs in `ws`, summed in fixed order by a second kernel (bitwise reproducible). */

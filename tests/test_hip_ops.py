@@ -1099,3 +1099,69 @@ def test_wgrad_direct_fragments_equal_the_lds_staged_kernel(dev, case):
         ops.set_option("wgrad_dyraw", 1)
     assert torch.equal(raw, pre) and torch.equal(raw, outs[1]), case
     assert_close(outs[0], wr.grad, what=f"wgrad {case}")
+
+
+@pytest.mark.parametrize("B,C,Co,H", [(16, 2048, 256, 32), (8, 2048, 256, 64), (16, 1024, 256, 32)])
+def test_dgrad_multi_equals_the_chain_of_dgrads(dev, B, C, Co, H):
+    """wsdl_conv2d_dgrad_multi (ASPP: the input gradient of the 1x1 and the three dilated 3x3 branches in ONE launch, the output
+    tile accumulating over all sources' taps) against the chain of wsdl_conv2d_dgrad calls it replaces and against float64
+    on a sample of output pixels; operands of very different magnitudes per source exercise the exact rescaling of the
+    accumulators between sources."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B + C)
+    ks, dils = [1, 3, 3, 3], [1, 12, 24, 36]
+    scales = [1.0, 3e-3, 40.0, 1e-5]
+    ws = [torch.randn(Co, C, k, k, device=dev, generator=g) / (C * k * k) ** 0.5 for k in ks]
+    dys = [torch.randn(B, Co, H, H, device=dev, generator=g) * sc for sc in scales]
+    wds = [ops.prep_weights(w, False, True)[1] for w in ws]
+    xshape = (B, C, H, H)
+    if not ops.dgrad_multi_ok(4, xshape, Co):
+        pytest.skip("geometry not served by the multi-source kernel")
+    base = torch.randn(xshape, device=dev, generator=g)
+    chain = base.clone()
+    for dy, wd, w, d in zip(dys, wds, ws, dils):
+        chain = ops.conv2d_dgrad(dy, wd, w.shape, xshape, 1, d * (w.shape[2] - 1) // 2, d, accumulate_into=chain)
+    order = [1, 2, 3, 0]                                              # smallest dilation first (it decides the column bands)
+    multi = ops.conv2d_dgrad_multi([dys[i] for i in order], [wds[i] for i in order], [tuple(ws[i].shape) for i in order],
+                                   [dils[i] for i in order], xshape, accumulate_into=base.clone())
+    plain = ops.conv2d_dgrad_multi([dys[i] for i in order], [wds[i] for i in order], [tuple(ws[i].shape) for i in order],
+                                   [dils[i] for i in order], xshape)
+    torch.cuda.synchronize()
+    scale = chain.abs().max().item()
+    assert ((multi - chain).abs().max().item()) <= 2e-5 * scale
+    assert ((plain + base - chain).abs().max().item()) <= 2e-5 * scale
+    # float64 on a few output positions (all channels): dx[b, :, y, x] = sum_i sum_taps W_i[:, :, ky, kx]^T dy_i[b, :, y + pad - ky d, ...]
+    ref_pts = [(0, 0, 0), (B - 1, H - 1, H - 1), (1, 13, 7), (2, H // 2, H // 2), (3, 5, H - 2)]
+    for b, y, x in ref_pts:
+        acc = base[b, :, y, x].double().cpu()
+        for dy, w, d in zip(dys, ws, dils):
+            k = w.shape[2]
+            pad = d * (k - 1) // 2
+            for ky in range(k):
+                for kx in range(k):
+                    oy, ox = y + pad - ky * d, x + pad - kx * d
+                    if 0 <= oy < H and 0 <= ox < H:
+                        acc += w[:, :, ky, kx].double().cpu().t() @ dy[b, :, oy, ox].double().cpu()
+        err = (multi[b, :, y, x].double().cpu() - acc).abs().max().item()
+        assert err <= 1e-5 * max(acc.abs().max().item(), 1e-30), (b, y, x, err)
+
+
+@pytest.mark.parametrize("B,C,Co,H", [(16, 2048, 256, 32), (8, 2048, 256, 64), (4, 512, 256, 32)])
+def test_fwd_group_equals_the_single_launches(dev, B, C, Co, H):
+    """wsdl_conv2d_fwd_group (ASPP's four branch convolutions as ONE grid, tiles of more than two taps cut into K slices)
+    against one wsdl_conv2d_fwd launch per branch: the same products in another order of summation."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(B * 3 + C)
+    ks, dils = [1, 3, 3, 3], [1, 12, 24, 36]
+    x = torch.randn(B, C, H, H, device=dev, generator=g)
+    ws = [torch.randn(Co, C, k, k, device=dev, generator=g) / (C * k * k) ** 0.5 for k in ks]
+    wfs = [ops.prep_weights(w, True, False)[0] for w in ws]
+    if not ops.fwd_group_ok(4, tuple(x.shape), Co):
+        pytest.skip("geometry not served by the grouped kernel")
+    single = [ops.conv2d_fwd(x, wf, w.shape, 1, d * (w.shape[2] - 1) // 2, d) for wf, w, d in zip(wfs, ws, dils)]
+    grouped = ops.conv2d_fwd_group(x, wfs, [tuple(w.shape) for w in ws], dils)
+    again = ops.conv2d_fwd_group(x, wfs, [tuple(w.shape) for w in ws], dils)
+    torch.cuda.synchronize()
+    for a, b, c in zip(single, grouped, again):
+        assert ((a - b).abs().max() / a.abs().max()).item() < 1e-5       # K up to 18432 summed in another order
+        assert torch.equal(b, c)                                       # fixed-order reduce: bitwise reproducible

@@ -69,6 +69,25 @@ class ASPP(nn.Module):
             cat = torch.empty(B, self.project[0].in_channels, H, W, device=x.device, dtype=torch.float32)
             slot = ops.amax_slot(x.device) if ops.CONV_ARITH[0] == 1 else None
             outs, off = [], 0
+            convs = [b[0] for b in branches[:-1]]
+            bns = [b[1] for b in branches[:-1]]
+            if (ops.ASPP_MULTI[0] and torch.is_grad_enabled() and x.requires_grad and len(set(cs)) == 1
+                    and all(m.stride == 1 and m.bias is None and m.weight.requires_grad and m.padding == m.dilation * (m.kernel_size - 1) // 2
+                            and getattr(m.weight, "_wsdl_grad_sink", None) is not None for m in convs)
+                    and all(bn.weight.requires_grad and getattr(bn.weight, "_wsdl_grad_sink", None) is not None
+                            and bn.momentum == bns[0].momentum and bn.eps == bns[0].eps for bn in bns)
+                    and ops.dgrad_multi_ok(len(convs), tuple(x.shape), cs[0])):
+                # the four convolution branches as ONE node: their input gradients are one launch (ops._ConvBNBranches)
+                holders = []
+                for c in cs:
+                    holders.append([cat[:, off:off + c], slot])
+                    off += c
+                for bn in bns:
+                    bn._pending_steps += 1
+                res = ops.conv_bn_branches(x, list(zip(convs, bns, holders)), bns[0].momentum, bns[0].eps)
+                outs, x = list(res[:-1]), res[-1]
+                outs.append(branches[-1](x))
+                return self.project(ops.concat_into(cat, slot, outs))
             for b, c in zip(branches[:-1], cs):
                 y, x = wnn.conv_bn(x, b[0], b[1], True, passthrough=True, out_holder=[cat[:, off:off + c], slot])
                 outs.append(y)

@@ -34,6 +34,13 @@ SIGNATURES = {
     "wsdl_conv2d_igemm_workspace": (_sz, [_i] * 11),
     "wsdl_conv2d_prep_weights_multi": (_i, [_vp, _i, _i, _vp]),
     "wsdl_conv2d_dgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _vp, _ll, _vp, _vp, _sz, _vp]),
+    "wsdl_conv2d_fwd_group_ok": (_i, [_i] * 6),
+    "wsdl_conv2d_fwd_group_workspace": (_sz, [_i, C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i]),
+    "wsdl_conv2d_fwd_group": (_i, [_i, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i), _i, _i, _i, _i, _i, _ll,
+                                   C.POINTER(_ll), _vp, _vp, _sz, _vp]),
+    "wsdl_conv2d_dgrad_multi_ok": (_i, [_i] * 6),
+    "wsdl_conv2d_dgrad_multi": (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
+                                     C.POINTER(_ll), _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
     "wsdl_amax": (_i, [_vp, _i, _ll, _ll, _vp, _i, _vp]),

@@ -28,6 +28,16 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// an additional source of a multi-source launch (conv_split.h, MS): operand tensor, weights, scale and tap geometry
+struct ConvSrc {
+    const float* x;
+    const float* wt;
+    const float* x_amax;
+    int KH, KW, bh, ch, K, Cin;
+    long long x_bs;
+    unsigned x_bytes;
+};
+
 struct ConvP {
     const float* x;
     const float* wt;   // [K][Cout]
@@ -58,6 +68,8 @@ struct ConvP {
     // written out by the BatchNorm backward
     const uint8_t* acc_mask;
     const float* acc_base;
+    int nsrc;              // multi-source launches: number of ADDITIONAL sources in src[] (0: an ordinary convolution)
+    ConvSrc src[3];
 };
 
 __device__ __forceinline__ float acc_prev(const ConvP& p, const float* ptr) {
@@ -1302,6 +1314,13 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
+    if (p.nsrc > 0) {        // several convolutions accumulated into one output (conv_split.h, MS)
+        if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2, false, true>), grid, dim3(512), 0, s, p);
+        else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1, false, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0, false, true>), grid, dim3(512), 0, s, p);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2>), grid, dim3(512), 0, s, p);
     else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
@@ -1436,6 +1455,10 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         q.b_tile0[nb > 1 ? nb : 0] = tiles;
         q.grid_x = nb > 1 ? tiles : 0;
         int rc;
+        if (p.nsrc > 0 && !t256) {
+            wsdl::set_error("conv: a multi-source launch needs the 256x128 split form (rows a multiple of 256, >= 256 tiles)");
+            return WSDL_EINVAL;
+        }
         if (t256) {
             rc = launch_split_256x128(q, s);
         } else
@@ -1867,6 +1890,191 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
     p.x_amax = dy_amax; p.y_amax = nullptr;
     return launch_igemm_sliced(p, H * W, (long long)Cout * OH * OW, wsdl::as_stream(stream),
                                2.0 * (double)B * OH * OW * (double)Cout * kh * kw * Cin, ws, ws_bytes);
+}
+
+// ---- several forward convolutions of ONE input in one launch (conv_split.h: conv_igemm_split_group_kernel) ----------------
+// K slices per problem: a tile executes 1 .. T taps (padding taps are skipped); slices of about two taps each keep the
+// longest workgroup of the launch short against the launch itself (the dispatcher then balances the CUs)
+static int group_ksplit(int max_taps) { return std::max(1, std::min(4, max_taps / 2)); }
+
+static int group_max_taps(int H, int W, int k, int dil) {
+    if (k == 1) return 1;
+    int rows = 1, cols = 1;                      // centre tap + the shifted ones that can reach a real pixel ('same' padding)
+    if (dil < H) rows += 2;
+    if (dil < W) cols += 2;
+    return rows * cols;
+}
+
+int wsdl_conv2d_fwd_group_ok(int n, int B, int Cin, int H, int W, int Cout) {
+    if (n < 2 || n > 4 || !g_conv_split || !g_tile256) return 0;
+    if (Cout % 256 != 0 || Cin % 16 != 0 || (H * W) % 4 != 0) return 0;
+    if (((long long)(B - 1) * Cin * H * W + (long long)Cin * H * W) * 4 > (1ll << 31) - 4) return 0;
+    if (wsdl::cdiv((long long)B * H * W, 128) % 8 != 0) return 0;        // every problem starts on a multiple of 8 workgroups
+    return 1;
+}
+
+size_t wsdl_conv2d_fwd_group_workspace(int n, const int* k, const int* dil, int B, int Cin, int H, int W, int Cout) {
+    if (!k || !dil || !wsdl_conv2d_fwd_group_ok(n, B, Cin, H, W, Cout)) return 0;
+    size_t total = 256;
+    for (int i = 0; i < n; ++i) {
+        const int ks = group_ksplit(group_max_taps(H, W, k[i], dil[i]));
+        if (ks > 1) total += wsdl::align_up((size_t)ks * Cout * B * H * W * sizeof(float), 256);
+    }
+    return total;
+}
+
+int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, float* const* y, const int* k, const int* dil,
+                          int B, int Cin, int H, int W, int Cout, long long x_bs, const long long* y_bs,
+                          const float* x_amax, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+    WSDL_REQUIRE(x && wt_fwd && y && k && dil, "conv2d_fwd_group: null pointer");
+    WSDL_REQUIRE(wsdl_conv2d_fwd_group_ok(n, B, Cin, H, W, Cout), "conv2d_fwd_group: geometry not supported (see "
+                 "wsdl_conv2d_fwd_group_ok): %d problems, B %d, %d -> %d channels, %d x %d", n, B, Cin, Cout, H, W);
+    WSDL_REQUIRE(!g_conv_arith || x_amax, "conv2d_fwd_group: the fp16x2 kernels need x_amax");
+    WSDL_REQUIRE(ws_bytes >= wsdl_conv2d_fwd_group_workspace(n, k, dil, B, Cin, H, W, Cout) && (ws || ws_bytes == 0),
+                 "conv2d_fwd_group: workspace too small");
+    hipStream_t s = wsdl::as_stream(stream);
+    ConvGroup grp{};
+    grp.n = n;
+    // heaviest problem first: most taps per tile first (the dispatcher starts workgroups in index order)
+    int order[4] = {0, 1, 2, 3};
+    std::stable_sort(order, order + n, [&](int a, int b) {
+        return group_max_taps(H, W, k[a], dil[a]) > group_max_taps(H, W, k[b], dil[b]); });
+    unsigned char* wsp = static_cast<unsigned char*>(ws);
+    int start = 0;
+    double flops = 0.0, executed = 0.0, bytes = 4.0 * (double)B * Cin * H * W;
+    const long long xbs = x_bs ? x_bs : (long long)Cin * H * W;
+    for (int j = 0; j < n; ++j) {
+        const int i = order[j];
+        WSDL_REQUIRE(wt_fwd[i] && y[i], "conv2d_fwd_group: null problem %d", i);
+        WSDL_REQUIRE((k[i] == 1 || k[i] == 3) && dil[i] >= 1, "conv2d_fwd_group: problem %d: 1x1 or 3x3, stride 1", i);
+        WSDL_REQUIRE(split_eligible(Cout, Cin, k[i] * k[i]), "conv2d_fwd_group: problem %d is not on the split kernels", i);
+        ConvP& p = grp.p[j];
+        const int pad = dil[i] * (k[i] - 1) / 2;
+        p.x = x; p.wt = static_cast<const float*>(wt_fwd[i]); p.y = y[i];
+        p.B = B; p.Cin = Cin; p.H = H; p.W = W; p.Cout = Cout; p.OH = H; p.OW = W; p.KH = p.KW = k[i];
+        p.ah = 1; p.bh = dil[i]; p.ch = -pad; p.sh = 1;
+        p.K = k[i] * k[i] * Cin;
+        p.x_bs = xbs;
+        p.y_bs = (y_bs && y_bs[i]) ? y_bs[i] : (long long)Cout * H * W;
+        p.res_bs = p.y_bs;
+        WSDL_REQUIRE(p.x_bs >= (long long)Cin * H * W && p.y_bs >= (long long)Cout * H * W, "conv2d_fwd_group: batch stride smaller than an image");
+        p.P = B * H * W;
+        p.x_bytes = (unsigned)(((long long)(B - 1) * p.x_bs + (long long)Cin * H * W) * 4);
+        p.x_amax = x_amax;
+        p.ow0 = 0; p.own = W; p.nb = 1;
+        Band bands[8];
+        int nb = 1;
+        bands[0] = Band{0, W};
+        if (g_col_bands) nb = column_bands(W, W, p.ah, p.bh, p.ch, p.sh, p.KW, bands);
+        int tiles = 0;
+        for (int b = 0; b < nb && nb > 1; ++b) {
+            p.b_ow0[b] = bands[b].ow0;
+            p.b_own[b] = bands[b].own;
+            p.b_tile0[b] = tiles;
+            tiles += wsdl::cdiv((long long)B * H * bands[b].own, 128);
+        }
+        p.nb = nb;
+        p.b_tile0[nb > 1 ? nb : 0] = tiles;
+        const int gx = nb > 1 ? tiles : wsdl::cdiv(p.P, 128), gy = Cout / 256;
+        const int ks = group_ksplit(group_max_taps(H, W, k[i], dil[i]));
+        p.ksplit = ks;
+        if (ks > 1) {
+            p.slab = reinterpret_cast<float*>(wsp);
+            wsp += wsdl::align_up((size_t)ks * Cout * p.P * sizeof(float), 256);
+        }
+        p.xcd_py = (start % 8 == 0) ? choose_xcd_py(p, gx, gy) : 0;
+        grp.start[j] = start;
+        grp.gx[j] = gx;
+        grp.gy[j] = gy;
+        start += gx * gy * ks;
+        const double f = 2.0 * p.P * (double)Cout * p.K;
+        flops += f;
+        if (wsdl::prof_enabled()) {
+            for (int b = 0; b < nb; ++b) {
+                ConvP q = p;
+                q.ow0 = bands[b].ow0; q.own = bands[b].own; q.P = B * H * q.own;
+                executed += f * ((double)q.own / W) * igemm_executed_fraction(q, 128);
+            }
+        }
+        bytes += 4.0 * ((double)p.K * Cout + (double)p.P * Cout);
+    }
+    grp.start[n] = start;
+    {
+        wsdl::ProfScope prof(WSDL_PROF_SPLIT_256x128, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
+        if (g_conv_arith == 2)
+            hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 2>), dim3(start), dim3(512), 0, s, grp);
+        else if (g_conv_arith)
+            hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 1>), dim3(start), dim3(512), 0, s, grp);
+        else
+            hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 0>), dim3(start), dim3(512), 0, s, grp);
+        WSDL_LAUNCH_CHECK();
+    }
+    for (int j = 0; j < n; ++j) {
+        const ConvP& p = grp.p[j];
+        if (p.ksplit <= 1) continue;
+        const long long total = (long long)p.Cout * p.P;
+        const bool vec4 = p.y_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+        if (vec4)
+            hipLaunchKernelGGL(conv_splitk_reduce_vec4_kernel, dim3((int)std::min<long long>((total / 4 + 255) / 256, 8192)),
+                               dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((int)std::min<long long>((total + 255) / 256, 4096)),
+                               dim3(256), 0, s, p);
+        WSDL_LAUNCH_CHECK();
+    }
+    return WSDL_OK;
+}
+
+// Is the one-launch input gradient of n convolutions over the same input available for this geometry (what
+// wsdl_conv2d_dgrad_multi requires beyond its arguments being well-formed)?
+int wsdl_conv2d_dgrad_multi_ok(int n, int B, int Cin, int H, int W, int Cout) {
+    if (n < 2 || n > 4 || !g_conv_split || !g_tile256) return 0;
+    if (Cin % 256 != 0 || Cout % 16 != 0) return 0;
+    if ((long long)wsdl::cdiv((long long)B * H * W, 128) * (Cin / 256) < 256) return 0;                  // the 256 x 128 form's own rule
+    if ((long long)wsdl::cdiv((long long)B * H * W, 128) * wsdl::cdiv(Cin, 128) < g_tile_threshold) return 0;
+    if (igemm_ksplit(B * H * W, Cin, Cout, 9, 1) != 1) return 0;
+    if (((long long)(B - 1) * Cout * H * W + (long long)Cout * H * W) * 4 > (1ll << 31) - 4) return 0;      // one batch slice
+    return 1;
+}
+
+int wsdl_conv2d_dgrad_multi(int n, const float* const* dy, const void* const* wt_dgrad, const float* const* dy_amax,
+                            const int* k, const int* dil, const long long* dy_bs, float* dx, int B, int Cin, int H, int W,
+                            int Cout, int accumulate, wsdl_stream_t stream) {
+    WSDL_REQUIRE(dy && wt_dgrad && dy_amax && k && dil && dx, "conv2d_dgrad_multi: null pointer");
+    WSDL_REQUIRE(wsdl_conv2d_dgrad_multi_ok(n, B, Cin, H, W, Cout), "conv2d_dgrad_multi: geometry not supported (see "
+                 "wsdl_conv2d_dgrad_multi_ok): %d sources, B %d, %d -> %d channels, %d x %d", n, B, Cin, Cout, H, W);
+    ConvP p{};
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) {
+        WSDL_REQUIRE(dy[i] && wt_dgrad[i], "conv2d_dgrad_multi: null source %d", i);
+        WSDL_REQUIRE((k[i] == 1 || k[i] == 3) && dil[i] >= 1, "conv2d_dgrad_multi: source %d: 1x1 or 3x3, stride 1", i);
+        WSDL_REQUIRE(split_eligible(Cin, Cout, k[i] * k[i]), "conv2d_dgrad_multi: source %d is not on the split kernels", i);
+        WSDL_REQUIRE(!g_conv_arith || dy_amax[i], "conv2d_dgrad_multi: source %d: the fp16x2 kernels need dy_amax", i);
+        const int pad = dil[i] * (k[i] - 1) / 2;                  // 'same' padding: every source's dY has the input's H x W
+        const long long bs = (dy_bs && dy_bs[i]) ? dy_bs[i] : (long long)Cout * H * W;
+        WSDL_REQUIRE(bs >= (long long)Cout * H * W, "conv2d_dgrad_multi: batch stride smaller than an image");
+        const unsigned xbytes = (unsigned)(((long long)(B - 1) * bs + (long long)Cout * H * W) * 4);
+        WSDL_REQUIRE(((long long)(B - 1) * bs + (long long)Cout * H * W) * 4 <= (1ll << 31) - 4, "conv2d_dgrad_multi: dY extent >= 2 GiB");
+        flops += 2.0 * (double)B * H * W * (double)Cout * k[i] * k[i] * Cin;
+        if (i == 0) {
+            p.x = dy[0]; p.wt = static_cast<const float*>(wt_dgrad[0]); p.x_amax = dy_amax[0];
+            p.KH = p.KW = k[0]; p.bh = -dil[0]; p.ch = pad; p.K = k[0] * k[0] * Cout; p.x_bs = bs; p.x_bytes = xbytes;
+        } else {
+            ConvSrc& c = p.src[i - 1];
+            c.x = dy[i]; c.wt = static_cast<const float*>(wt_dgrad[i]); c.x_amax = dy_amax[i];
+            c.KH = c.KW = k[i]; c.bh = -dil[i]; c.ch = pad; c.K = k[i] * k[i] * Cout; c.Cin = Cout; c.x_bs = bs; c.x_bytes = xbytes;
+        }
+    }
+    p.nsrc = n - 1;
+    p.y = dx;
+    p.B = B; p.Cin = Cout; p.H = H; p.W = W; p.Cout = Cin; p.OH = H; p.OW = W;
+    p.ah = 1; p.sh = 1;
+    p.y_bs = (long long)Cin * H * W;
+    p.res_bs = p.y_bs;
+    p.relu = 0; p.accumulate = accumulate; p.P = B * H * W;
+    p.acc_mask = nullptr; p.acc_base = dx;
+    p.y_amax = nullptr;
+    return launch_igemm(p, wsdl::as_stream(stream), flops, nullptr, 0);
 }
 
 int wsdl_conv2d_prep_weights_multi(const wsdl_prep_desc* desc, int n, int total_blocks, wsdl_stream_t stream) {

@@ -152,8 +152,20 @@ __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_t
 // LDS rows become 128 bytes, unit u = 4 piece + (k / 8) of 16 bytes stored at unit u ^ (row & 7): conflict-free for the
 // operand reads (lane l: row l & 15, k-group l >> 4 - checked against the b128 lane groups) and for the activations'
 // stores (8 consecutive pixel rows, one unit).
-template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
-__global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
+//
+// MS (multi-source; round 5): the output tile accumulates over SEVERAL convolutions that share their output - the input
+// gradient of a tensor that fed several convolutions (ASPP: dX = sum over the 1x1 and the three dilated branches of
+// dgrad(dY_b, W_b)).  One launch, one accumulator, one store instead of a chain of launches that each read the previous
+// sum back and write it again (4 x 134 MB written, 3 x 134 MB read at B = 16), and the branches' uneven padding-tap
+// counts average out inside every workgroup.  Source 0 is ConvP's own (x, wt, ...), sources 1 .. p.nsrc are p.src[]; each
+// has its operand tensor, weights, scales and tap geometry; rows (Cout), the output and the input map's size are shared.
+// Between sources the pipeline drains and the accumulators move to the next source's power-of-two units (exact).
+//
+// The body is a device function of (problem, tile indices, grid extent): conv_igemm_split_kernel runs it on its own grid,
+// conv_igemm_split_group_kernel (round 5) on a grid that strings several problems together (ASPP's four branches in one launch).
+template <int BM, int BN, int WM, int BK, int NT, int AR, bool MF, bool MS>
+__device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int bx_in, const int by_in, const int bz,
+                                                      const int grid_x, const int grid_y) {
     static_assert(!MF || (AR >= 1 && BK == 32), "16x16x32 form: fp16x2, K chunk 32");
     using Ar = SplitArith<AR>;
     using frag = typename Ar::frag;
@@ -181,14 +193,15 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = bx_in, by = by_in;
     if (p.xcd_py > 0) {
-        // host guarantees: gridDim.x * gridDim.y % 8 == 0, gridDim.y % py == 0, gridDim.x % (8 / py) == 0
-        const int gx = gridDim.x;
+        // host guarantees: grid_x * grid_y % 8 == 0, grid_y % py == 0, grid_x % (8 / py) == 0 (and, in a group, that the
+        // problem's first workgroup has a linear index that is a multiple of 8: workgroup L runs on XCD L % 8)
+        const int gx = grid_x;
         const int L = by * gx + bx;
         const int xcd = L & 7, idx = L >> 3;
         const int py = p.xcd_py, px = 8 / py;
-        const int lx = gx / px, ly = (int)gridDim.y / py;
+        const int lx = gx / px, ly = grid_y / py;
         bx = (xcd / py) * lx + idx % lx;
         by = (xcd % py) * ly + idx / lx;
     }
@@ -210,17 +223,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
     const int OHOW = p.OH * p.OW;
     const int HW = p.H * p.W;
 
-    const int wbytes = (p.K / 16) * p.Cout * K16B;       // the layout without its trailer
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wt), 0, wbytes, 0x00020000);
-    float xs = 1.f, out_scale = 1.f;
-    if constexpr (AR >= 1) {
-        int ex, ew;
-        xs = pow2_scale(*p.x_amax, ex);
-        (void)pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(p.wt) + wbytes), ew);
-        out_scale = pow2(-(ex + ew));
-    }
-
     const int pl = tid % BN, kr = tid / BN;
     const int pix = n0 + pl;
     const bool pix_ok = pix < W_P;
@@ -231,55 +233,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
         const int r = pix - pb * OHW;
         poh = r / w_own;
         pow_ = w_ow0 + (r - poh * w_own);
-    }
-    const unsigned img_off = (unsigned)((long long)pb * p.x_bs) + (unsigned)(kr * B_PER * HW);   // elements
-
-    auto tap_src = [&](int t, int& sp) {
-        const int ti = t / p.KW, tj = t - ti * p.KW;
-        const int nh = poh * p.ah + ti * p.bh + p.ch;
-        const int nw = pow_ * p.ah + tj * p.bh + p.ch;
-        bool ok = pix_ok && nh >= 0 && nw >= 0;
-        int ih = nh, iw = nw;
-        if (p.sh != 1) {
-            ih = nh / p.sh;
-            iw = nw / p.sh;
-            ok = ok && (ih * p.sh == nh) && (iw * p.sh == nw);
-        }
-        ok = ok && ih < p.H && iw < p.W;
-        sp = ih * p.W + iw;
-        return ok;
-    };
-
-    const int T = p.KH * p.KW;
-    const int cpt = p.Cin / BK;
-    int nv = 0;
-    for (int t = 0; t < T; ++t) {
-        int sp;
-        const bool ok = tap_src(t, sp);
-        if (__syncthreads_or(ok)) {
-            if (tid == 0) vtaps[nv] = t;
-            ++nv;
-        }
-    }
-    const int nq_all = nv * cpt;
-    const int q0 = p.ksplit > 1 ? (int)((long long)nq_all * blockIdx.z / p.ksplit) : 0;
-    const int q1 = p.ksplit > 1 ? (int)((long long)nq_all * (blockIdx.z + 1) / p.ksplit) : nq_all;
-    const int nq = q1 - q0;
-    __syncthreads();
-
-    // weights: unit u of the chunk = (k-step, row, 16-byte part); a k16 slab of the row tile is contiguous
-    unsigned voff_a[A_U], lds_a[A_U];
-#pragma unroll
-    for (int e = 0; e < A_U; ++e) {
-        const int u = tid + e * NT;
-        const int ks = u / A_UPS, v = u - ks * A_UPS;
-        const int row = v / UPR, part = v - row * UPR;
-        voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
-                        ? (unsigned)(ks * p.Cout * K16B + (m0 * UPR + v) * 16) : kOOB;
-        if constexpr (MF)                               // part = 2 piece + half of the k16 slab -> unit 4 piece + 2 ks + half
-            lds_a[e] = (unsigned)(row * ROW + (((4 * (part >> 1) + 2 * ks + (part & 1)) ^ (row & 7)) << 4));
-        else
-            lds_a[e] = (unsigned)(row * ROW + ks * K16B + part * 16);
     }
 
     constexpr int TS = MF ? 16 : 32;                     // side of an MFMA output tile
@@ -298,6 +251,100 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
                 acc[i][j][r] = 0.f;
                 if constexpr (LO) acc_lo[i][j][r] = 0.f;
             }
+    // lane -> (column of the output tile, row group): D[row][col] of v_mfma_f32_32x32x16 / 16x16x32
+    const int l31 = MF ? (lane & 15) : (lane & 31), lh = MF ? (lane >> 4) : (lane >> 5);
+    auto acc_row = [&](int r) { return MF ? lh * 4 + r : (r & 3) + 8 * (r >> 2) + 4 * lh; };
+
+    float out_scale = 1.f;
+    int e_units = 0;                                     // MS: the accumulators hold sum * 2^e_units
+    const int n_src = MS ? p.nsrc + 1 : 1;
+    for (int src = 0; src < n_src; ++src) {
+    // this source's operands and tap geometry (MS = false: ConvP's own, folded at compile time)
+    // (selected field by field with constant indices: a pointer into the by-value parameter would move it to scratch)
+#define WSDL_SRC(f) ((!MS || src == 0) ? p.f : src == 1 ? p.src[0].f : src == 2 ? p.src[1].f : p.src[2].f)
+    const float* const s_x = WSDL_SRC(x);
+    const float* const s_wt = WSDL_SRC(wt);
+    const float* const s_amax = WSDL_SRC(x_amax);
+    const int s_KH = WSDL_SRC(KH), s_KW = WSDL_SRC(KW), s_bh = WSDL_SRC(bh), s_ch = WSDL_SRC(ch);
+    const int s_K = WSDL_SRC(K), s_Cin = WSDL_SRC(Cin);
+    const long long s_x_bs = WSDL_SRC(x_bs);
+    const unsigned s_x_bytes = WSDL_SRC(x_bytes);
+#undef WSDL_SRC
+
+    const int wbytes = (s_K / 16) * p.Cout * K16B;       // the layout without its trailer
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_x), 0, (int)s_x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(s_wt), 0, wbytes, 0x00020000);
+    float xs = 1.f;
+    if constexpr (AR >= 1) {
+        int ex, ew;
+        xs = pow2_scale(*s_amax, ex);
+        (void)pow2_scale(*reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(s_wt) + wbytes), ew);
+        out_scale = pow2(-(ex + ew));
+        if constexpr (MS) {
+            if (src > 0 && ex + ew != e_units) {         // the sum so far, in this source's units (a power of two: exact)
+                const float f = pow2(ex + ew - e_units);
+#pragma unroll
+                for (int i = 0; i < TMI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNI; ++j)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) {
+                            acc[i][j][r] *= f;
+                            if constexpr (LO) acc_lo[i][j][r] *= f;
+                        }
+            }
+            e_units = ex + ew;
+        }
+    }
+    const unsigned img_off = (unsigned)((long long)pb * s_x_bs) + (unsigned)(kr * B_PER * HW);   // elements
+
+    auto tap_src = [&](int t, int& sp) {
+        const int ti = t / s_KW, tj = t - ti * s_KW;
+        const int nh = poh * p.ah + ti * s_bh + s_ch;
+        const int nw = pow_ * p.ah + tj * s_bh + s_ch;
+        bool ok = pix_ok && nh >= 0 && nw >= 0;
+        int ih = nh, iw = nw;
+        if (p.sh != 1) {
+            ih = nh / p.sh;
+            iw = nw / p.sh;
+            ok = ok && (ih * p.sh == nh) && (iw * p.sh == nw);
+        }
+        ok = ok && ih < p.H && iw < p.W;
+        sp = ih * p.W + iw;
+        return ok;
+    };
+
+    const int T = s_KH * s_KW;
+    const int cpt = s_Cin / BK;
+    int nv = 0;
+    for (int t = 0; t < T; ++t) {
+        int sp;
+        const bool ok = tap_src(t, sp);
+        if (__syncthreads_or(ok)) {
+            if (tid == 0) vtaps[nv] = t;
+            ++nv;
+        }
+    }
+    const int nq_all = nv * cpt;
+    const int q0 = p.ksplit > 1 ? (int)((long long)nq_all * bz / p.ksplit) : 0;
+    const int q1 = p.ksplit > 1 ? (int)((long long)nq_all * (bz + 1) / p.ksplit) : nq_all;
+    const int nq = q1 - q0;
+    __syncthreads();
+
+    // weights: unit u of the chunk = (k-step, row, 16-byte part); a k16 slab of the row tile is contiguous
+    unsigned voff_a[A_U], lds_a[A_U];
+#pragma unroll
+    for (int e = 0; e < A_U; ++e) {
+        const int u = tid + e * NT;
+        const int ks = u / A_UPS, v = u - ks * A_UPS;
+        const int row = v / UPR, part = v - row * UPR;
+        voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
+                        ? (unsigned)(ks * p.Cout * K16B + (m0 * UPR + v) * 16) : kOOB;
+        if constexpr (MF)                               // part = 2 piece + half of the k16 slab -> unit 4 piece + 2 ks + half
+            lds_a[e] = (unsigned)(row * ROW + (((4 * (part >> 1) + 2 * ks + (part & 1)) ^ (row & 7)) << 4));
+        else
+            lds_a[e] = (unsigned)(row * ROW + ks * K16B + part * 16);
+    }
 
     u32x4 ra[A_U];
     unsigned rb[B_PER];
@@ -317,7 +364,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
             ++ld_vi;
             set_tap(ld_vi);
         }
-        const int c16 = (ld_tap * p.Cin + ld_c * BK) / 16;
+        const int c16 = (ld_tap * s_Cin + ld_c * BK) / 16;
         const unsigned soff_a = (unsigned)(c16 * p.Cout * K16B);
 #pragma unroll
         for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], soff_a, 0);
@@ -381,9 +428,6 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
         if (nq > 1) load_next();
     }
     __syncthreads();
-    // lane -> (column of the output tile, row group): D[row][col] of v_mfma_f32_32x32x16 / 16x16x32
-    const int l31 = MF ? (lane & 15) : (lane & 31), lh = MF ? (lane >> 4) : (lane >> 5);
-    auto acc_row = [&](int r) { return MF ? lh * 4 + r : (r & 3) + 8 * (r >> 2) + 4 * lh; };
     auto mfma_chunk = [&](int cur) {
         if constexpr (MF) {
             const unsigned char* Ab = As[cur] + (wm * (BM / WM) + l31) * ROW;
@@ -468,10 +512,11 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
 #endif
         lds_barrier();
     }
+    }   // sources
 
     if (p.ksplit > 1) {
         // slabs are indexed by the pixel's position in the whole output (b, oh, ow), not inside the block's column band
-        float* sl = p.slab + (long long)blockIdx.z * p.Cout * p.P;
+        float* sl = p.slab + (long long)bz * p.Cout * p.P;
 #pragma unroll
         for (int j = 0; j < TNI; ++j) {
             const int opix = n0 + wn * (BN / WN) + j * TS + l31;
@@ -522,6 +567,34 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_k
         }
     }
     if (p.y_amax) publish_amax(vmax, p.y_amax);
+}
+
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false, bool MS = false>
+__global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
+    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, MS>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// Several convolutions in ONE launch: workgroups [start[g], start[g + 1]) of the 1-D grid work on problem g, as its
+// (gx[g], gy[g], K slices) grid would have.  ASPP's branches read the same 134 MB input and execute 1 .. 9 taps per tile
+// (padding taps are skipped): launched one after the other each ends with CUs idling behind its longest tiles
+// (0.28-0.31 of the MFMA peak against 0.40-0.45 for the balanced layer4 shapes); strung together, heaviest problem first,
+// the dispatcher keeps every CU busy until the common end.
+struct ConvGroup {
+    int n;
+    int start[5];
+    int gx[4], gy[4];
+    ConvP p[4];
+};
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
+__global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_group_kernel(ConvGroup grp) {
+    const int L = blockIdx.x;
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < grp.n && L >= grp.start[i]) g = i;
+    const int local = L - grp.start[g], gx = grp.gx[g], gy = grp.gy[g];
+    const int plane = gx * gy, bz = local / plane, r = local - bz * plane;
+    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false>(grp.p[g], r % gx, r / gx, bz, gx, gy);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -640,6 +640,78 @@ def conv2d_dgrad(dy, wt_dgrad, wshape, xshape, stride, pad, dil, accumulate_into
     return dx
 
 
+def fwd_group_ok(n, xshape, cout):
+    """Does the library serve ``n`` forward convolutions of one input of ``xshape`` as one grouped launch?"""
+    B, Cin, H, W = xshape
+    return bool(lib().wsdl_conv2d_fwd_group_ok(int(n), B, Cin, H, W, int(cout)))
+
+
+def conv2d_fwd_group(x, wfs, wshapes, dils, x_amax=None, outs=None):
+    """[conv(x, w_i)] for 1x1 / 3x3 stride-1 'same' convolutions of ONE input in one launch (include/wsdl_hip.h
+    wsdl_conv2d_fwd_group): raw outputs, no epilogue."""
+    n = len(wfs)
+    if x_amax is None:
+        x_amax = amax_of(x, _split_kc(x.shape[1], 9))
+    x, x_bs = _planes(x, "x")
+    B, Cin, H, W = x.shape
+    Cout = wshapes[0][0]
+    if any(ws[0] != Cout or ws[1] != Cin for ws in wshapes):
+        raise WsdlError("conv2d_fwd_group: the problems must share their channel counts")
+    IA, PA, LA = C.c_int * n, _vp * n, C.c_longlong * n
+    ks, ds = IA(*[int(ws[2]) for ws in wshapes]), IA(*[int(d) for d in dils])
+    nws = lib().wsdl_conv2d_fwd_group_workspace(n, ks, ds, B, Cin, H, W, Cout)
+    if nws == 0:
+        raise WsdlError("conv2d_fwd_group: geometry not supported")
+    ws = workspace(nws, x.device)
+    if outs is None:
+        outs = [torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32) for _ in range(n)]
+    bss = []
+    dense = []
+    for o in outs:
+        t, bs = _planes(o, "out")
+        if t is not o:
+            raise WsdlError("conv2d_fwd_group: preallocated outputs must be dense planes")
+        dense.append(t)
+        bss.append(bs)
+    check(lib().wsdl_conv2d_fwd_group(n, _p(x), PA(*[_p(w) for w in wfs]), PA(*[_p(t) for t in dense]), ks, ds, B, Cin, H, W,
+                                      Cout, x_bs, LA(*bss), _p(x_amax), _p(ws), ws.numel(), _stream()))
+    return outs
+
+
+def dgrad_multi_ok(n, xshape, cout):
+    """Does the library serve the one-launch input gradient of ``n`` convolutions over an input of ``xshape``?"""
+    B, Cin, H, W = xshape
+    return bool(lib().wsdl_conv2d_dgrad_multi_ok(int(n), B, Cin, H, W, int(cout)))
+
+
+def conv2d_dgrad_multi(dys, wds, wshapes, dils, xshape, accumulate_into=None, dy_amaxes=None):
+    """dx = [accumulate_into +] sum_i dgrad(dys[i], wds[i]) in ONE launch (include/wsdl_hip.h wsdl_conv2d_dgrad_multi):
+    convolutions of the same input, 1x1 / 3x3, stride 1, 'same' padding.  The first source decides the column bands of
+    the padding-tap skipping."""
+    n = len(dys)
+    B, Cin, H, W = xshape
+    Cout = wshapes[0][0]
+    amaxes = []
+    dense = []
+    bss = []
+    for i in range(n):
+        if wshapes[i][0] != Cout or wshapes[i][1] != Cin:
+            raise WsdlError("conv2d_dgrad_multi: the sources must share their channel counts")
+        a = dy_amaxes[i] if dy_amaxes is not None and dy_amaxes[i] is not None else \
+            amax_of(dys[i], _split_kc(Cout, wshapes[i][2] * wshapes[i][3]))
+        t, bs = _planes(dys[i], "dy")
+        amaxes.append(a)
+        dense.append(t)
+        bss.append(bs)
+    dx = accumulate_into if accumulate_into is not None else torch.empty(xshape, device=dys[0].device, dtype=torch.float32)
+    PA, IA, LA = _vp * n, C.c_int * n, C.c_longlong * n
+    check(lib().wsdl_conv2d_dgrad_multi(n, PA(*[_p(t) for t in dense]), PA(*[_p(w) for w in wds]), PA(*[_p(a) for a in amaxes]),
+                                        IA(*[int(ws[2]) for ws in wshapes]), IA(*[int(d) for d in dils]), LA(*bss), _p(dx),
+                                        B, Cin, H, W, Cout, int(accumulate_into is not None), _stream()))
+    dx._wsdl_fresh = True
+    return dx
+
+
 def _wgrad_split(wshape):
     """May the library's fp16x2 weight-gradient kernel take this shape (then both operands need amax scalars - a read
     pass on the main stream for a tensor that carries none, so this must not claim more than the library's own rule)."""
@@ -1006,6 +1078,98 @@ class _ConvBNAct(torch.autograd.Function):
             dx = input_grad()
         return (dx, dw, dgamma if ctx.needs_input_grad[2] else None, dbeta if ctx.needs_input_grad[3] else None,
                 dres, None, None, None, None, None, None, None, None, None, None, None, None)
+
+
+ASPP_MULTI = [os.environ.get("WSDL_ASPP_MULTI", "1") != "0"]     # A/B: 0 = the branches as a chain of conv -> BatchNorm nodes
+ASPP_GROUP_FWD = [os.environ.get("WSDL_ASPP_GROUP_FWD", "1") != "0"]   # A/B: 0 = the branches' forward convolutions one launch each
+
+
+class _ConvBNBranches(torch.autograd.Function):
+    """n train-mode conv -> BatchNorm -> ReLU branches over ONE input (the 1x1 and the three dilated 3x3 branches of ASPP), each
+    writing its output into its channel slice of the concatenation buffer.  What it does differently from n chained
+    ``_ConvBNAct`` nodes is the input gradient: ONE launch that accumulates all branches' taps per output tile
+    (``conv2d_dgrad_multi``) instead of n launches that each read the running sum back and write it again.
+    Arguments: x, momentum, eps, branches = [(stride-1 padding, dilation, cache, out_holder)], then per branch
+    weight, gamma, beta, running_mean, running_var.  Returns y_0 .. y_{n-1}, x' (x routed through the node: the gradient
+    arriving for it - the pooling branch's - is the launch's ``accumulate_into``)."""
+
+    @staticmethod
+    def forward(ctx, x, momentum, eps, branches, *tensors):
+        n = len(branches)
+        params = [tensors[5 * i:5 * i + 5] for i in range(n)]
+        taps = max(w.shape[2] * w.shape[3] for (w, *_r) in params)
+        x_amax = amax_of(x, _split_kc(x.shape[1], taps) or any(_wgrad_split(w.shape) for (w, *_r) in params))
+        saved, outs, wshapes = [x], [], []
+        preps = [_cached_prep(cache, w, x.requires_grad) for (_pad, _dil, cache, _h), (w, *_r) in zip(branches, params)]
+        convs = None
+        if ASPP_GROUP_FWD[0] and fwd_group_ok(n, tuple(x.shape), params[0][0].shape[0]):
+            convs = conv2d_fwd_group(x, [pr[0] for pr in preps], [tuple(w.shape) for (w, *_r) in params],
+                                     [b[1] for b in branches], x_amax=x_amax)
+        for i, ((pad, dil, cache, holder), (w, gamma, beta, rm, rv)) in enumerate(zip(branches, params)):
+            wf, wd = preps[i]
+            conv = convs[i] if convs is not None else conv2d_fwd(x, wf, w.shape, 1, pad, dil, x_amax=x_amax)
+            y, mean, invstd, _bits = bn_train_fwd(conv, _dense(gamma), _dense(beta), rm, rv, momentum, eps, None, True,
+                                                  out=_alias(holder[0]), want_mask=True, mask_if=False, amax_into=holder[1])
+            saved += [conv, gamma, mean, invstd, wd, beta]
+            outs.append(y)
+            wshapes.append(tuple(w.shape))
+        ctx.cfg = ([(b[0], b[1]) for b in branches], wshapes, tuple(x.shape))
+        ctx.params = [(w, g, b) for (w, g, b, _rm, _rv) in params]
+        ctx.x_amax = x_amax
+        ctx.save_for_backward(*saved)
+        xv = x.view_as(x)
+        if x_amax is not None:
+            _publish_amax(xv, x_amax)
+        return (*outs, xv)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        geo, wshapes, xshape = ctx.cfg
+        n = len(geo)
+        dys, dxres = grads[:n], grads[n]
+        saved = ctx.saved_tensors
+        x = saved[0]
+        dconvs, wds = [], []
+        for i in range(n):
+            conv, gamma, mean, invstd, wd, beta = saved[1 + 6 * i:7 + 6 * i]
+            pw, pg, pb = ctx.params[i]
+            if dys[i] is None:
+                raise WsdlError("conv -> BatchNorm branches: no gradient arrived for branch %d" % i)
+            sg = _sink_of(pg)
+            if sg is None or sg is not _sink_of(pb) or _sink_of(pw) is None:
+                raise WsdlError("conv -> BatchNorm branches: the parameters must be owned by a FlatAdam (gradient sinks)")
+            fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
+            dconv, _, _, _ = bn_train_bwd(conv, dys[i], None, _dense(gamma), mean, invstd, True, False, pg.grad, pb.grad,
+                                          accumulate=not fresh, beta=beta)
+            sg.grad_ready(pg)
+            sg.grad_ready(pb)
+            pad, dil = geo[i]
+            _wgrad_into(pw, x, dconv, wshapes[i], 1, pad, dil, _sink_of(pw), ctx.x_amax)
+            dconvs.append(dconv)
+            wds.append(wd)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            into = dxres if (_owned(dxres) and tuple(dxres.shape) == tuple(xshape)) else None
+            # the source that decides the column bands first: the smallest dilation among the 3x3 branches
+            order = sorted(range(n), key=lambda i: (wshapes[i][2] == 1, geo[i][1]))
+            dx = conv2d_dgrad_multi([dconvs[i] for i in order], [wds[i] for i in order], [wshapes[i] for i in order],
+                                    [geo[i][1] for i in order], xshape, accumulate_into=into)
+            if into is None and dxres is not None:
+                dx = dx + dxres
+        elif dxres is not None:
+            dx = dxres
+        return (dx, None, None, None) + (None,) * (5 * n)
+
+
+def conv_bn_branches(x, branches, momentum, eps):
+    """``branches``: [(conv module-like with .weight/.padding/.dilation and a cache dict, bn module-like, out_holder)] - see
+    _ConvBNBranches; the caller (ASPP) has checked ``dgrad_multi_ok`` and train mode."""
+    geo, tensors = [], []
+    for conv, bn, holder in branches:
+        geo.append((conv.padding, conv.dilation, conv.__dict__.setdefault("_wsdl_cache", {}), holder))
+        tensors += [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    bump_stats_epoch()
+    return _ConvBNBranches.apply(x, momentum, eps, geo, *tensors)
 
 
 class _ConvAffineAct(torch.autograd.Function):

@@ -133,7 +133,7 @@ class PlannedTrainStep:
         return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device, float(opt.lr),
                 tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params),
                 tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale), ops.LAYOUT_EPOCH[0],
-                ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0],
+                ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0], ops.ASPP_MULTI[0], ops.ASPP_GROUP_FWD[0],
                 ops.raw_stream(images.device))
 
     def usable(self, images, masks):
