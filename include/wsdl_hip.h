@@ -445,6 +445,8 @@ int wsdl_plan_recording(void);                       /* 1 between begin and end 
 int wsdl_plan_end(void** plan_out);                  /* error (and no plan) if the sequence cannot be replayed */
 int wsdl_plan_abort(void);                           /* drop the recording in progress */
 int wsdl_plan_mark(long long tag);
+int wsdl_plan_pause(void);                           /* host section: what the library is asked to do until wsdl_plan_resume is NOT */
+int wsdl_plan_resume(void);                          /* recorded (the host repeats it itself between the segments of a replay)      */
 int wsdl_plan_poison(const char* why);               /* the caller did something between begin and end that a replay would miss */
 int wsdl_plan_replay(void* plan);
 int wsdl_plan_replay_segment(void* plan, int segment);

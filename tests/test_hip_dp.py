@@ -366,3 +366,68 @@ def test_alternating_loop_under_dp_takes_the_same_steps_on_every_rank(dev, tmp_p
     got = torch.load(out, weights_only=False)
     assert got["steps"] == [2, 2]                                  # min(2, 1) batches per epoch x 2 epochs
     assert torch.equal(got["params"][0], got["params"][1])
+
+
+def _worker_plan_dp(rank, world, port, out, backend, planned):
+    """Ten data-parallel steps: with ``planned`` the steps after the reducer has settled are launch-plan replays whose
+    collectives / wait() run as host sections."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", WSDL_PLAN_STEP="1" if planned else "0")
+    if backend == "gloo":
+        os.environ["WSDL_DIST_BACKEND"] = "gloo"
+    else:
+        os.environ.pop("WSDL_DIST_BACKEND", None)
+        os.environ["WSDL_FORCE_DIST"] = "1"
+    torch.set_num_threads(2)
+    torch.cuda.set_device(0)
+    import torch.distributed as dist
+    from weaklysuperviseddl_amd.dp import init_distributed, GradBucketReducer
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+    dev = torch.device("cuda:0")
+    init_distributed()
+    model = _seg_model(dev, seed=rank)
+    opt = make_optimizer(model, lr=1e-4)
+    red = GradBucketReducer(opt, modules=[model])
+    batches = [tuple(t.to(dev) for t in _shard(rank if world > 1 else 0)), tuple(t.to(dev).flip(0).contiguous() for t in _shard(rank if world > 1 else 0))]
+    losses = []
+    for i in range(10):
+        losses.append(float(train_step(model, opt, *batches[i % 2])))
+    torch.cuda.synchronize()
+    st = next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
+    params = opt.flat_param.detach().cpu()
+    gathered = [torch.zeros_like(params) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(gathered, params)
+    else:
+        gathered = [params]
+    if rank == 0:
+        torch.save({"params": gathered, "losses": losses, "replays": 0 if st is None else st.replays,
+                    "disabled": None if st is None else st.disabled,
+                    "sections": 0 if st is None or st.plan is None else len(st.plan.sections),
+                    "buckets": len(red.bucket_size), "early": red.last_early_launches,
+                    "ctl": (red.control_exchanges_blocking, red.control_exchanges_async)}, out)
+    if world > 1:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
+def test_data_parallel_steps_replayed_from_a_plan_equal_the_eager_ones(dev, tmp_path, backend, world):
+    """Under a GradBucketReducer the bucket all-reduces (launched from backward hooks in an eager step) and ``wait()`` become
+    HOST SECTIONS of the step's launch plan: a replay issues the same collectives at the same places of the launch sequence.
+    One rank over RCCL (the collectives themselves on the one GPU there is) and two ranks over gloo sharing the GPU: ten
+    steps with replays equal ten eager data-parallel steps bit for bit, on every replica."""
+    res = {}
+    for planned in (False, True):
+        out = str(tmp_path / f"plan_dp_{int(planned)}.pt")
+        mp.spawn(_worker_plan_dp, args=(world, _free_port(), out, backend, planned), nprocs=world, join=True)
+        res[planned] = torch.load(out)
+    a, b = res[False], res[True]
+    assert b["disabled"] is None and b["replays"] >= 3, (b["disabled"], b["replays"])
+    assert b["sections"] == b["buckets"] + 1 or b["sections"] >= 2, b["sections"]           # every non-empty bucket + wait()
+    assert a["losses"] == b["losses"]
+    for pa, pb in zip(a["params"], b["params"]):
+        assert torch.equal(pa, pb)
+    assert all(torch.equal(b["params"][0], p) for p in b["params"])                         # replicas identical
+    assert b["early"] == a["early"]

@@ -90,6 +90,8 @@ SIGNATURES = {
     "wsdl_plan_end": (_i, [C.POINTER(_vp)]),
     "wsdl_plan_abort": (_i, []),
     "wsdl_plan_mark": (_i, [_ll]),
+    "wsdl_plan_pause": (_i, []),
+    "wsdl_plan_resume": (_i, []),
     "wsdl_plan_poison": (_i, [C.c_char_p]),
     "wsdl_plan_replay": (_i, [_vp]),
     "wsdl_plan_replay_segment": (_i, [_vp, _i]),

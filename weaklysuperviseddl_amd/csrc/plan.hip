@@ -52,6 +52,7 @@ struct Plan {
 };
 
 Plan* g_plan_rec = nullptr;
+static Plan* g_plan_paused = nullptr;      // wsdl_plan_pause: the recording a host section interrupted
 
 void plan_add_kernel(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, std::shared_ptr<void> storage,
                      void* const* argv, int argc) {
@@ -202,6 +203,8 @@ int wsdl_plan_end(void** plan_out) {
 
 int wsdl_plan_abort(void) {
     delete wsdl::g_plan_rec;
+    delete wsdl::g_plan_paused;
+    wsdl::g_plan_paused = nullptr;
     wsdl::g_plan_rec = nullptr;
     return WSDL_OK;
 }
@@ -214,6 +217,20 @@ int wsdl_plan_mark(long long tag) {
         p->marks.push_back(p->ops.size());
         p->ops.push_back(op);
     }
+    return WSDL_OK;
+}
+
+int wsdl_plan_pause(void) {
+    WSDL_REQUIRE(wsdl::g_plan_rec != nullptr && wsdl::g_plan_paused == nullptr, "plan_pause: no recording to pause");
+    wsdl::g_plan_paused = wsdl::g_plan_rec;
+    wsdl::g_plan_rec = nullptr;
+    return WSDL_OK;
+}
+
+int wsdl_plan_resume(void) {
+    WSDL_REQUIRE(wsdl::g_plan_paused != nullptr && wsdl::g_plan_rec == nullptr, "plan_resume: no paused recording");
+    wsdl::g_plan_rec = wsdl::g_plan_paused;
+    wsdl::g_plan_paused = nullptr;
     return WSDL_OK;
 }
 

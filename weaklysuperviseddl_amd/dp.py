@@ -132,6 +132,7 @@ class GradBucketReducer:
         self.active = dist.is_initialized() and (self.world > 1 or _forced())
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step_hook = self.wait
+        optimizer._wsdl_reducer = self
         n = optimizer.numel
         nparams = len(optimizer.params)
         self._segmented = getattr(optimizer, "segments", None) is not None
@@ -253,9 +254,26 @@ class GradBucketReducer:
                 return
             self._launch(b, early)
 
+    def plan_ready(self):
+        """May a training step under this reducer be recorded into / replayed from a launch plan (plan.PlannedTrainStep)?  Only
+        once the firing set has settled (steady mode): then every step launches the same buckets from the same places and
+        ``wait()`` finds nothing new - the collectives and ``wait()`` are the plan's host sections.  A rank that drops out
+        of steady mode (a deviation seen in ``wait()``) goes back to eager steps; eager and replayed steps issue the SAME
+        collectives in the same order, so ranks may even differ in which of the two they run."""
+        if not self.active:
+            return True
+        return self._steady and not self._early and not self._held and self._error is None and not self._accumulating
+
     def _launch(self, b, early=False):
-        self._launched[b] = True
         lo, hi = self._range[b]
+        if hi > lo and self.opt.flat_grad.is_cuda and not self._early:
+            # behind everything both streams hold so far (recorded into a launch plan), then the collective itself as a host section
+            from . import ops
+            side = ops.side_stream(self.opt.flat_grad.device)
+            ops.stream_wait(side, ops.raw_stream(self.opt.flat_grad.device))
+            ops.host_section(self._launch_section, b, early)
+            return
+        self._launched[b] = True
         work = None
         if hi > lo:
             if early:
@@ -265,13 +283,23 @@ class GradBucketReducer:
         if self._early:
             self.opt.step_segment(b, after=work)        # Adam on the bucket's parameters, behind its collective
 
-    def _all_reduce(self, view):
+    def _launch_section(self, b, early):
+        """Bucket b's all-reduce from the side stream + the bookkeeping of ``_launch`` - the part of a bucket launch that a
+        replayed plan repeats live (no gradient hook fires in a replay)."""
+        self._launched[b] = True
+        if early:
+            self.early_launches += 1
+        lo, hi = self._range[b]
+        self._all_reduce(self.opt.flat_grad[lo:hi], ordered=True)
+
+    def _all_reduce(self, view, ordered=False):
         if view.is_cuda:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
             from . import ops
             side = ops.side_stream(view.device)
-            ops.stream_wait(side, ops.raw_stream(view.device))
+            if not ordered:
+                ops.stream_wait(side, ops.raw_stream(view.device))
             with torch.cuda.stream(side):
                 timed = getattr(self, "time_buckets", False)
                 if timed:
@@ -327,6 +355,11 @@ class GradBucketReducer:
         learn which parameters to leave out next step - all from the bitmap every rank agrees on."""
         opt = self.opt
         if self.active:
+            from . import ops as _ops
+            if _ops.PLAN_REPLAYING[0]:
+                # a replayed step: no gradient hook fired - the firing set is the settled one the plan was recorded under
+                self._fired = dict(self._last_fired)
+            self._last_fired = dict(self._fired)
             if self._steady and self._ctl_work is not None:
                 # last step's exchange: launched a whole step ago, so this does not block in practice
                 self._ctl_work.wait()

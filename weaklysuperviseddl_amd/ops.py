@@ -36,6 +36,28 @@ def _stream():
 PLAN_REC = [None]
 
 
+PLAN_REPLAYING = [False]     # a plan with host sections is being replayed (the sections run live, in their places)
+
+
+def host_section(fn, *args):
+    """Run ``fn(*args)`` - host work that must happen at THIS place of the launch sequence on every iteration and that a
+    plan cannot hold: a collective of torch.distributed, a wait on its work handle, control-plane exchanges.  Outside a
+    recording it is a plain call.  While a plan is being recorded the plan is cut here (``wsdl_plan_mark``), the
+    recording pauses for the call, and a replay calls ``fn(*args)`` again between the two segments."""
+    rec = PLAN_REC[0]
+    if rec is None:
+        return fn(*args)
+    check(lib().wsdl_plan_mark(len(rec.sections)))
+    check(lib().wsdl_plan_pause())
+    PLAN_REC[0] = None
+    try:
+        return fn(*args)
+    finally:
+        PLAN_REC[0] = rec
+        check(lib().wsdl_plan_resume())
+        rec.sections.append((fn, args))
+
+
 def _p(t):
     if t is None:
         return None

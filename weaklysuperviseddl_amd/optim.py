@@ -230,7 +230,9 @@ class FlatAdam:
 
     def _step(self):
         if self.pre_step_hook is not None:
-            self.pre_step_hook()
+            # (the data-parallel reducer's wait(): collectives' work handles, control-plane exchange - host work that a launch
+            # plan repeats live at this place)
+            ops.host_section(self.pre_step_hook)
         if self.segments is not None:
             if self.external_trigger or self.early_step or any(self._stepped):
                 self._finish_segments()         # (the segment hook has re-laid-out the weights)

@@ -34,23 +34,36 @@ class PlanError(WsdlError):
 
 
 class _Recording:
-    __slots__ = ("keep",)
+    __slots__ = ("keep", "sections")
 
     def __init__(self):
         self.keep = []
+        self.sections = []          # host sections (ops.host_section): [(fn, args)] in recorded order
 
 
 class LaunchPlan:
     """A recorded launch sequence (``record``).  ``keep``: everything the launches touch."""
 
-    def __init__(self, handle, keep):
-        self.handle, self.keep = handle, keep
+    def __init__(self, handle, keep, sections=()):
+        self.handle, self.keep, self.sections = handle, keep, list(sections)
         k, m, w, e, mk = (C.c_longlong(0) for _ in range(5))
         check(lib().wsdl_plan_stats(handle, C.byref(k), C.byref(m), C.byref(w), C.byref(e), C.byref(mk)))
         self.stats = {"kernels": k.value, "memsets": m.value, "stream_waits": w.value, "event_ops": e.value, "marks": mk.value}
 
     def replay(self):
-        check(lib().wsdl_plan_replay(self.handle))
+        if not self.sections:
+            check(lib().wsdl_plan_replay(self.handle))
+            return
+        # segments of launches with the recorded host work (collectives, waits on their handles) live in between
+        ops.PLAN_REPLAYING[0] = True
+        try:
+            for k in range(len(self.sections) + 1):
+                check(lib().wsdl_plan_replay_segment(self.handle, k))
+                if k < len(self.sections):
+                    fn, args = self.sections[k]
+                    fn(*args)
+        finally:
+            ops.PLAN_REPLAYING[0] = False
 
     def replay_segment(self, k):
         check(lib().wsdl_plan_replay_segment(self.handle, int(k)))
@@ -92,11 +105,20 @@ def record(fn, *args, **kwargs):
         err = PlanError(lib().wsdl_last_error().decode())
         err.result = out                # the call has run: its result is valid, only the plan is not
         raise err
-    return LaunchPlan(h.value, rec.keep), out
+    if len(rec.sections) != 0:
+        n = C.c_longlong(0)
+        check(lib().wsdl_plan_stats(h.value, None, None, None, None, C.byref(n)))
+        if n.value != len(rec.sections):
+            lib().wsdl_plan_destroy(h.value)
+            err = PlanError("record: marks and host sections do not match")
+            err.result = out
+            raise err
+    return LaunchPlan(h.value, rec.keep, rec.sections), out
 
 
 PLAN_STEP = [os.environ.get("WSDL_PLAN_STEP", "1") != "0"]      # train_step replays a plan where it can (0: always eager)
 PLAN_WARMUP = int(os.environ.get("WSDL_PLAN_WARMUP", "2"))      # eager calls before the recorded one
+PLAN_DP = [os.environ.get("WSDL_PLAN_DP", "1") != "0"]           # replay under a GradBucketReducer too (0: data-parallel steps stay eager)
 
 
 def _hook_tables(model):
@@ -130,7 +152,9 @@ class PlannedTrainStep:
     # -- what must be equal for a recorded plan to stand for the call
     def _key(self, images, masks):
         opt = self.opt
+        red = getattr(opt, "_wsdl_reducer", None)
         return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device, float(opt.lr),
+                None if red is None else (id(red), id(red._steady_set)),
                 tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params),
                 tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale), ops.LAYOUT_EPOCH[0],
                 ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0], ops.ASPP_MULTI[0], ops.ASPP_GROUP_FWD[0],
@@ -138,9 +162,16 @@ class PlannedTrainStep:
 
     def usable(self, images, masks):
         opt = self.opt
+        red = getattr(opt, "_wsdl_reducer", None)
+        if red is None:
+            dp_ok = opt.pre_step_hook is None and not opt.grad_ready_hooks
+        else:
+            # data parallel: once the reducer's firing set has settled every step issues the same collectives at the same
+            # places - they become host sections of the plan (ops.host_section)
+            dp_ok = PLAN_DP[0] and red.plan_ready() and not getattr(red, "time_buckets", False)
         return (self.disabled is None and PLAN_STEP[0] and images.is_cuda and masks.is_cuda and self.model.training
                 and torch.is_grad_enabled() and ops.PLAN_REC[0] is None and not ops.PROF_ON[0]
-                and opt.pre_step_hook is None and not opt.grad_ready_hooks and not getattr(opt, "time_tail", False)
+                and dp_ok and not getattr(opt, "time_tail", False)
                 and not getattr(opt, "capture_mode", False) and not any(map(len, self._hooks))
                 and not torch.cuda.is_current_stream_capturing())
 
