@@ -37,6 +37,15 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSDL_FORCE_DIST") == "1") and \
+        os.environ.get("RANK", "0") == "0" and "NCCL_DEBUG" not in os.environ:
+    # Rank 0 of a multi-rank run asks RCCL to report its topology and its algorithm / protocol choices into a file that the
+    # `dp.rccl` object of the JSON line is parsed from (rccl_debug_env below is the same rule for the ranks this script spawns
+    # itself).  Set BEFORE torch is imported: the library reads its debug settings once.
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
+    os.environ["NCCL_DEBUG_FILE"] = "/tmp/wsdl_rccl_rank0_%p.log"
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -832,6 +841,12 @@ def main():
         issue_by_rank = gathered
     result["host"]["issue_ms_per_step_by_rank"] = issue_by_rank
     result["optimizer_tail_ms"] = None if tail is None else round(tail, 4)
+    torch.cuda.synchronize()
+    result["range"] = dict(ops.range_status(device),
+                           note="range sentinel of the fp16x2 arithmetic (one power-of-two scale per tensor): the BatchNorm kernels publish "
+                                "max|tensor| and the smallest non-zero maximum of any 256-value piece; worst_log2 = the largest log2 of "
+                                "their ratio over the last step's tensors, exceeded = some tensor beyond 2^25 (there conv_arith = 2, the "
+                                "range guard, is the arithmetic to use; FlatAdam.step() warns once)")
     result["streams"] = ops.stream_census(device)
     if dp_on and dist.get_backend() != "nccl":
         result["config"]["rehearsal"] = ("ranks share the GPU(s) and the gradients travel over gloo through host memory: a rehearsal "

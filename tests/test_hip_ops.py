@@ -1165,3 +1165,34 @@ def test_fwd_group_equals_the_single_launches(dev, B, C, Co, H):
     for a, b, c in zip(single, grouped, again):
         assert ((a - b).abs().max() / a.abs().max()).item() < 1e-5       # K up to 18432 summed in another order
         assert torch.equal(b, c)                                       # fixed-order reduce: bitwise reproducible
+
+
+def test_range_sentinel_flags_tensors_beyond_the_safe_range(dev):
+    """The BatchNorm kernels publish, besides max|tensor|, the smallest non-zero maximum of any 256-value piece (range sentinel);
+    wsdl_range_check turns a step's pairs into "some tensor spans more than 2^25".  Unit data: a few bits of spread, no flag.
+    Images graded by 2^30 across the batch (the 'graded30' data of the arithmetic test, here as the gradient entering a
+    BatchNorm backward): flagged, worst spread ~2^30 - the signal that selects conv_arith = 2."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(9)
+    B, C, H = 4, 256, 32
+    x = torch.randn(B, C, H, H, device=dev, generator=g)
+    gamma, beta = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.1
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+
+    def run(dy):
+        ops.reset_amax_pool(dev)
+        y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, relu=True)
+        dx, _, _, _ = ops.bn_train_bwd(x, dy, None, gamma, mean, invstd, True, False, beta=beta)
+        ops.range_check(dev)
+        torch.cuda.synchronize()
+        return ops.range_status(dev), dx
+
+    dy = torch.randn(B, C, H, H, device=dev, generator=g)
+    st, _ = run(dy)
+    assert st["pairs_seen"] >= 2 and not st["exceeded"] and st["worst_log2"] <= 12, st
+    grade = torch.tensor([2.0 ** (-30.0 * b / (B - 1)) for b in range(B)], device=dev).view(B, 1, 1, 1)
+    st, dx = run(dy * grade)
+    assert st["exceeded"] and st["pairs_over_limit"] >= 1 and 25 < st["worst_log2"] <= 34, st
+    # the published maximum is still the tensor's (the slot's first float), whatever the second one holds
+    assert abs(float(dx._wsdl_amax) - dx.abs().max().item()) <= 1e-6 * dx.abs().max().item()
+    ops.reset_amax_pool(dev)

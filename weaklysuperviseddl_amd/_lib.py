@@ -108,6 +108,7 @@ SIGNATURES = {
     "wsdl_add_int": (_i, [_vp, _i, _ll, _vp]),
     "wsdl_mul": (_i, [_vp, _vp, _vp, _i, _vp]),
     "wsdl_clamp_max_i64": (_i, [_vp, _vp, _ll, _ll, _vp]),
+    "wsdl_range_check": (_i, [_vp, _i, _i, _vp, _vp]),
     "wsdl_scale_mean": (_i, [_vp, _i, _f, _vp, _vp]),
     "wsdl_scale_fill": (_i, [_vp, _f, _vp, _i, _vp]),
 }
@@ -131,6 +132,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the .so is stale / symbol missing
             fn.restype, fn.argtypes = res, args
+        # this binding's amax slots are (max, ~min piece maximum) pairs (ops.amax_slot): the BatchNorm kernels publish both
+        handle.wsdl_set_option(b"range_sentinel", 1)
         _lib = handle
     return _lib
 

@@ -59,6 +59,7 @@ struct ProfScope {
 extern int g_bn_resident;
 extern int g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
 extern int g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
+extern int g_range_sentinel;      // "range_sentinel": the amax pointers of the BatchNorm entry points are (max, ~min piece max) PAIRS
 
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
 constexpr int kReduceSlots = 4096;
@@ -146,6 +147,40 @@ __device__ __forceinline__ void publish_amax(float m, float* __restrict__ amax) 
             unsigned* a = reinterpret_cast<unsigned*>(amax);
             const unsigned bits = __builtin_bit_cast(unsigned, m);
             if (bits > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, bits);
+        }
+    }
+}
+// Range sentinel (wsdl_set_option "range_sentinel"): besides max|v| of the tensor, the SMALLEST non-zero maximum any piece of
+// it has - a piece being what one wave stores in one pass (256 consecutive values of a channel of one image) or one
+// workgroup's run.  The fp16x2 convolutions scale a tensor by ONE power of two: a region 2^E below the tensor's maximum is
+// computed to 2^-(38-E) of its own maximum, past 1e-3 from E ~ 29 (conv_split.h).  wsdl_range_check turns the pairs
+// (max, min piece maximum) of a step into "spread exceeded 2^25 somewhere" without a host synchronisation.  The minimum is
+// kept as the bitwise complement of its float bits, so that the zero a slot starts from means "none yet" and atomicMax
+// orders it.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void publish_amax_min(float m, float pmin, float* __restrict__ amax, float* __restrict__ cmin) {
+    __shared__ float s_amax2[16], s_min2[16];
+    m = wave_max(m);
+    pmin = wave_min(pmin);
+    if ((threadIdx.x & 63) == 0) {
+        s_amax2[threadIdx.x >> 6] = m;
+        s_min2[threadIdx.x >> 6] = pmin;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x * blockDim.y + 63) >> 6;
+        for (int i = 1; i < nw; ++i) {
+            m = fmaxf(m, s_amax2[i]);
+            pmin = fminf(pmin, s_min2[i]);
+        }
+        if (m > 0.f) {
+            unsigned* a = reinterpret_cast<unsigned*>(amax);
+            const unsigned bits = __builtin_bit_cast(unsigned, m);
+            if (bits > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, bits);
+        }
+        if (cmin && pmin > 0.f && pmin < 3.0e38f) {
+            unsigned* a = reinterpret_cast<unsigned*>(cmin);
+            const unsigned inv = ~__builtin_bit_cast(unsigned, pmin);
+            if (inv > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, inv);
         }
     }
 }

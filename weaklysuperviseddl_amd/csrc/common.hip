@@ -9,6 +9,7 @@
 namespace wsdl {
 
 static thread_local char g_err[512] = "";
+int g_range_sentinel = 0;
 
 void set_error(const char* fmt, ...) {
     va_list ap;

@@ -1762,6 +1762,7 @@ int wsdl_set_option(const char* name, int value) {
         g_conv_arith = value;
         return WSDL_OK;
     }
+    if (!strcmp(name, "range_sentinel")) { wsdl::g_range_sentinel = value != 0; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
     if (!strcmp(name, "layercam_tail_mod")) {

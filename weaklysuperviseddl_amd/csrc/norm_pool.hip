@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
-    long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask) {
+    long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask, float* __restrict__ cmin) {
     // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
     // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
     __shared__ double sm[16];
@@ -336,10 +336,11 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     }
     __syncthreads();
     const float mu = bc[0], g = bc[1] * gamma[c], be = beta[c];
-    float vmax = 0.f;
+    float vmax = 0.f, tmin = 3.4e38f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
+        float pm = 0.f;
         if (i4 < n4) {
             const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             float4 o = v[k];
@@ -351,11 +352,16 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = o;
-            vmax = amax4(vmax, o);
+            pm = amax4(0.f, o);
+            vmax = fmaxf(vmax, pm);
             if (rmask) store_mask_pair(rmask, ((long long)b * C + c) * HW + r, o);
         }
+        if (cmin) {                     // (uniform) the wave's piece of this pass: 256 consecutive values of one channel
+            pm = wave_max(pm);
+            if (pm > 0.f) tmin = fminf(tmin, pm);
+        }
     }
-    if (amax) publish_amax(vmax, amax);
+    if (amax) publish_amax_min(vmax, tmin, amax, cmin);
 }
 
 template <int NT, int V = 16>
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
-    float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask) {
+    float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask, float* __restrict__ cmin) {
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -413,10 +419,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     }
     __syncthreads();
     const float k0 = bc[0], k1 = bc[1], gi = gamma[c] * is;
-    float vmax = 0.f;
+    float vmax = 0.f, tmin = 3.4e38f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
+        float pm = 0.f;
         if (i4 < n4) {
             const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long o = ((long long)b * C + c) * HW + r;
@@ -426,11 +433,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             d.z = gi * (g[k].z - k0 - xh[k].z * k1);
             d.w = gi * (g[k].w - k0 - xh[k].w * k1);
             *reinterpret_cast<float4*>(dx + o) = d;
-            vmax = amax4(vmax, d);
+            pm = amax4(0.f, d);
+            vmax = fmaxf(vmax, pm);
             if (dres) *reinterpret_cast<float4*>(dres + o) = g[k];
         }
+        if (cmin) {
+            pm = wave_max(pm);
+            if (pm > 0.f) tmin = fminf(tmin, pm);
+        }
     }
-    if (amax) publish_amax(vmax, amax);
+    if (amax) publish_amax_min(vmax, tmin, amax, cmin);
 }
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
@@ -731,23 +743,24 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     if (!y_bs) y_bs = (long long)C * HW;
     WSDL_REQUIRE(!relu_mask || (y_bs & 3) == 0, "bn_train_fwd: the bit mask needs a 16-byte aligned batch stride");
     hipStream_t s = wsdl::as_stream(stream);
+    float* cmin = (wsdl::g_range_sentinel && y_amax) ? y_amax + 1 : nullptr;      // "range_sentinel": y_amax is a (max, ~min) pair
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
         if (nt == 1025)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 16>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask);
+                               y_amax, relu_mask, cmin);
         else if (nt == 1024)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask);
+                               y_amax, relu_mask, cmin);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask);
+                               y_amax, relu_mask, cmin);
         else
             hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask);
+                               y_amax, relu_mask, cmin);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -781,19 +794,20 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!dy_bs) dy_bs = (long long)C * HW;
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
+    float* cmin = (wsdl::g_range_sentinel && dx_amax) ? dx_amax + 1 : nullptr;
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW, true) : 0) {
         if (nt == 1024)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask);
+                               dx_amax, beta, relu_mask, cmin);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask);
+                               dx_amax, beta, relu_mask, cmin);
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask);
+                               dx_amax, beta, relu_mask, cmin);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }

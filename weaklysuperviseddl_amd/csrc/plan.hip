@@ -172,6 +172,35 @@ __global__ void scale_fill_kernel(const float* __restrict__ g, float c, float* _
     if (i < n) out[i] = g[0] * c;
 }
 
+// (max, ~min piece maximum) pairs of one step's tensors -> out[0] = the largest log2(max / min) over the pairs that hold both,
+// out[1] = how many pairs exceed `limit_log2`, out[2] = how many were looked at.  One workgroup, plain stores: `out` may be
+// host memory the device can write (the host reads it a step later, no synchronisation).
+__global__ void range_check_kernel(const unsigned* __restrict__ pairs, int npairs, int limit_log2, float* __restrict__ out) {
+    __shared__ float sm[16];
+    float worst = 0.f, over = 0.f, seen = 0.f;
+    for (int i = threadIdx.x; i < npairs; i += blockDim.x) {
+        const unsigned mx = pairs[2 * i], inv = pairs[2 * i + 1];
+        if (mx == 0u || inv == 0u) continue;
+        const unsigned mn = ~inv;
+        const int spread = (int)((mx >> 23) & 0xffu) - (int)((mn >> 23) & 0xffu);      // floats >= 0: exponent difference
+        seen += 1.f;
+        worst = fmaxf(worst, (float)spread);
+        if (spread > limit_log2) over += 1.f;
+    }
+    worst = wave_max(worst);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) worst = fmaxf(worst, sm[i]);
+    over = block_sum(over, sm);
+    seen = block_sum(seen, sm);
+    if (threadIdx.x == 0) {
+        out[0] = worst;
+        out[1] = over;
+        out[2] = seen;
+    }
+}
+
 }  // namespace wsdl
 
 using wsdl::Plan;
@@ -394,6 +423,14 @@ int wsdl_scale_mean(const float* x, int n, float w, float* out, wsdl_stream_t st
 int wsdl_scale_fill(const float* g, float c, float* out, int n, wsdl_stream_t stream) {
     WSDL_REQUIRE(g && out && n > 0, "scale_fill: null pointer / empty");
     hipLaunchKernelGGL(wsdl::scale_fill_kernel, dim3(wsdl::cdiv(n, 256)), dim3(256), 0, wsdl::as_stream(stream), g, c, out, n);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_range_check(const float* pairs, int npairs, int limit_log2, float* out, wsdl_stream_t stream) {
+    WSDL_REQUIRE(pairs && out && npairs > 0, "range_check: null pointer / empty");
+    hipLaunchKernelGGL(wsdl::range_check_kernel, dim3(1), dim3(256), 0, wsdl::as_stream(stream),
+                       reinterpret_cast<const unsigned*>(pairs), npairs, limit_log2, out);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

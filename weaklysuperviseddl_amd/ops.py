@@ -394,8 +394,10 @@ def amax_slot(device):
     after its producer (the weight-gradient kernels on the side stream: ``side.wait_stream(main)``)."""
     key = (device, raw_stream(device))
     pool = _amax_pools.get(key)
-    if pool is None or pool[1] >= pool[0].numel():
-        buf = memset_zero(torch.empty(AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32))
+    if pool is None or pool[1] >= AMAX_POOL_SLOTS[0]:
+        # a slot is a PAIR of floats: [max|tensor|, ~bits of the smallest non-zero piece maximum] - the second one is written
+        # by the BatchNorm kernels only (range sentinel, include/wsdl_hip.h wsdl_range_check); callers see the first
+        buf = memset_zero(torch.empty(2 * AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32))
         if not torch.cuda.is_current_stream_capturing():
             # slots are read by kernels on the other streams of this library (weight gradients on the side stream, the
             # main stream joining a CAM lane): keep the caching allocator from recycling a retired pool under them
@@ -406,7 +408,37 @@ def amax_slot(device):
         _amax_pools[key] = pool
     i = pool[1]
     pool[1] += 1
-    return pool[0][i:i + 1]
+    return pool[0][2 * i:2 * i + 1]
+
+
+RANGE_LIMIT_LOG2 = 25          # a tensor whose pieces' maxima spread further than 2^25 leaves the fp16x2 arithmetic's safe range
+_range_out = {}
+
+
+def range_check(device):
+    """Reduce the (max, min piece maximum) pairs of the amax slots handed out on ``device`` since their pools were created
+    (launches of the library on the current stream; no host synchronisation): ``range_status`` reads the result later."""
+    device = _norm_device(device)
+    pools = [(k, v) for k, v in _amax_pools.items() if k[0] == device and v[1] > 0]
+    if not pools:
+        return
+    out = _range_out.get(device)
+    if out is None:
+        out = _range_out[device] = torch.zeros(8, 3, dtype=torch.float32).pin_memory()
+    for j, (_k, (buf, used)) in enumerate(pools[:8]):
+        check(lib().wsdl_range_check(_p(buf), int(used), RANGE_LIMIT_LOG2, _p(out[j]), _stream()))
+
+
+def range_status(device):
+    """What the last completed ``range_check`` found: {"worst_log2", "pairs_over_limit", "pairs_seen", "exceeded"} - read from
+    host memory the check kernels write; a step old at most."""
+    out = _range_out.get(_norm_device(device))
+    if out is None:
+        return {"worst_log2": 0.0, "pairs_over_limit": 0, "pairs_seen": 0, "exceeded": False, "limit_log2": RANGE_LIMIT_LOG2}
+    worst = float(out[:, 0].max())
+    over = int(out[:, 1].sum())
+    return {"worst_log2": worst, "pairs_over_limit": over, "pairs_seen": int(out[:, 2].sum()), "exceeded": over > 0,
+            "limit_log2": RANGE_LIMIT_LOG2}
 
 
 _lane_streams = {}     # device -> the library's streams beyond the side and the prep stream (LayerCAM lanes 2, 3, ...)

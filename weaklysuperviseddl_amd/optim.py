@@ -23,6 +23,7 @@ import torch
 from . import ops
 
 _ALIGN = 64   # floats; keeps every parameter 256-byte aligned inside the flat buffer
+RANGE_SENTINEL = [True]      # FlatAdam.step() checks the step's tensors for regions below the fp16x2 arithmetic's safe range
 
 
 class FlatAdam:
@@ -253,5 +254,17 @@ class FlatAdam:
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
         self._dirty = False                     # (joined above)
+        if self.flat_param.is_cuda and RANGE_SENTINEL[0] and ops.CONV_ARITH[0] == 1:
+            # range sentinel of the fp16x2 arithmetic: what the PREVIOUS step's tensors spanned (read from host memory the check
+            # kernel wrote - no synchronisation), then this step's check
+            st = ops.range_status(self.flat_param.device)
+            if st["exceeded"] and not getattr(self, "_range_warned", False):
+                self._range_warned = True
+                import warnings
+                warnings.warn(f"weaklysuperviseddl_amd: {st['pairs_over_limit']} activation / gradient tensors of the last step span "
+                              f"more than 2^{st['limit_log2']} between their largest and their smallest region (worst 2^{st['worst_log2']:.0f}):"
+                              " the default convolution arithmetic (fp16x2, one scale per tensor) computes the small regions to "
+                              "fewer than 13 bits there - select the range guard: ops.set_option('conv_arith', 2)")
+            ops.range_check(self.flat_param.device)
         if self.post_step_hook is not None:
             self.post_step_hook()
