@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WSDL_FORCE_DIST") == "1") and \
-        os.environ.get("RANK", "0") == "0" and "NCCL_DEBUG" not in os.environ:
+        os.environ.get("RANK", "0") == "0" and os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
     # Rank 0 of a multi-rank run asks RCCL to report its topology and its algorithm / protocol choices into a file that the
     # `dp.rccl` object of the JSON line is parsed from (rccl_debug_env below is the same rule for the ranks this script spawns
     # itself).  Set BEFORE torch is imported: the library reads its debug settings once.
@@ -548,8 +548,8 @@ RCCL_PROTOS = {0: "LL", 1: "LL128", 2: "Simple"}
 def rccl_debug_env(env, rank, log_dir="/tmp"):
     """Rank 0 of a multi-rank run asks RCCL to say what it does (topology at init, algorithm / protocol per collective size)
     into a file bench.py parses afterwards (``dp.rccl``); the caller's own NCCL_DEBUG settings win."""
-    if int(rank) != 0 or "NCCL_DEBUG" in env:
-        return env
+    if int(rank) != 0 or env.get("NCCL_DEBUG", "").upper() in ("INFO", "TRACE"):
+        return env              # (a caller who asked for INFO / TRACE output himself keeps it; VERSION / WARN are raised to INFO)
     env = dict(env)
     env["NCCL_DEBUG"] = "INFO"
     env["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
@@ -579,6 +579,8 @@ def parse_rccl_log(text, keep=24):
             version = msg
         if re.search(r"^(Channel|Ring|Trees|Connected all|\d+ coll channels|comm 0x|Using network|P2P|Setting affinity)", msg) \
                 and len(topo) < keep:
+            if msg.startswith("Channel") and sum(t.startswith("Channel") for t in topo) >= 2:
+                continue                # (one line per channel, up to 128 of them: the first two say what they look like)
             topo.append(msg[:200])
     chosen = sorted(choices.values(), key=lambda e: -e["bytes"])
     algos = sorted({e["algo"] for e in chosen})
@@ -844,7 +846,7 @@ def main():
     torch.cuda.synchronize()
     result["range"] = dict(ops.range_status(device),
                            note="range sentinel of the fp16x2 arithmetic (one power-of-two scale per tensor): the BatchNorm kernels publish "
-                                "max|tensor| and the smallest non-zero maximum of any 256-value piece; worst_log2 = the largest log2 of "
+                                "max|tensor| and the smallest non-zero channel maximum; worst_log2 = the largest log2 of "
                                 "their ratio over the last step's tensors, exceeded = some tensor beyond 2^25 (there conv_arith = 2, the "
                                 "range guard, is the arithmetic to use; FlatAdam.step() warns once)")
     result["streams"] = ops.stream_census(device)

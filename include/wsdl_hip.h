@@ -61,7 +61,7 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches)
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
- *   range_sentinel 0*  1 = the amax arguments of wsdl_bn_train_fwd / _bwd are (max, ~min piece maximum) pairs (wsdl_range_check)
+ *   range_sentinel 0*  1 = the amax arguments of wsdl_bn_train_fwd / _bwd are (max, ~min channel maximum) pairs (wsdl_range_check)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      64 channels, n > 1 = from n channels; measured: resident wins at every channel count of the networks)
  *   bn_wide_c    512*  resident BatchNorm kernels as 1024 threads x 4 float4 (instead of 256 x 16) up to this channel count
@@ -477,11 +477,11 @@ int wsdl_clamp_max_i64(const long long* x, long long* y, long long n, long long 
  * reference's combined losses, AlternatingDirectionBoundaryLoss.py:196-200; fixed summation order) and its gradient
  * out[i] = g[0] * c (c = w / n).  The sum of terms is wsdl_add. */
 /* Range sentinel of the fp16x2 arithmetic.  wsdl_set_option("range_sentinel", 1) declares that every y_amax / dx_amax handed
- * to wsdl_bn_train_fwd / wsdl_bn_train_bwd points at TWO floats: [0] receives max|tensor| as before, [1] the smallest non-zero
- * maximum of any PIECE of the tensor (256 consecutive values of one channel of one image in the channel-resident kernels),
+ * to wsdl_bn_train_fwd / wsdl_bn_train_bwd points at TWO floats (8-byte aligned): [0] receives max|tensor| as before, [1] the smallest non-zero
+ * maximum of any CHANNEL of the tensor (the channel-resident kernels run one workgroup per channel),
  * kept as the bitwise complement of its float bits (a zeroed pair = nothing published).  The convolutions scale a tensor by
  * ONE power of two, so a region 2^E below the tensor's maximum is computed to 2^-(38-E) of its own maximum - past the 1e-3
- * of the parity bar from E ~ 29.  wsdl_range_check reduces npairs such pairs: out[0] = the largest log2(max / min piece
+ * of the parity bar from E ~ 29.  wsdl_range_check reduces npairs such pairs: out[0] = the largest log2(max / min channel
  * maximum), out[1] = the number of pairs beyond limit_log2 (25: the safe range), out[2] = pairs looked at.  `out` may be
  * pinned host memory: the host reads it a step later, without a synchronisation, and selects conv_arith = 2 (the guard). */
 int wsdl_range_check(const float* pairs, int npairs, int limit_log2, float* out, wsdl_stream_t stream);

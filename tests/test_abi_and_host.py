@@ -200,7 +200,9 @@ def test_bench_spawn_logic_dry_run_for_8_ranks():
     # rank 0 (and only rank 0) asks RCCL to report its topology and its algorithm / protocol choices into a file
     assert envs[0]["NCCL_DEBUG"] == "INFO" and "TUNING" in envs[0]["NCCL_DEBUG_SUBSYS"] and "%p" in envs[0]["NCCL_DEBUG_FILE"]
     assert all("NCCL_DEBUG" not in e for e in envs[1:])
-    assert bench.rank_environments(2, 2, {"NCCL_DEBUG": "WARN"})[0]["NCCL_DEBUG"] == "WARN"        # the caller's setting wins
+    assert bench.rank_environments(2, 2, {"NCCL_DEBUG": "WARN"})[0]["NCCL_DEBUG"] == "INFO"        # VERSION / WARN are raised to INFO
+    e0 = bench.rank_environments(2, 2, {"NCCL_DEBUG": "TRACE"})[0]
+    assert e0["NCCL_DEBUG"] == "TRACE" and "NCCL_DEBUG_FILE" not in e0                            # a caller's own INFO / TRACE stays
 
 
 def test_bench_dp_self_description_fields():

@@ -1168,10 +1168,11 @@ def test_fwd_group_equals_the_single_launches(dev, B, C, Co, H):
 
 
 def test_range_sentinel_flags_tensors_beyond_the_safe_range(dev):
-    """The BatchNorm kernels publish, besides max|tensor|, the smallest non-zero maximum of any 256-value piece (range sentinel);
+    """The BatchNorm kernels publish, besides max|tensor|, the smallest non-zero channel maximum (range sentinel);
     wsdl_range_check turns a step's pairs into "some tensor spans more than 2^25".  Unit data: a few bits of spread, no flag.
-    Images graded by 2^30 across the batch (the 'graded30' data of the arithmetic test, here as the gradient entering a
-    BatchNorm backward): flagged, worst spread ~2^30 - the signal that selects conv_arith = 2."""
+    Channels graded by 2^30 (gamma falling by 2^30 across the channels: the forward output and the input gradient both carry
+    it): flagged, worst spread ~2^30 - the signal that selects conv_arith = 2.  (Grading the IMAGES of a batch does not survive
+    a BatchNorm: its backward mixes the images of a channel through the batch statistics - checked here too.)"""
     from weaklysuperviseddl_amd import ops
     g = torch.Generator(device=dev).manual_seed(9)
     B, C, H = 4, 256, 32
@@ -1179,20 +1180,24 @@ def test_range_sentinel_flags_tensors_beyond_the_safe_range(dev):
     gamma, beta = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.1
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
 
-    def run(dy):
+    def run(dy, ga, be):
         ops.reset_amax_pool(dev)
-        y, mean, invstd = ops.bn_train_fwd(x, gamma, beta, rm.clone(), rv.clone(), 0.1, 1e-5, relu=True)
-        dx, _, _, _ = ops.bn_train_bwd(x, dy, None, gamma, mean, invstd, True, False, beta=beta)
+        y, mean, invstd = ops.bn_train_fwd(x, ga, be, rm.clone(), rv.clone(), 0.1, 1e-5, relu=True)
+        dx, _, _, _ = ops.bn_train_bwd(x, dy, None, ga, mean, invstd, True, False, beta=be)
         ops.range_check(dev)
         torch.cuda.synchronize()
-        return ops.range_status(dev), dx
+        return ops.range_status(dev), y, dx
 
     dy = torch.randn(B, C, H, H, device=dev, generator=g)
-    st, _ = run(dy)
-    assert st["pairs_seen"] >= 2 and not st["exceeded"] and st["worst_log2"] <= 12, st
-    grade = torch.tensor([2.0 ** (-30.0 * b / (B - 1)) for b in range(B)], device=dev).view(B, 1, 1, 1)
-    st, dx = run(dy * grade)
-    assert st["exceeded"] and st["pairs_over_limit"] >= 1 and 25 < st["worst_log2"] <= 34, st
+    st, _, _ = run(dy, gamma, beta)
+    assert st["pairs_seen"] >= 2 and not st["exceeded"] and st["worst_log2"] <= 14, st
+    grade_b = torch.tensor([2.0 ** (-30.0 * b / (B - 1)) for b in range(B)], device=dev).view(B, 1, 1, 1)
+    st, _, _ = run(dy * grade_b, gamma, beta)
+    assert not st["exceeded"], st                                   # the backward's batch statistics mix the images
+    grade_c = torch.tensor([2.0 ** (-30.0 * c / (C - 1)) for c in range(C)], device=dev)
+    st, y, dx = run(dy, gamma * grade_c, beta * grade_c)
+    assert st["exceeded"] and st["pairs_over_limit"] == 2 and 25 < st["worst_log2"] <= 36, st
     # the published maximum is still the tensor's (the slot's first float), whatever the second one holds
-    assert abs(float(dx._wsdl_amax) - dx.abs().max().item()) <= 1e-6 * dx.abs().max().item()
+    for t in (y, dx):
+        assert abs(float(t._wsdl_amax) - t.abs().max().item()) <= 1e-6 * t.abs().max().item()
     ops.reset_amax_pool(dev)

@@ -133,7 +133,8 @@ def lib():
             fn = getattr(handle, name)      # AttributeError if the .so is stale / symbol missing
             fn.restype, fn.argtypes = res, args
         # this binding's amax slots are (max, ~min piece maximum) pairs (ops.amax_slot): the BatchNorm kernels publish both
-        handle.wsdl_set_option(b"range_sentinel", 1)
+        # (WSDL_RANGE_SENTINEL=0: the A/B partner - the second float of a pair is then never written)
+        handle.wsdl_set_option(b"range_sentinel", int(os.environ.get("WSDL_RANGE_SENTINEL", "1") != "0"))
         _lib = handle
     return _lib
 

@@ -336,11 +336,10 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     }
     __syncthreads();
     const float mu = bc[0], g = bc[1] * gamma[c], be = beta[c];
-    float vmax = 0.f, tmin = 3.4e38f;
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
-        float pm = 0.f;
         if (i4 < n4) {
             const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             float4 o = v[k];
@@ -352,16 +351,11 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             }
             if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
             *reinterpret_cast<float4*>(y + (long long)b * y_bs + (long long)c * HW + r) = o;
-            pm = amax4(0.f, o);
-            vmax = fmaxf(vmax, pm);
+            vmax = amax4(vmax, o);
             if (rmask) store_mask_pair(rmask, ((long long)b * C + c) * HW + r, o);
         }
-        if (cmin) {                     // (uniform) the wave's piece of this pass: 256 consecutive values of one channel
-            pm = wave_max(pm);
-            if (pm > 0.f) tmin = fminf(tmin, pm);
-        }
     }
-    if (amax) publish_amax_min(vmax, tmin, amax, cmin);
+    if (amax) publish_amax_min(vmax, amax, cmin);
 }
 
 template <int NT, int V = 16>
@@ -419,11 +413,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     }
     __syncthreads();
     const float k0 = bc[0], k1 = bc[1], gi = gamma[c] * is;
-    float vmax = 0.f, tmin = 3.4e38f;
+    float vmax = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
-        float pm = 0.f;
         if (i4 < n4) {
             const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
             const long long o = ((long long)b * C + c) * HW + r;
@@ -433,16 +426,11 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             d.z = gi * (g[k].z - k0 - xh[k].z * k1);
             d.w = gi * (g[k].w - k0 - xh[k].w * k1);
             *reinterpret_cast<float4*>(dx + o) = d;
-            pm = amax4(0.f, d);
-            vmax = fmaxf(vmax, pm);
+            vmax = amax4(vmax, d);
             if (dres) *reinterpret_cast<float4*>(dres + o) = g[k];
         }
-        if (cmin) {
-            pm = wave_max(pm);
-            if (pm > 0.f) tmin = fminf(tmin, pm);
-        }
     }
-    if (amax) publish_amax_min(vmax, tmin, amax, cmin);
+    if (amax) publish_amax_min(vmax, amax, cmin);
 }
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form

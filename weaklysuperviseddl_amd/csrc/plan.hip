@@ -172,7 +172,7 @@ __global__ void scale_fill_kernel(const float* __restrict__ g, float c, float* _
     if (i < n) out[i] = g[0] * c;
 }
 
-// (max, ~min piece maximum) pairs of one step's tensors -> out[0] = the largest log2(max / min) over the pairs that hold both,
+// (max, ~min channel maximum) pairs of one step's tensors -> out[0] = the largest log2(max / min) over the pairs that hold both,
 // out[1] = how many pairs exceed `limit_log2`, out[2] = how many were looked at.  One workgroup, plain stores: `out` may be
 // host memory the device can write (the host reads it a step later, no synchronisation).
 __global__ void range_check_kernel(const unsigned* __restrict__ pairs, int npairs, int limit_log2, float* __restrict__ out) {

@@ -395,7 +395,7 @@ def amax_slot(device):
     key = (device, raw_stream(device))
     pool = _amax_pools.get(key)
     if pool is None or pool[1] >= AMAX_POOL_SLOTS[0]:
-        # a slot is a PAIR of floats: [max|tensor|, ~bits of the smallest non-zero piece maximum] - the second one is written
+        # a slot is a PAIR of floats: [max|tensor|, ~bits of the smallest non-zero channel maximum] - the second one is written
         # by the BatchNorm kernels only (range sentinel, include/wsdl_hip.h wsdl_range_check); callers see the first
         buf = memset_zero(torch.empty(2 * AMAX_POOL_SLOTS[0], device=device, dtype=torch.float32))
         if not torch.cuda.is_current_stream_capturing():
@@ -411,12 +411,12 @@ def amax_slot(device):
     return pool[0][2 * i:2 * i + 1]
 
 
-RANGE_LIMIT_LOG2 = 25          # a tensor whose pieces' maxima spread further than 2^25 leaves the fp16x2 arithmetic's safe range
+RANGE_LIMIT_LOG2 = 25          # a tensor whose channel maxima spread further than 2^25 leaves the fp16x2 arithmetic's safe range
 _range_out = {}
 
 
 def range_check(device):
-    """Reduce the (max, min piece maximum) pairs of the amax slots handed out on ``device`` since their pools were created
+    """Reduce the (max, min channel maximum) pairs of the amax slots handed out on ``device`` since their pools were created
     (launches of the library on the current stream; no host synchronisation): ``range_status`` reads the result later."""
     device = _norm_device(device)
     pools = [(k, v) for k, v in _amax_pools.items() if k[0] == device and v[1] > 0]

@@ -23,7 +23,8 @@ import torch
 from . import ops
 
 _ALIGN = 64   # floats; keeps every parameter 256-byte aligned inside the flat buffer
-RANGE_SENTINEL = [True]      # FlatAdam.step() checks the step's tensors for regions below the fp16x2 arithmetic's safe range
+import os as _os
+RANGE_SENTINEL = [_os.environ.get("WSDL_RANGE_SENTINEL", "1") != "0"]      # FlatAdam.step() checks the step's tensors for regions below the fp16x2 arithmetic's safe range
 
 
 class FlatAdam:
