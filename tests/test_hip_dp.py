@@ -371,6 +371,8 @@ def test_alternating_loop_under_dp_takes_the_same_steps_on_every_rank(dev, tmp_p
 def _worker_plan_dp(rank, world, port, out, backend, planned):
     """Ten data-parallel steps: with ``planned`` the steps after the reducer has settled are launch-plan replays whose
     collectives / wait() run as host sections."""
+    if isinstance(planned, (tuple, list)):
+        planned = planned[rank]             # per rank: the ranks of a job need not agree on replaying
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HSA_ENABLE_IPC_MODE_LEGACY="0", WSDL_PLAN_STEP="1" if planned else "0")
     if backend == "gloo":
@@ -431,3 +433,20 @@ def test_data_parallel_steps_replayed_from_a_plan_equal_the_eager_ones(dev, tmp_
         assert torch.equal(pa, pb)
     assert all(torch.equal(b["params"][0], p) for p in b["params"])                         # replicas identical
     assert b["early"] == a["early"]
+
+
+def test_ranks_that_disagree_on_replaying_stay_in_step(dev, tmp_path):
+    """Rank 0 records, verifies and replays a plan while rank 1 stays eager (its plans are switched off): recording's
+    verification steps are rank-local (no collective, no control exchange), and an eager and a replayed step issue the same
+    collectives in the same order - the job neither hangs nor diverges, and equals the all-eager job bit for bit."""
+    res = {}
+    for name, planned in (("eager", (False, False)), ("mixed", (True, False))):
+        out = str(tmp_path / f"mixed_{name}.pt")
+        mp.spawn(_worker_plan_dp, args=(2, _free_port(), out, "gloo", planned), nprocs=2, join=True)
+        res[name] = torch.load(out)
+    a, b = res["eager"], res["mixed"]
+    assert b["disabled"] is None and b["replays"] >= 3, (b["disabled"], b["replays"])
+    assert a["losses"] == b["losses"]
+    for pa, pb in zip(a["params"], b["params"]):
+        assert torch.equal(pa, pb)
+    assert torch.equal(b["params"][0], b["params"][1])

@@ -17,5 +17,12 @@ for sh in $SHAPES; do
     echo "[mfma3x3] $name $pass done" >&2
   done
 done
+# ASPP as the step runs it since round 5: the four branch convolutions as ONE grouped forward launch and ONE multi-source
+# input-gradient launch (the single-branch rows above stay in the table for comparison and are left out of the fwd / dgrad totals)
+for pass in fwd dgrad; do
+  rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/aspp_4branches_${pass} -- python3 $R/tools/one_conv.py --shape aspp,16,32 --pass $pass --reps 5 "$@" > /dev/null 2>&1 || { echo "FAILED aspp_4branches $pass"; exit 1; }
+  echo "aspp_4branches $pass aspp,16,32" >> $O/index.txt
+  echo "[mfma3x3] aspp_4branches $pass done" >&2
+done
 python3 $R/tools/mfma_busy_table.py $O > $O/table.txt
 cat $O/table.txt

@@ -8,8 +8,9 @@ import sys
 O = sys.argv[1]
 print(f"{'shape':22s} {'pass':6s} {'kernel':58s} {'launches':>8s} {'MFMA busy':>10s} {'cycles/launch':>14s}")
 tot = collections.defaultdict(lambda: [0.0, 0.0])
-for line in open(O + "/index.txt"):
-    name, ps, geo = line.split()
+lines = [l.split() for l in open(O + "/index.txt")]
+grouped = {ps for name, ps, _g in lines if name == "aspp_4branches"}       # passes the step runs as one launch for all ASPP branches
+for name, ps, geo in lines:
     tag = name.replace("/", "_").replace(".", "_")
     f = glob.glob(f"{O}/{tag}_{ps}/**/*_counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
@@ -23,7 +24,11 @@ for line in open(O + "/index.txt"):
     n, busy = acc[best]["SQ_VALU_MFMA_BUSY_CYCLES"]
     _, gui = acc[best]["GRBM_GUI_ACTIVE"]
     simd_cycles = gui / 8.0 * 1024.0
-    print(f"{name:22s} {ps:6s} {best:58s} {n:8d} {busy / simd_cycles:10.3f} {gui / 8.0 / n:14.0f}")
+    single = name in ("aspp_d12", "aspp_d24", "aspp_d36") and ps in grouped
+    print(f"{name:22s} {ps:6s} {best:58s} {n:8d} {busy / simd_cycles:10.3f} {gui / 8.0 / n:14.0f}"
+          + ("   (single launch: not in the step, not in the totals)" if single else ""))
+    if single:
+        continue
     tot[ps][0] += busy
     tot[ps][1] += simd_cycles
     tot["all"][0] += busy

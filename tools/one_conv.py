@@ -24,8 +24,28 @@ def main():
     for kv in [x for x in a.opt.split(",") if x]:
         k, v = kv.split("=")
         ops.set_option(k, v)
-    Cin, Cout, k, s, d, H, B = [int(v) for v in a.shape.split(",")]
     dev = torch.device("cuda:0")
+    if a.shape.startswith("aspp"):
+        # ASPP's four branch convolutions as the step runs them (round 5): one grouped forward launch / one multi-source
+        # input-gradient launch.  --shape aspp[,B[,H]]
+        parts = a.shape.split(",")
+        B, H = (int(parts[1]) if len(parts) > 1 else 16), (int(parts[2]) if len(parts) > 2 else 32)
+        ks, dils = [1, 3, 3, 3], [1, 12, 24, 36]
+        x = torch.randn(B, 2048, H, H, device=dev)
+        ws = [torch.randn(256, 2048, k, k, device=dev) * 0.02 for k in ks]
+        preps = [ops.prep_weights(w) for w in ws]
+        dys = [torch.randn(B, 256, H, H, device=dev) for _ in ks]
+        shapes = [tuple(w.shape) for w in ws]
+        order = [1, 2, 3, 0]
+        for _ in range(a.reps):
+            if a.which == "fwd":
+                ops.conv2d_fwd_group(x, [p[0] for p in preps], shapes, dils)
+            else:
+                ops.conv2d_dgrad_multi([dys[i] for i in order], [preps[i][1] for i in order], [shapes[i] for i in order],
+                                       [dils[i] for i in order], tuple(x.shape))
+        torch.cuda.synchronize()
+        return
+    Cin, Cout, k, s, d, H, B = [int(v) for v in a.shape.split(",")]
     pad = (k // 2) * d if k > 1 else 0
     x = torch.randn(B, Cin, H, H, device=dev)
     w = torch.randn(Cout, Cin, k, k, device=dev) * 0.05

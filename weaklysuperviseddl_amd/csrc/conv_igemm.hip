@@ -1239,6 +1239,7 @@ double wgrad_executed_fraction(int P, int OH, int ow0, int own, int H, int W, in
 }
 
 int g_tile_threshold = 400;   // blocks below which the half-size pixel tile is used
+int g_group_tps10 = 30;       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (30: d12 in 3 slices, d24 whole - 648 / 623 / 636 us at 20 / 30 / 45)
 constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
 
 int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 32
@@ -1763,6 +1764,7 @@ int wsdl_set_option(const char* name, int value) {
         return WSDL_OK;
     }
     if (!strcmp(name, "range_sentinel")) { wsdl::g_range_sentinel = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 30; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
     if (!strcmp(name, "layercam_tail_mod")) {
@@ -1896,7 +1898,7 @@ int wsdl_conv2d_dgrad(const float* dy, const void* wt_dgrad, float* dx, int B, i
 // ---- several forward convolutions of ONE input in one launch (conv_split.h: conv_igemm_split_group_kernel) ----------------
 // K slices per problem: a tile executes 1 .. T taps (padding taps are skipped); slices of about two taps each keep the
 // longest workgroup of the launch short against the launch itself (the dispatcher then balances the CUs)
-static int group_ksplit(int max_taps) { return std::max(1, std::min(4, max_taps / 2)); }
+static int group_ksplit(int max_taps) { return std::max(1, std::min(4, (max_taps * 10) / g_group_tps10)); }
 
 static int group_max_taps(int H, int W, int k, int dil) {
     if (k == 1) return 1;

@@ -189,6 +189,10 @@ class GradBucketReducer:
         self._held = {}                    # steady mode: gradients of cut-out parameters that fired here, held back one step
         self.control_exchanges_blocking = 0
         self.control_exchanges_async = 0
+        # True while a rank verifies a freshly recorded launch plan: the verification's extra steps (an eager one on a probe
+        # batch, the same batch through the replay) issue NO collective and take no part in the control exchange - ranks may
+        # record at different moments (or not at all) without their collective sequences drifting apart
+        self._local_only = False
         if self.active:
             self._control = control_group(process_group)
             self._bitmap = torch.zeros(nparams + 1, dtype=torch.uint8)          # last byte: error flag
@@ -293,6 +297,8 @@ class GradBucketReducer:
         self._all_reduce(self.opt.flat_grad[lo:hi], ordered=True)
 
     def _all_reduce(self, view, ordered=False):
+        if self._local_only:
+            return          # verification of a launch plan (plan.PlannedTrainStep): the extra steps stay inside the rank
         if view.is_cuda:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
@@ -354,6 +360,17 @@ class GradBucketReducer:
         """Launch any bucket whose hooks did not all fire, reduce late gradients of excluded parameters, join, and
         learn which parameters to leave out next step - all from the bitmap every rank agrees on."""
         opt = self.opt
+        if self.active and self._local_only:
+            self._join_side()
+            for b in range(len(self.bucket_size)):          # same ranges as last step: only re-arm the counters
+                lo, hi = self._range[b]
+                idx = [i for i, bb in enumerate(self.bucket_of) if bb == b and i not in self._excluded]
+                self._remaining[b] = (idx[-1] - idx[0] + 1) if (idx and hi > lo) else 0
+            self._pending = []
+            self._fired = {}
+            self._launched = [False] * len(self.bucket_size)
+            self.early_launches = 0
+            return
         if self.active:
             from . import ops as _ops
             if _ops.PLAN_REPLAYING[0]:

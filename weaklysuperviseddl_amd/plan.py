@@ -220,13 +220,20 @@ class PlannedTrainStep:
 
         probe_img = self.s_images * 0.75 + 0.1
         probe_masks = 1 - torch.clamp(self.s_masks, max=1)
-        restore(before)
-        ref_loss = self.eager(probe_img, probe_masks).clone()
-        ref = [t.clone() for t in state]
-        restore(before)
-        self.s_images.copy_(probe_img)
-        self.s_masks.copy_(probe_masks)
-        plan.replay()
+        red = getattr(opt, "_wsdl_reducer", None)
+        if red is not None:
+            red._local_only = True          # data parallel: the two verification steps exchange nothing (dp.GradBucketReducer)
+        try:
+            restore(before)
+            ref_loss = self.eager(probe_img, probe_masks).clone()
+            ref = [t.clone() for t in state]
+            restore(before)
+            self.s_images.copy_(probe_img)
+            self.s_masks.copy_(probe_masks)
+            plan.replay()
+        finally:
+            if red is not None:
+                red._local_only = False
         bad = [i for i, (t, a) in enumerate(zip(state, ref)) if not torch.equal(t, a)]
         loss_same = torch.equal(loss.detach(), ref_loss)
         restore(after)
