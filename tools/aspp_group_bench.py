@@ -67,4 +67,4 @@ print(f"input gradient: chain of four {timeit(dgrad_chain):.1f} us, multi-source
 for tps in (20, 30, 45):
     ops.set_option("group_tps10", tps)
     print(f"group_tps10 = {tps}: grouped forward {timeit(fwd_group):.1f} us")
-ops.set_option("group_tps10", 30)
+ops.set_option("group_tps10", 20)

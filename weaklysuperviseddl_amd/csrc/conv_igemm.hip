@@ -60,6 +60,7 @@ struct ConvP {
     int b_ow0[4], b_own[4], b_tile0[5];
     int grid_x;         // host only: pixel tiles of the launch when banded (0 = cdiv(P, BN))
     int xcd_py;         // split kernels: > 0 = XCD-aware tile order with this many row groups (1, 2, 4 or 8); 0 = launch order
+    int xcd_rowfast;    // ... with the XCD's tiles taken row tile fastest (multi-source launches)
     const float* x_amax;   // split kernels, fp16x2 arithmetic: device scalar >= max|x| (the scale of the activation operand)
     float* y_amax;         // optional: receives max|y| of what the epilogue stores (atomicMax into a zeroed device scalar)
     // accumulate with a bit mask (dgrad of a bottleneck's first convolution): the value already in y counts only where bit
@@ -1239,7 +1240,11 @@ double wgrad_executed_fraction(int P, int OH, int ow0, int own, int H, int W, in
 }
 
 int g_tile_threshold = 400;   // blocks below which the half-size pixel tile is used
-int g_group_tps10 = 30;       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (30: d12 in 3 slices, d24 whole - 648 / 623 / 636 us at 20 / 30 / 45)
+int g_xcd_rowfast = 0;               // experiment: row-tile-fastest XCD order for every XCD-mapped launch of the split kernels
+int g_ms_rowfast = 1, g_ms_py = 0;   // multi-source launches: row-tile-fastest XCD order; forced number of row groups (0 = auto)
+int g_group_interleave = 1;          // grouped forward: stream-interleaved workgroup order when the streams fill the XCDs evenly
+int g_group_tps10 = 20;       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (20: d12 in 4 slices, d24 in 2 = eight
+                              // streams, one per XCD.  648 / 623 / 636 us at 20 / 30 / 45 on one box, 662 / 713 at 20 / 30 on another)
 constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
 
 int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 32
@@ -1315,6 +1320,19 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
+    p.xcd_rowfast = g_xcd_rowfast;
+    if (p.nsrc > 0 && g_ms_rowfast && grid.y % 2 == 0 && ((long long)grid.x * grid.y) % 8 == 0) {
+        // the sources' weights together are the larger operand and every workgroup streams all of them: let the workgroups
+        // an XCD runs at once span row tiles as well as pixel tiles
+        // py row groups: an XCD owns grid.y / py row tiles x grid.x * py / 8 pixel tiles and runs ~32 of them at once, row tile
+        // fastest.  ASPP's 8 x 128 tiles, same box: pixel-fastest order 792 us; row-fastest py = 1 / 2 / 4: 774 / 804 / 710 us
+        int py = g_ms_py > 0 ? g_ms_py : 4;
+        while (py > 1 && (grid.y % py || grid.x % (8 / py))) py /= 2;
+        if (grid.y % py == 0 && grid.x % (8 / py) == 0) {
+            p.xcd_py = py;
+            p.xcd_rowfast = 1;
+        }
+    }
     if (p.nsrc > 0) {        // several convolutions accumulated into one output (conv_split.h, MS)
         if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2, false, true>), grid, dim3(512), 0, s, p);
         else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1, false, true>), grid, dim3(512), 0, s, p);
@@ -1764,7 +1782,11 @@ int wsdl_set_option(const char* name, int value) {
         return WSDL_OK;
     }
     if (!strcmp(name, "range_sentinel")) { wsdl::g_range_sentinel = value != 0; return WSDL_OK; }
-    if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 30; return WSDL_OK; }
+    if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 20; return WSDL_OK; }
+    if (!strcmp(name, "group_interleave")) { g_group_interleave = value; return WSDL_OK; }
+    if (!strcmp(name, "ms_rowfast")) { g_ms_rowfast = value; return WSDL_OK; }
+    if (!strcmp(name, "xcd_rowfast")) { g_xcd_rowfast = value; return WSDL_OK; }
+    if (!strcmp(name, "ms_py")) { g_ms_py = value; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
     if (!strcmp(name, "layercam_tail_mod")) {
@@ -2002,6 +2024,27 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
         bytes += 4.0 * ((double)p.K * Cout + (double)p.P * Cout);
     }
     grp.start[n] = start;
+    // stream-interleaved order: one (problem, K slice) stream per residue of the workgroup index - when the streams number a
+    // multiple or a divisor of the 8 XCDs and every problem has the same tile count, each XCD runs whole streams
+    {
+        int ns = 0;
+        bool same = true;
+        for (int j = 0; j < n; ++j) {
+            ns += grp.p[j].ksplit;
+            same = same && grp.gx[j] * grp.gy[j] == grp.gx[0] * grp.gy[0];
+        }
+        if (g_group_interleave && same && ns <= 8 && (8 % ns == 0)) {
+            grp.ns = ns;
+            int s = 0;
+            for (int j = 0; j < n; ++j)
+                for (int z = 0; z < grp.p[j].ksplit; ++z) {
+                    grp.s_prob[s] = j;
+                    grp.s_slice[s] = z;
+                    ++s;
+                }
+            for (int j = 0; j < n; ++j) grp.p[j].xcd_py = 0;      // the streams ARE the XCD assignment
+        }
+    }
     {
         wsdl::ProfScope prof(WSDL_PROF_SPLIT_256x128, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
         if (g_conv_arith == 2)

@@ -202,8 +202,15 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
         const int xcd = L & 7, idx = L >> 3;
         const int py = p.xcd_py, px = 8 / py;
         const int lx = gx / px, ly = grid_y / py;
-        bx = (xcd / py) * lx + idx % lx;
-        by = (xcd % py) * ly + idx / lx;
+        if (p.xcd_rowfast) {
+            // the workgroups an XCD runs at once (consecutive idx) cover ly row tiles x a few pixel tiles: they share the pixel
+            // tiles' activations AND the row tiles' weights (pixel-fastest order gives them one row tile and 32 pixel tiles)
+            bx = (xcd / py) * lx + idx / ly;
+            by = (xcd % py) * ly + idx % ly;
+        } else {
+            bx = (xcd / py) * lx + idx % lx;
+            by = (xcd % py) * ly + idx / lx;
+        }
     }
     const int m0 = by * BM;
     int w_ow0 = p.ow0, w_own = p.own, w_tile0 = 0;
@@ -583,11 +590,23 @@ struct ConvGroup {
     int n;
     int start[5];
     int gx[4], gy[4];
+    // interleaved form (ns > 0): workgroup L works on stream L % ns - a (problem, K slice) pair - and on tile L / ns of it.  With
+    // ns = 8 (the XCDs: workgroup L runs on XCD L % 8) every XCD runs ONE stream: its 32 workgroups at a time read the same
+    // weights through the same L2.  In problem-major order workgroups of many streams share each L2, nothing is reused and the
+    // launch fetches 3.9 GB past L2 for 0.26 GB of operands (profiles/r05_notes.md).
+    int ns;
+    int s_prob[8], s_slice[8];
     ConvP p[4];
 };
 template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_group_kernel(ConvGroup grp) {
     const int L = blockIdx.x;
+    if (grp.ns > 0) {
+        const int s = L % grp.ns, r = L / grp.ns;
+        const int g = grp.s_prob[s], gx = grp.gx[g], gy = grp.gy[g];
+        conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false>(grp.p[g], r % gx, r / gx, grp.s_slice[s], gx, gy);
+        return;
+    }
     int g = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
