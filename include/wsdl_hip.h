@@ -61,6 +61,9 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches)
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
+ *   group_tps10   20*  wsdl_conv2d_fwd_group: taps per K slice in tenths (20: a 9-tap problem in 4 slices, a 4-tap one in 2)
+ *   group_interleave 1* ... with the workgroups of its (problem, slice) streams interleaved, one stream per XCD when there are 8
+ *   ms_rowfast     1*  wsdl_conv2d_dgrad_multi: XCD-aware tile order taken row tile fastest;  ms_py 0* = 4 row groups (1 / 2 / 4 / 8)
  *   range_sentinel 0*  1 = the amax arguments of wsdl_bn_train_fwd / _bwd are (max, ~min channel maximum) pairs (wsdl_range_check)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      64 channels, n > 1 = from n channels; measured: resident wins at every channel count of the networks)
