@@ -411,6 +411,11 @@ int wsdl_plane_relu_minmax(const float* x, float* y, int planes, int hw, wsdl_st
  * (hipGraph) launches, where a host `step` would be frozen at capture time. */
 int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                    float beta2, float eps, int step, const int* step_dev, float grad_scale, wsdl_stream_t stream);
+/* The same step with EVERY per-step quantity on the device: hyper_dev = {lr, beta1, beta2, eps, grad_scale} (five floats) and
+ * the step number step_dev - a learning-rate schedule then changes five floats in device memory, not a kernel argument, so a
+ * recorded launch plan (below) stays valid. */
+int wsdl_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper_dev, const int* step_dev,
+                       wsdl_stream_t stream);
 
 /* ---- refine_pseudo_mask inner step (TraditionalModel/AlternatingDirectionCutLoss.py:736-757) -
  * KL(softmax(X) || S) with log(X+1e-8), reduction 'batchmean', and its gradient wrt softmax(X). */

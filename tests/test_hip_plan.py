@@ -115,8 +115,9 @@ def test_planned_train_step_is_bit_identical_to_the_eager_path(dev):
 
 
 def test_planned_step_interleaved_with_eval_and_eager_steps(dev):
-    """An evaluation forward between replays reads the layouts the replay wrote; an eager step in between (parameters
-    changed behind the plan's back) makes the next call record again instead of replaying stale layouts."""
+    """An evaluation forward between replays reads the layouts the replay wrote; an eager step in between leaves the layouts
+    current (it ends with the same in-place re-layout), so the plan goes on replaying; parameters written some other way
+    (a state_dict loaded back) are re-laid out before the next replay."""
     from weaklysuperviseddl_amd import plan
     from weaklysuperviseddl_amd.TraditionalModel import train_step
     from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import _train_step_eager
@@ -138,7 +139,11 @@ def test_planned_step_interleaved_with_eval_and_eager_steps(dev):
             train_step(model, opt, *batches[0])
             _train_step_eager(model, opt, *batches[1])                 # behind the plan's back
             train_step(model, opt, *batches[0])
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
             train_step(model, opt, *batches[1])
+            model.load_state_dict(sd)                                  # parameters rewritten by copies: the layouts are stale
+            train_step(model, opt, *batches[1])
+            train_step(model, opt, *batches[0])
             torch.cuda.synchronize()
             return model, opt, outs, next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
         finally:
@@ -146,7 +151,7 @@ def test_planned_step_interleaved_with_eval_and_eager_steps(dev):
 
     m0, o0, e0, _ = run(False)
     m1, o1, e1, st = run(True)
-    assert st.disabled is None and st.records == 2 and st.replays >= 2, (st.disabled, st.records, st.replays)
+    assert st.disabled is None and st.records == 1 and st.replays >= 6, (st.disabled, st.records, st.replays)
     assert torch.equal(e0[0], e1[0])
     for a, b in zip(_state(m0, o0), _state(m1, o1)):
         assert torch.equal(a, b)
@@ -267,3 +272,49 @@ def test_host_issue_time_of_a_replayed_step(dev):
     report_line(f"train step B=16 256x256: host issue eager {res[False][0]:.2f} ms (step {res[False][1]:.2f}), "
                 f"plan replay {res[True][0]:.2f} ms (step {res[True][1]:.2f})")
     assert res[True][0] < 0.6 * res[False][0]
+
+
+def test_an_odd_sized_last_batch_gets_its_own_plan_on_its_second_occurrence(dev):
+    """Epochs of three full batches and a smaller last one: the full batch's plan is kept, the odd shape runs eagerly the
+    first time it turns up and is recorded the second time; everything equals the eager run bit for bit."""
+    full = [_batch(4, 64, dev, s) for s in (31, 32, 33)]
+    last = _batch(2, 64, dev, 34)
+    batches = (full + [last]) * 3
+    m0, o0, l0, _ = _run(dev, False, len(batches), batches)
+    m1, o1, l1, st = _run(dev, True, len(batches), batches)
+    assert st.disabled is None and st.records == 2 and len(st.entries) == 2, (st.disabled, st.records, len(st.entries))
+    assert st.replays == len(batches) - 2 - 1 - 2          # two warm-up calls, the odd shape's first (eager) call, two recordings
+    assert l0 == l1
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+
+
+def test_a_learning_rate_schedule_does_not_invalidate_the_plan(dev):
+    """lr, betas, eps and grad_scale reach the Adam kernel through device memory (FlatAdam.hyper_dev): a schedule that changes
+    the learning rate every step changes five floats, not a launch - ONE recording, and the run equals the eager one bit for bit."""
+    from weaklysuperviseddl_amd import plan
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    batches = [_batch(4, 64, dev, s) for s in (41, 42)]
+
+    def run(planned):
+        old = plan.PLAN_STEP[0]
+        plan.PLAN_STEP[0] = planned
+        try:
+            model, opt = _model_and_opt(dev, 3)
+            torch.manual_seed(77)
+            for i in range(8):
+                opt.lr = 1e-4 * (0.8 ** i)
+                train_step(model, opt, *batches[i % 2])
+            torch.cuda.synchronize()
+            return model, opt, next(iter(opt.__dict__.get("_wsdl_planned", {}).values()), None)
+        finally:
+            plan.PLAN_STEP[0] = old
+
+    m0, o0, _ = run(False)
+    m1, o1, st = run(True)
+    assert st.disabled is None and st.records == 1 and st.replays == 5, (st.disabled, st.records, st.replays)
+    for a, b in zip(_state(m0, o0), _state(m1, o1)):
+        assert torch.equal(a, b)
+    # and the schedule really acted: a run at constant lr ends elsewhere
+    m2, o2, _l, _s = _run(dev, False, 8, batches, seed=3)
+    assert not torch.equal(o2.flat_param, o0.flat_param)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "wsdl_keep_largest": (_i, [_vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "wsdl_plane_relu_minmax": (_i, [_vp, _vp, _i, _i, _vp]),
     "wsdl_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    "wsdl_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "wsdl_kl_div_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
     "wsdl_kl_div_per_image_fwd_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _sz, _vp, _sz, _vp]),
     "wsdl_refine_combine": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp, _i, _sz, _vp]),

@@ -286,7 +286,15 @@ __global__ void layercam_upsample_kernel(CamLayers L, const float* __restrict__ 
 // torch.optim.Adam (no amsgrad, no weight decay): exp_avg, exp_avg_sq, bias corrections as torch
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float b1, float b2, float eps, float step_size,
-                            float sqrt_bc2, float gscale, const int* __restrict__ step_dev, float lr) {
+                            float sqrt_bc2, float gscale, const int* __restrict__ step_dev, float lr,
+                            const float* __restrict__ hyper) {
+    if (hyper) {            // lr, beta1, beta2, eps, grad_scale on the device: a schedule changes them without a new launch plan
+        lr = hyper[0];
+        b1 = hyper[1];
+        b2 = hyper[2];
+        eps = hyper[3];
+        gscale = hyper[4];
+    }
     if (step_dev) {
         // the step number lives on the device (hipGraph replay: the host value is frozen at capture time); same
         // double-precision bias corrections as the host path
@@ -414,7 +422,19 @@ int wsdl_adam_step(float* p, const float* g, float* m, float* v, size_t n, float
     const float sqrt_bc2 = (float)std::sqrt(bc2);
     const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 8192);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), p, g, m, v, n, beta1,
-                       beta2, eps, step_size, sqrt_bc2, grad_scale, step_dev, lr);
+                       beta2, eps, step_size, sqrt_bc2, grad_scale, step_dev, lr, (const float*)nullptr);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
+int wsdl_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper_dev, const int* step_dev,
+                       wsdl_stream_t stream) {
+    WSDL_REQUIRE(p && g && m && v && n > 0 && hyper_dev && step_dev, "adam_step_dev: null pointer / empty");
+    WSDL_REQUIRE((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                  reinterpret_cast<uintptr_t>(v)) % 16 == 0, "adam_step_dev: buffers must be 16-byte aligned");
+    const int blocks = (int)std::min<size_t>((n / 4 + 255) / 256 + 1, 8192);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, wsdl::as_stream(stream), p, g, m, v, n, 0.f, 0.f, 0.f, 0.f, 1.f,
+                       1.f, step_dev, 0.f, hyper_dev);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -1769,10 +1769,15 @@ def plane_relu_minmax(x):
     return y
 
 
-def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None):
-    """``step_dev``: device int32 step number (used instead of ``step`` - hipGraph replay)."""
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None, hyper_dev=None):
+    """``step_dev``: device int32 step number (used instead of ``step`` - hipGraph replay).  ``hyper_dev``: device floats
+    (lr, beta1, beta2, eps, grad_scale) used instead of the host values (with ``step_dev``): nothing of the launch changes
+    when a schedule changes them."""
     for t in (p, g, m, v):
         _req(t, "adam buffer")
+    if hyper_dev is not None and step_dev is not None:
+        check(lib().wsdl_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper_dev), _p(step_dev), _stream()))
+        return
     check(lib().wsdl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
                                float(eps), int(step), _p(step_dev), float(grad_scale), _stream()))
 

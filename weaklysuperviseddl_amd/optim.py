@@ -36,6 +36,10 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.grad_scale = lr, betas, eps, grad_scale
         self.step_count = 0
         self.step_dev = torch.zeros(1, device=dev, dtype=torch.int32) if dev.type == "cuda" else None   # device twin
+        # lr, beta1, beta2, eps, grad_scale as the Adam kernel reads them (device floats: a schedule or a reducer changing one of
+        # them changes memory, not a launch - a recorded launch plan of the step stays valid); sync_hyper() keeps them current
+        self.hyper_dev = torch.zeros(5, device=dev, dtype=torch.float32) if dev.type == "cuda" else None
+        self._hyper_host = None
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
@@ -158,7 +162,7 @@ class FlatAdam:
                 ops.add_int(self.step_dev, 1)
             ops.adam_step_flat(self.flat_param[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
                                self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
-                               step_dev=self.step_dev)
+                               step_dev=self.step_dev, hyper_dev=self.hyper_dev)
             if not self.capture_mode:
                 ev = self._seg_events[k]               # one event per segment, re-recorded step after step
                 if ev is None:
@@ -184,6 +188,13 @@ class FlatAdam:
         self._remaining = [sum(1 for i in idx if i in self._expected) for idx in self.seg_params]
         self._backward_pending = False
 
+    def sync_hyper(self):
+        """Copy (lr, beta1, beta2, eps, grad_scale) to the device when one of them changed since the last call."""
+        cur = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale))
+        if self.hyper_dev is not None and cur != self._hyper_host:
+            self.hyper_dev.copy_(torch.tensor(cur, dtype=torch.float32))
+            self._hyper_host = cur
+
     def take_fresh(self, p):
         f = self._fresh.get(id(p), False)
         self._fresh[id(p)] = False
@@ -195,6 +206,7 @@ class FlatAdam:
             h(p)
 
     def zero_grad(self, set_to_none=False):
+        self.sync_hyper()               # (segments may be stepped from backward hooks, before step() is reached)
         if self.flat_grad.is_cuda and getattr(self, "_dirty", True):
             ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
         if self.flat_grad.is_cuda:
@@ -231,6 +243,7 @@ class FlatAdam:
         return self._step()
 
     def _step(self):
+        self.sync_hyper()
         if self.pre_step_hook is not None:
             # (the data-parallel reducer's wait(): collectives' work handles, control-plane exchange - host work that a launch
             # plan repeats live at this place)
@@ -251,7 +264,7 @@ class FlatAdam:
             ops.add_int(self.step_dev, 1)
             ops.adam_step_flat(self.flat_param, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.lr,
                                self.betas[0], self.betas[1], self.eps, self.step_count, self.grad_scale,
-                               step_dev=self.step_dev)
+                               step_dev=self.step_dev, hyper_dev=self.hyper_dev)
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
         self._dirty = False                     # (joined above)

@@ -131,6 +131,16 @@ def _hook_tables(model):
     return out
 
 
+MAX_PLANS = 2       # plans kept per training step (each holds a step's activations): the usual batch and one odd-sized one
+
+
+class _Entry:
+    __slots__ = ("plan", "s_images", "s_masks", "s_loss", "bn_delta", "sites")
+
+    def __init__(self, plan, s_images, s_masks, s_loss, bn_delta, sites):
+        self.plan, self.s_images, self.s_masks, self.s_loss, self.bn_delta, self.sites = plan, s_images, s_masks, s_loss, bn_delta, sites
+
+
 class PlannedTrainStep:
     """``train_step(model, optimizer, images, masks, ...)`` as a verified plan replay (module docstring)."""
 
@@ -139,8 +149,10 @@ class PlannedTrainStep:
         self.model, self.opt, self.eager = model, optimizer, eager
         self.warmup = PLAN_WARMUP if warmup is None else int(warmup)
         self.calls = 0
-        self.plan = None
+        self.plan = None                # the plan of the most recent replay / recording (``entries`` holds one per key)
         self.key = None
+        self.entries = {}               # key -> _Entry: a plan per (shapes, options) - e.g. an epoch's smaller last batch
+        self.seen = {}                  # key -> eligible calls that found no plan for it
         self.disabled = None            # why this step stays eager, once it does
         self.replays = 0
         self.records = 0
@@ -153,10 +165,10 @@ class PlannedTrainStep:
     def _key(self, images, masks):
         opt = self.opt
         red = getattr(opt, "_wsdl_reducer", None)
-        return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device, float(opt.lr),
+        # (lr, betas, eps, grad_scale are NOT part of the key: the Adam kernel reads them from device memory - optim.FlatAdam.hyper_dev)
+        return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device,
                 None if red is None else (id(red), id(red._steady_set)),
-                tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params),
-                tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale), ops.LAYOUT_EPOCH[0],
+                tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params), ops.LAYOUT_EPOCH[0],
                 ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0], ops.ASPP_MULTI[0], ops.ASPP_GROUP_FWD[0],
                 ops.raw_stream(images.device))
 
@@ -183,10 +195,11 @@ class PlannedTrainStep:
         ts += [m._counter for m in self._dropouts if m._counter is not None]
         return ts
 
-    def _record(self, images, masks):
+    def _record(self, images, masks, key=None):
         dev = images.device
         opt = self.opt
         self.records += 1
+        self.plan = None
         self.s_images = images.detach().clone()
         self.s_masks = masks.detach().to(torch.int64).clone()
         state = self._state()
@@ -246,9 +259,15 @@ class PlannedTrainStep:
                              + ") - the step contains work a plan does not see (kernels of the tensor library in a custom loss?)")
             return loss_real
         self.plan, self.s_loss = plan, loss.detach()
-        self._layout_sites = [(m.__dict__["_wsdl_cache"], m.weight) for m in self._convs
-                              if m.__dict__.get("_wsdl_cache", {}).get("prep") is not None and m.weight.requires_grad]
-        self._epoch_after = ops.PARAM_EPOCH[0]
+        # the weight-layout buffers the plan's launches read and rewrite: (module cache, weight, the (fwd, dgrad) pair as recorded)
+        sites = [(m.__dict__["_wsdl_cache"], m.weight, m.__dict__["_wsdl_cache"]["prep"]) for m in self._convs
+                 if m.__dict__.get("_wsdl_cache", {}).get("prep") is not None and m.weight.requires_grad]
+        ent = _Entry(plan, self.s_images, self.s_masks, self.s_loss, self._bn_delta, sites)
+        if key is not None:
+            while len(self.entries) >= MAX_PLANS:
+                self.entries.pop(next(iter(self.entries)))
+            self.entries[key] = ent
+        self.key = key
         return loss_real                    # (``loss`` itself lives in the plan: the next replay overwrites it)
 
     def _relayout(self):
@@ -256,35 +275,57 @@ class PlannedTrainStep:
         if self.opt.post_step_hook is not None:
             self.opt.post_step_hook()
 
+    def _buffers_intact(self, ent):
+        """Do the modules still hold the layout buffers the plan's launches point at?  (A cache miss elsewhere - an eval forward
+        after the layout options changed - allocates new ones: the plan would go on writing the old.)"""
+        return all(cache.get("prep") is prep for cache, _w, prep in ent.sites)
+
+    def _layouts_current(self, ent):
+        """Do those buffers hold the layouts of the CURRENT parameters?  Yes after a replay or an eager step (both end with the
+        re-layout); no after parameters were written some other way (load_state_dict): then they are re-laid out in place."""
+        ep = ops.PARAM_EPOCH[0]
+        return all(cache.get("prep_key") == (ep, w._version, w.data_ptr()) for cache, w, _prep in ent.sites)
+
     def __call__(self, images, masks):
         self.calls += 1
         if self.calls <= self.warmup or not self.usable(images, masks):
             return self.eager(images, masks)
         key = self._key(images, masks)
-        if self.plan is None or key != self.key or ops.PARAM_EPOCH[0] != self._epoch_after:
-            # (last condition: the parameters changed behind the plan's back - an eager step, load_state_dict - so the weight
-            # layouts the plan's forward reads are stale: record again, one eager step, rather than reason about who owns
-            # which layout buffer)
-            self.plan, self.key = None, key
-            return self._record(images, masks)
-        if images.data_ptr() != self.s_images.data_ptr():
-            self.s_images.copy_(images)
-        if masks.data_ptr() != self.s_masks.data_ptr():
-            self.s_masks.copy_(masks)
-        self.plan.replay()
+        ent = self.entries.get(key)
+        if ent is not None and not self._buffers_intact(ent):
+            self.entries.pop(key)
+            ent = None
+        if ent is None:
+            n = self.seen[key] = self.seen.get(key, 0) + 1
+            if self.entries and n < 2:
+                return self.eager(images, masks)        # a second shape seen once (an epoch's last batch): eager until it recurs
+            if self.records >= 6 and self.replays < 2 * self.records:
+                self.disabled = ("the step's key keeps changing (shapes, learning rate or options differ from call to call): "
+                                 "recording costs three steps each time")
+                return self.eager(images, masks)
+            if len(self.seen) > 64:
+                self.seen.clear()
+            return self._record(images, masks, key)
+        if not self._layouts_current(ent):
+            self._relayout()
+        self.opt.sync_hyper()                   # a learning-rate schedule: five floats in device memory, the plan stays
+        self.plan, self.key, self.s_images, self.s_masks, self.s_loss = ent.plan, key, ent.s_images, ent.s_masks, ent.s_loss
+        if images.data_ptr() != ent.s_images.data_ptr():
+            ent.s_images.copy_(images)
+        if masks.data_ptr() != ent.s_masks.data_ptr():
+            ent.s_masks.copy_(masks)
+        ent.plan.replay()
         self.replays += 1
         # host-side twins of what the replayed kernels did
         self.opt.step_count += 1
-        for b, d in self._bn_delta:
+        for b, d in ent.bn_delta:
             b._pending_steps += d
         ops.bump_param_epoch()
         ops.bump_stats_epoch()
         ep = ops.PARAM_EPOCH[0]
-        for cache, w in self._layout_sites:         # the replay re-laid the weights out in place: the caches stay valid
+        for cache, w, _prep in ent.sites:           # the replay re-laid the weights out in place: the caches stay valid
             cache["prep_key"] = (ep, w._version, w.data_ptr())
-        self._epoch_after = ep
-        return self.s_loss.clone()
-
+        return ent.s_loss.clone()
 
 
 def planned_step_for(model, optimizer, eager, tag):
