@@ -278,7 +278,10 @@ class PlannedTrainStep:
     def _buffers_intact(self, ent):
         """Do the modules still hold the layout buffers the plan's launches point at?  (A cache miss elsewhere - an eval forward
         after the layout options changed - allocates new ones: the plan would go on writing the old.)"""
-        return all(cache.get("prep") is prep for cache, _w, prep in ent.sites)
+        def same(cur, rec):
+            return cur is not None and all((a is None) == (b is None) and (a is None or a.data_ptr() == b.data_ptr())
+                                           for a, b in zip(cur, rec))
+        return all(same(cache.get("prep"), prep) for cache, _w, prep in ent.sites)
 
     def _layouts_current(self, ent):
         """Do those buffers hold the layouts of the CURRENT parameters?  Yes after a replay or an eager step (both end with the
