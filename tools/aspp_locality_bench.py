@@ -61,11 +61,3 @@ for rf, py in ((0, 0), (1, 1), (1, 2), (1, 4)):
     print(f"multi-source input gradient, rowfast {rf} py {py}: {timeit(dg):.1f} us (equal to the first form: {torch.equal(cur, ref)})")
 ops.set_option("ms_rowfast", 1)
 ops.set_option("ms_py", 0)
-for n256 in (0, 1):
-    ops.set_option("tile_n256", n256)
-    base.zero_()
-    dg()
-    cur = base.clone()
-    err = ((cur - ref).abs().max() / ref.abs().max()).item()
-    print(f"multi-source input gradient, 256 x {256 if n256 else 128} tiles: {timeit(dg):.1f} us (max rel diff to the first form {err:.1e})")
-ops.set_option("tile_n256", 0)

@@ -1316,11 +1316,12 @@ int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU wh
 // (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
 // alone (+3.5 % per kernel), 1-2.6 % slower on the STEP, where it leaves no room for the weight-gradient workgroups beside it
 // (818.6 -> 828.2, 824 -> 845 img/s on two boxes with the 16-deep form, profiles/r02_notes.md).  Removed.)
-int g_tile_n256 = 0;     // 256 x 256 tiles (two pixel tiles per workgroup share each weight chunk in LDS: half the weight traffic past
-                         // L2, 128 accumulators per lane): bit 1 multi-source launches, bit 2 grouped forward, bit 4 every 256-row launch
-int launch_split_256x128(const ConvP& p_in, hipStream_t s, bool n256 = false) {
+// (256 x 256 tiles - two pixel tiles per workgroup sharing each weight chunk in LDS, 128 accumulators per lane, 202-215 registers,
+// 82 KB of LDS - were an experiment of round 5 ("tile_n256"): multi-source input gradient 738 us against 724, every eligible
+// launch of the step -1.9 % img/s.  Removed; profiles/r05_notes.md.)
+int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     ConvP p = p_in;
-    dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, n256 ? 256 : 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
+    dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     p.xcd_rowfast = g_xcd_rowfast;
     if (p.nsrc > 0 && g_ms_rowfast && grid.y % 2 == 0 && ((long long)grid.x * grid.y) % 8 == 0) {
@@ -1334,12 +1335,6 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s, bool n256 = false) {
             p.xcd_py = py;
             p.xcd_rowfast = 1;
         }
-    }
-    if (n256 && g_conv_arith == 1) {
-        if (p.nsrc > 0) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 256, 4, 16, 512, 1, false, true>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 256, 4, 16, 512, 1, false, false>), grid, dim3(512), 0, s, p);
-        WSDL_LAUNCH_CHECK();
-        return WSDL_OK;
     }
     if (p.nsrc > 0) {        // several convolutions accumulated into one output (conv_split.h, MS)
         if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2, false, true>), grid, dim3(512), 0, s, p);
@@ -1455,9 +1450,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     // 256-row tiles only where the rows fill them (>= 90 %: not for 128-channel outputs)
     const bool t256 = cfg == 0 && split && g_tile256 && p.Cout * 10 >= wsdl::cdiv(p.Cout, 256) * 256 * 9 &&
                       (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 256) * p.ksplit >= 256;
-    const bool n256 = t256 && g_conv_arith == 1 && ((g_tile_n256 & 4) || (p.nsrc > 0 && (g_tile_n256 & 1))) &&
-                      (long long)wsdl::cdiv(p.P, 256) * wsdl::cdiv(p.Cout, 256) * p.ksplit >= 256;
-    const int bn_tile = n256 ? 256 : cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128;
+    const int bn_tile = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128;
     double executed = flops;
     if (aligned && wsdl::prof_enabled()) {
         executed = 0.0;
@@ -1489,7 +1482,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
             return WSDL_EINVAL;
         }
         if (t256) {
-            rc = launch_split_256x128(q, s, n256);
+            rc = launch_split_256x128(q, s);
         } else
         switch (cfg) {
             case 0: rc = launch_cfg<128, 128, 2>(q, s, aligned, split); break;
@@ -1795,7 +1788,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 20; return WSDL_OK; }
     if (!strcmp(name, "group_interleave")) { g_group_interleave = value; return WSDL_OK; }
     if (!strcmp(name, "ms_rowfast")) { g_ms_rowfast = value; return WSDL_OK; }
-    if (!strcmp(name, "tile_n256")) { g_tile_n256 = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_rowfast")) { g_xcd_rowfast = value; return WSDL_OK; }
     if (!strcmp(name, "ms_py")) { g_ms_py = value; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
