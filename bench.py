@@ -163,6 +163,33 @@ def _pmc_file():
     return files[-1], d
 
 
+def kernel_matches(cls, name):
+    """Is the profiler's kernel `name` an instantiation of the library's timing class `cls` (wsdl_prof_class_name)?  Class names
+    carry placeholders where instantiations differ (AR = the arithmetic, BK / MODE / DYRAW = any) and may leave trailing template
+    arguments out (those must then be the profiler's printed defaults: anything)."""
+    from weaklysuperviseddl_amd import ops
+    name = name.replace("(anonymous namespace)::", "").replace("wsdl::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    name = name.split("(")[0].strip()
+    base = cls.split("<")[0]
+    if name.split("<")[0] != base:
+        return False
+    want = [t.strip() for t in cls[len(base):].strip("<>").split(",")] if "<" in cls else []
+    got = [t.strip() for t in name[len(base):].strip("<>").split(",")] if "<" in name else []
+    if len(want) > len(got):
+        return False
+    for w, g in zip(want, got):
+        if w == "AR":
+            if g != str(ops.CONV_ARITH[0] if ops.CONV_ARITH[0] != 1 else 1):
+                return False
+        elif w in ("BK", "MODE", "DYRAW", "MF"):
+            continue
+        elif w != g:
+            return False
+    return True
+
+
 def pmc_traffic(kernel, with_source=False):
     """HBM bytes per launch (fetch + write) of `kernel` from the committed rocprofv3 --pmc passes of this command
     (profiles/r*_pmc_traffic.json: FETCH_SIZE x 2 - gfx950 counts half of a coalesced read, calibrated on a
@@ -171,16 +198,8 @@ def pmc_traffic(kernel, with_source=False):
     path, d = _pmc_file()
     if path is None:
         return (None, None) if with_source else None
-    from weaklysuperviseddl_amd import ops
-    # the library's timing classes name the arithmetic template argument "AR"; rocprofv3 prints its value
-    name = kernel.replace(", AR>", f", {ops.CONV_ARITH[0]}>")
     kernels = d.get("kernels", {})
-    # rocprofv3 prints the K chunk the class name calls BK and the trailing template arguments it leaves at their defaults:
-    # of the candidates, the one the profiled run launched most
-    cands = []
-    for nm in ([name.replace(", BK,", f", {bk},") for bk in (16, 32)] if ", BK," in name else [name]):
-        cands += [v for kk, v in kernels.items() if kk == nm or kk.startswith(nm[:-1] + ", ") or
-                  (not nm.endswith(">") and kk.startswith(nm + "<"))]
+    cands = [v for kk, v in kernels.items() if kernel_matches(kernel, kk)]
     k = max(cands, key=lambda v: v.get("launches", 0)) if cands else None
     val = None if not k else round(k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"])
     if with_source:
@@ -214,25 +233,9 @@ def rocprof_avg_us(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1_serial_kernel_stats.csv")))
     if not files:
         return None, None, None
-    from weaklysuperviseddl_amd import ops
-    base = kernel.split("<")[0]
-    targs = kernel[len(base):].strip("<>").split(",") if "<" in kernel else []
-    targs = [t.strip() for t in targs]
     best = None
     for row in csv.DictReader(open(files[-1])):
-        name = row["Name"]
-        if f"::{base}<" not in name and f" {base}<" not in name and not name.startswith(base + "<") and f"::{base}(" not in name \
-                and not name.startswith(base + "("):
-            continue
-        got = name.split(base, 1)[1]
-        got = [t.strip() for t in got[1:got.index(">")].split(",")] if got.startswith("<") else []
-        ok = True
-        for i, t in enumerate(targs):          # class names carry placeholders (AR, BK, MODE, DYRAW) where instantiations differ
-            if t == "AR":
-                ok &= i < len(got) and got[i] == str(ops.CONV_ARITH[0])
-            elif t.isdigit():
-                ok &= i < len(got) and got[i] == t
-        if ok and (best is None or int(row["Calls"]) > int(best["Calls"])):
+        if kernel_matches(kernel, row["Name"]) and (best is None or int(row["Calls"]) > int(best["Calls"])):
             best = row
     if best is None:
         return None, None, os.path.relpath(files[-1], ROOT)

@@ -123,7 +123,9 @@ enum { WSDL_PROF_IGEMM_128x128_A = 0,  /* conv_igemm_fast_kernel<128,128,2,16> (
        WSDL_PROF_WGRAD_SPLIT16D = 20,  /* conv_wgrad_split16d_kernel<MODE, DYRAW> (x fragments straight from global memory); class 17 is then
                                           the LDS-staged conv_wgrad_split16_kernel / conv_wgrad_split32_kernel.  Both brackets include the
                                           launch's dy_split16 pre-pass where there is one */
-       WSDL_PROF_NCLASSES = 21 };
+       WSDL_PROF_SPLIT_GROUP = 21,     /* conv_igemm_split_group_kernel<256,128,4,16,512,AR,false>: several forward convolutions, one launch */
+       WSDL_PROF_SPLIT_MULTI = 22,     /* conv_igemm_split_kernel<256,128,4,16,512,AR,false,true>: several input gradients, one accumulator */
+       WSDL_PROF_NCLASSES = 23 };
 const char* wsdl_prof_class_name(int cls);
 int wsdl_prof_enable(int on);
 int wsdl_prof_collect(int cls, long long* launches, double* total_ms, double* total_work,

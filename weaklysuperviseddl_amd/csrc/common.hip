@@ -93,8 +93,10 @@ const char* wsdl_prof_class_name(int cls) {
         "pairwise_kernel", "layercam_partial_kernel",
         "conv_igemm_split_kernel<128, 128, 2, 16, 256, AR>", "conv_igemm_split_kernel<128, 64, 2, 32, 256, AR>",
         "conv_igemm_split_kernel<64, 256, 1, 16, 256, AR>", "conv_igemm_split_kernel<64, 128, 1, 32, 256, AR>",
-        "conv_wgrad_split16_kernel<128, 128, false>", "conv_igemm_split_kernel<256, 128, 4, BK, 512, AR>",
-        "stem_conv7x7s2_kernel", "conv_wgrad_split16d_kernel<MODE, DYRAW>"};
+        "conv_wgrad_split16_kernel<128, 128, false>", "conv_igemm_split_kernel<256, 128, 4, BK, 512, AR, false, false>",
+        "stem_conv7x7s2_kernel", "conv_wgrad_split16d_kernel<MODE, DYRAW>",
+        "conv_igemm_split_group_kernel<256, 128, 4, 16, 512, AR, false>",
+        "conv_igemm_split_kernel<256, 128, 4, 16, 512, AR, false, true>"};
     // (BK: 16 in the 256x128 form - the profiler's name has the number; the split weight-gradient class: the default fp16x2 kernel's name; bf16x3 launches conv_wgrad_split32_kernel)
     return cls >= 0 && cls < WSDL_PROF_NCLASSES ? names[cls] : "?";
 }

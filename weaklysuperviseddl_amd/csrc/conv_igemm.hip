@@ -1461,7 +1461,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         }
     }
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
-    wsdl::ProfScope prof(t256 ? WSDL_PROF_SPLIT_256x128
+    wsdl::ProfScope prof(t256 ? (p.nsrc > 0 ? WSDL_PROF_SPLIT_MULTI : WSDL_PROF_SPLIT_256x128)
                               : split ? WSDL_PROF_SPLIT_128x128 + cfg : WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1),
                          s, flops, executed, bytes);
     {
@@ -2049,7 +2049,7 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
         }
     }
     {
-        wsdl::ProfScope prof(WSDL_PROF_SPLIT_256x128, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
+        wsdl::ProfScope prof(WSDL_PROF_SPLIT_GROUP, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
         if (g_conv_arith == 2)
             hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 2>), dim3(start), dim3(512), 0, s, grp);
         else if (g_conv_arith)

@@ -1947,7 +1947,7 @@ def prof_reset():
     check(lib().wsdl_prof_reset())
 
 
-PROF_NCLASSES = 21
+PROF_NCLASSES = 23
 
 
 def prof_class_name(cls):
