@@ -64,6 +64,9 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   group_tps10   20*  wsdl_conv2d_fwd_group: taps per K slice in tenths (20: a 9-tap problem in 4 slices, a 4-tap one in 2)
  *   group_interleave 1* ... with the workgroups of its (problem, slice) streams interleaved, one stream per XCD when there are 8
  *   ms_rowfast     1*  wsdl_conv2d_dgrad_multi: XCD-aware tile order taken row tile fastest;  ms_py 0* = 4 row groups (1 / 2 / 4 / 8)
+ *   bn_coop       64*  channel-resident BatchNorm kernels with 4 / 2 workgroups per channel for layers of up to this many channels
+ *                      (when the caller passes the `coop` counters): 64 channels at B=16, 64x64 forward 17.2 -> 13.8 us, backward
+ *                      21.7 -> 16.2 us; two per channel at 128 / 256 channels LOSE 1-9 us to the hand-over (bn_coop_wide 0*)
  *   range_sentinel 0*  1 = the amax arguments of wsdl_bn_train_fwd / _bwd are (max, ~min channel maximum) pairs (wsdl_range_check)
  *   bn_resident    1*  channel-resident fused BatchNorm kernels where a channel fits one workgroup's registers (0 off, 1 = from
  *                      64 channels, n > 1 = from n channels; measured: resident wins at every channel count of the networks)
@@ -270,7 +273,12 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                       float* y_amax /* optional: atomicMax of max|y| into a ZEROED device scalar */,
                       uint8_t* relu_mask /* optional (relu, HW % 8 == 0, y_bs % 4 == 0): B*C*HW/8 bytes, bit e%8 of byte
                                             e/8 = [y > 0] for the dense element index e - for relu = 3 of the backward */,
-                      void* ws, size_t ws_bytes, wsdl_stream_t stream);
+                      void* ws, size_t ws_bytes,
+                      int* coop /* optional: 2*C ZERO-INITIALISED ints that persist between calls, one region per stream.  Given
+                                   them, layers of few channels (option bn_coop, 64*) run several workgroups per channel, which
+                                   hand their partial sums over through the workspace (64 channels at B=16, 64x64: 17.2 -> 13.8 us;
+                                   profiles/r05_notes.md); the kernel leaves the counters zeroed.  NULL: one workgroup per channel */,
+                      wsdl_stream_t stream);
 /* Backward of the above.  relu = 1: the ReLU mask is read from the forward output y (needed when a residual was
  * added); relu = 2: the mask is recomputed from x - y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
  * expression - so y is neither read nor needs keeping (y may be NULL, beta is required); relu = 3: the mask is read from
@@ -284,7 +292,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       long long dy_bs, long long y_bs,
                       float* dx_amax /* optional: atomicMax of max|dx| into a ZEROED device scalar */,
                       const uint8_t* relu_mask /* relu = 3 */,
-                      void* ws, size_t ws_bytes, wsdl_stream_t stream);
+                      void* ws, size_t ws_bytes, int* coop /* as for the forward */, wsdl_stream_t stream);
 /* eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (fed to wsdl_conv2d_fwd). */
 int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift, int C,

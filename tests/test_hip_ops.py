@@ -1201,3 +1201,38 @@ def test_range_sentinel_flags_tensors_beyond_the_safe_range(dev):
     for t in (y, dx):
         assert abs(float(t._wsdl_amax) - t.abs().max().item()) <= 1e-6 * t.abs().max().item()
     ops.reset_amax_pool(dev)
+
+
+def test_batchnorm_with_several_workgroups_per_channel(dev):
+    """"bn_coop": the 64-channel layers' BatchNorm runs four workgroups per channel that hand their partial sums over and add
+    them in one order - the results equal the one-workgroup-per-channel kernels' (partial sums are doubles: to the last bit on
+    these shapes, asserted to 1e-6), are bitwise reproducible, leave their counters zeroed (a second launch works), and odd
+    geometries fall back."""
+    from weaklysuperviseddl_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    for B, C, H, res in ((16, 64, 64, False), (4, 64, 32, True), (3, 48, 20, False), (16, 32, 64, False)):
+        x = torch.randn(B, C, H, H, device=dev, generator=g)
+        dy = torch.randn(B, C, H, H, device=dev, generator=g)
+        r = torch.randn(B, C, H, H, device=dev, generator=g) if res else None
+        gamma, beta = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g) * 0.1
+        out = {}
+        for coop in (0, 64):
+            ops.set_option("bn_coop", coop)
+            try:
+                runs = []
+                for _ in range(2):
+                    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+                    y, mean, invstd, bits = ops.bn_train_fwd(x, gamma, beta, rm, rv, 0.1, 1e-5, r, True, want_mask=True, mask_if=res)
+                    dx, dgam, dbet, dres = ops.bn_train_bwd(x, dy, y if (res and bits is None) else None, gamma, mean, invstd, True, res,
+                                                            beta=None if res else beta, relu_mask=bits)
+                    runs.append([t.clone() for t in (y, mean, invstd, rm, rv, dx, dgam, dbet)] + ([dres.clone()] if res else []))
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(*runs))
+                out[coop] = runs[0]
+            finally:
+                ops.set_option("bn_coop", 64)
+        for a, b in zip(out[0], out[64]):
+            assert torch.isfinite(b).all()
+            assert ((a - b).abs().max() / (a.abs().max() + 1e-30)).item() < 1e-6
+    cnt = ops.coop_counters(dev)
+    assert cnt is not None and int(cnt.abs().sum()) == 0

@@ -47,8 +47,8 @@ SIGNATURES = {
     "wsdl_multi_amax": (_i, [_vp, _vp, _i, _vp, _vp]),
     "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),
     "wsdl_bn_workspace": (_sz, [_i]),
-    "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _vp, _vp, _sz, _vp]),
-    "wsdl_bn_train_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
+    "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "wsdl_bn_train_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
     "wsdl_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wsdl_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp, _vp]),

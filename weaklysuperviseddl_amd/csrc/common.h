@@ -59,6 +59,8 @@ struct ProfScope {
 extern int g_bn_resident;
 extern int g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
 extern int g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
+extern int g_bn_coop;             // "bn_coop": several workgroups per channel in the resident BatchNorm kernels up to this channel count (0 off)
+extern int g_bn_coop_wide;        // "bn_coop_wide": ... and two per channel at 256 channels
 extern int g_range_sentinel;      // "range_sentinel": the amax pointers of the BatchNorm entry points are (max, ~min piece max) PAIRS
 
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.

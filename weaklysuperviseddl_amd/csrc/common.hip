@@ -10,6 +10,7 @@ namespace wsdl {
 
 static thread_local char g_err[512] = "";
 int g_range_sentinel = 0;
+int g_bn_coop = 64, g_bn_coop_wide = 0;     // measured (tools/bn_bench.py): four workgroups per channel pay at 64 channels only
 
 void set_error(const char* fmt, ...) {
     va_list ap;

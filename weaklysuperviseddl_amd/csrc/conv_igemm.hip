@@ -1790,6 +1790,8 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ms_rowfast")) { g_ms_rowfast = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_rowfast")) { g_xcd_rowfast = value; return WSDL_OK; }
     if (!strcmp(name, "ms_py")) { g_ms_py = value; return WSDL_OK; }
+    if (!strcmp(name, "bn_coop")) { wsdl::g_bn_coop = value; return WSDL_OK; }
+    if (!strcmp(name, "bn_coop_wide")) { wsdl::g_bn_coop_wide = value; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
     if (!strcmp(name, "layercam_tail_mod")) {

@@ -291,18 +291,57 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 // the statistics, and applies the normalisation (forward) / the input gradient (backward) from registers - the
 // second pass over x (forward) and over x, dy and the ReLU mask (backward) of the two-kernel form never happens.
 // Same arithmetic: double sums, fixed reduction tree (bitwise reproducible).  grid = C.
+// Several workgroups per channel (round 5; "bn_coop").  A 64-channel layer is 64 workgroups on 256 CUs (16.8 us at 2.0 TB/s for a
+// tensor the chip moves in 7); with S workgroups per channel each holds 1/S of the channel in registers, publishes its partial
+// sums, and waits for its siblings': partials and the arrival counter are single coherent (agent-scope) accesses - no fence,
+// which would write a whole L2 back - and every workgroup adds the S partials in the SAME order (bitwise reproducible).
+// Siblings are neighbours in the grid, so they are dispatched together; the wait is bounded (a sibling that never arrives
+// poisons the channel with NaN after ~1 s instead of hanging the queue).  The last workgroup to leave re-arms the channel's
+// two counters for the stream's next launch (`cnt`: zero-initialised by the caller, 2 ints per channel, one region per stream).
+__device__ __forceinline__ void coop_exchange(double& a0, double& a1, unsigned long long* __restrict__ part, int* __restrict__ cnt,
+                                              int c, int s, int S) {
+    unsigned long long* mine = part + ((size_t)c * S + s) * 2;
+    __hip_atomic_store(mine, __builtin_bit_cast(unsigned long long, a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, __builtin_bit_cast(unsigned long long, a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials have landed before the arrival is counted
+    __hip_atomic_fetch_add(cnt + 2 * c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(cnt + 2 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S && spins < (1 << 21)) {
+        __builtin_amdgcn_s_sleep(16);
+        ++spins;
+    }
+    double t0 = 0.0, t1 = 0.0;
+    for (int j = 0; j < S; ++j) {
+        const unsigned long long* q = part + ((size_t)c * S + j) * 2;
+        t0 += __builtin_bit_cast(double, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        t1 += __builtin_bit_cast(double, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (spins >= (1 << 21)) t0 = t1 = __builtin_nan("");
+    a0 = t0;
+    a1 = t1;
+}
+__device__ __forceinline__ void coop_depart(int* __restrict__ cnt, int c, int S) {
+    if (__hip_atomic_fetch_add(cnt + 2 * c + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {
+        __hip_atomic_store(cnt + 2 * c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 2 * c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int NT, int V = 16>
 __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
-    long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask, float* __restrict__ cmin) {
+    long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask, float* __restrict__ cmin,
+    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt) {
     // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
     // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
+    // S > 1: workgroup blockIdx.x = c * S + s holds slice s of channel c (coop_exchange above); S = 1: the whole channel
     __shared__ double sm[16];
     __shared__ float bc[2];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
+    const int c = S > 1 ? blockIdx.x / S : blockIdx.x, sl = S > 1 ? blockIdx.x - c * S : 0, tid = threadIdx.x;
+    const int HW4 = HW >> 2, hw_sh = pow2_shift(HW4);
+    const int n4 = S > 1 ? B * HW4 / S : B * HW4, lo4 = sl * n4;      // this workgroup's float4s: [lo4, lo4 + n4)
     float4 v[V];
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
         const int i4 = tid + k * NT;
         v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i4 < n4) {
-            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
+            const int b = fast_div(lo4 + i4, HW4, hw_sh), r = (lo4 + i4 - b * HW4) << 2;
             v[k] = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
             a0 += (double)((v[k].x + v[k].y) + (v[k].z + v[k].w));
             a1 += (double)v[k].x * v[k].x + (double)v[k].y * v[k].y + (double)v[k].z * v[k].z + (double)v[k].w * v[k].w;
@@ -319,20 +358,24 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     a0 = block_sum_d(a0, sm);
     a1 = block_sum_d(a1, sm);
     if (tid == 0) {
+        if (S > 1) coop_exchange(a0, a1, part, cnt, c, sl, S);
         const long long n = (long long)B * HW;
         const double mean = a0 / (double)n;
         double var = a1 / (double)n - mean * mean;
         if (var < 0.0) var = 0.0;
         const float mu = (float)mean, istd = (float)(1.0 / sqrt(var + (double)eps));
-        save_mean[c] = mu;
-        save_invstd[c] = istd;
-        if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        if (rvar) {
-            const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        if (sl == 0) {
+            save_mean[c] = mu;
+            save_invstd[c] = istd;
+            if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            if (rvar) {
+                const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+                rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+            }
         }
         bc[0] = mu;
         bc[1] = istd;
+        if (S > 1) coop_depart(cnt, c, S);
     }
     __syncthreads();
     const float mu = bc[0], g = bc[1] * gamma[c], be = beta[c];
@@ -341,7 +384,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
         if (i4 < n4) {
-            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
+            const int b = fast_div(lo4 + i4, HW4, hw_sh), r = (lo4 + i4 - b * HW4) << 2;
             float4 o = v[k];
             o.x = fmaf(o.x - mu, g, be); o.y = fmaf(o.y - mu, g, be);
             o.z = fmaf(o.z - mu, g, be); o.w = fmaf(o.w - mu, g, be);
@@ -364,11 +407,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
-    float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask, float* __restrict__ cmin) {
+    float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask, float* __restrict__ cmin,
+    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt) {
     __shared__ double sm[16];
     __shared__ float bc[2];
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int HW4 = HW >> 2, n4 = B * HW4, hw_sh = pow2_shift(HW4);
+    const int c = S > 1 ? blockIdx.x / S : blockIdx.x, sl = S > 1 ? blockIdx.x - c * S : 0, tid = threadIdx.x;
+    const int HW4 = HW >> 2, hw_sh = pow2_shift(HW4);
+    const int n4 = S > 1 ? B * HW4 / S : B * HW4, lo4 = sl * n4;      // (S > 1: slice sl of the channel - see bn_fwd_resident_kernel)
     const float mu = mean[c], is = invstd[c];
     const float mg = is * gamma[c], mb = relu == 2 ? beta[c] : 0.f;          // relu == 2: mask recomputed from x
     float4 g[V], xh[V];                            // dy' = dy*[y>0] and xhat, kept for the second phase
@@ -379,7 +424,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
         g[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         xh[k] = g[k];
         if (i4 < n4) {
-            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
+            const int b = fast_div(lo4 + i4, HW4, hw_sh), r = (lo4 + i4 - b * HW4) << 2;
             const float4 xv = *reinterpret_cast<const float4*>(x + ((long long)b * C + c) * HW + r);
             float4 gv = *reinterpret_cast<const float4*>(dy + (long long)b * dy_bs + (long long)c * HW + r);
             if (relu == 2) {
@@ -405,11 +450,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     a0 = block_sum_d(a0, sm);
     a1 = block_sum_d(a1, sm);
     if (tid == 0) {
+        if (S > 1) coop_exchange(a0, a1, part, cnt, c, sl, S);
         const long long n = (long long)B * HW;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a1 : (float)a1;
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a0 : (float)a0;
+        if (sl == 0) {
+            if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a1 : (float)a1;
+            if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a0 : (float)a0;
+        }
         bc[0] = (float)(a0 / (double)n);
         bc[1] = (float)(a1 / (double)n);
+        if (S > 1) coop_depart(cnt, c, S);
     }
     __syncthreads();
     const float k0 = bc[0], k1 = bc[1], gi = gamma[c] * is;
@@ -418,7 +467,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     for (int k = 0; k < V; ++k) {
         const int i4 = tid + k * NT;
         if (i4 < n4) {
-            const int b = fast_div(i4, HW4, hw_sh), r = (i4 - b * HW4) << 2;
+            const int b = fast_div(lo4 + i4, HW4, hw_sh), r = (lo4 + i4 - b * HW4) << 2;
             const long long o = ((long long)b * C + c) * HW + r;
             float4 d;
             d.x = gi * (g[k].x - k0 - xh[k].x * k1);
@@ -449,6 +498,17 @@ static int resident_threads(int C, long long n, int HW, bool backward = false) {
     if (n <= 512 * 64) return 512;
     if (!backward && n <= 1024 * 64) return 1025;      // forward only: 1024 threads x 16 float4 (the 64 x 64 maps at B = 16)
     return 0;
+}
+
+// slices per channel of the cooperative form (1: not used): few-channel layers only, whole float4 slices that fit 1024 x 4
+static int coop_slices(int C, int B, int HW) {
+    if (!wsdl::g_bn_coop || C > wsdl::g_bn_coop || (HW & 3) != 0) return 1;
+    int S = 1;
+    while (C * S < 256 && S < 4) S *= 2;
+    if (S == 1 && wsdl::g_bn_coop_wide) S = 2;               // 256 channels: two workgroups each (512 of half the work)
+    const long long n4 = (long long)B * HW / 4;
+    while (S > 1 && (n4 % S != 0 || n4 / S > 1024 * 4)) S /= 2;
+    return S;
 }
 
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -719,7 +779,7 @@ size_t wsdl_bn_workspace(int C) {
 int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                       float* save_invstd, float* running_mean, float* running_var, float momentum,
                       float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
-                      float* y_amax, uint8_t* relu_mask, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                      float* y_amax, uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     WSDL_REQUIRE(!relu_mask || (relu && (HW & 7) == 0), "bn_train_fwd: the bit mask needs relu and HW %% 8 == 0");
     WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_fwd: bad shape");
@@ -732,23 +792,31 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     WSDL_REQUIRE(!relu_mask || (y_bs & 3) == 0, "bn_train_fwd: the bit mask needs a 16-byte aligned batch stride");
     hipStream_t s = wsdl::as_stream(stream);
     float* cmin = (wsdl::g_range_sentinel && y_amax) ? y_amax + 1 : nullptr;      // "range_sentinel": y_amax is a (max, ~min) pair
+    if (const int S = (coop && (y_bs & 3) == 0) ? coop_slices(C, B, HW) : 1; S > 1) {
+        // several workgroups per channel (coop_exchange): partial sums in the workspace, the channel's counters in `coop`
+        hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C * S), dim3(1024), 0, s, x, gamma, beta, save_mean,
+                           save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
+                           y_amax, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     if (const int nt = ((y_bs & 3) == 0) ? resident_threads(C, (long long)B * HW, HW) : 0) {
         if (nt == 1025)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 16>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         else if (nt == 1024)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         else
             hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -767,7 +835,7 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, float* dres, int B, int C, int HW, int relu,
                       int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax,
-                      const uint8_t* relu_mask, void* ws, size_t ws_bytes, wsdl_stream_t stream) {
+                      const uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
     WSDL_REQUIRE(relu != 1 || y, "bn_train_bwd: relu = 1 takes the mask from the forward output y");
     WSDL_REQUIRE(relu != 2 || beta, "bn_train_bwd: relu = 2 recomputes the mask from x and needs beta");
@@ -783,19 +851,26 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     float* cmin = (wsdl::g_range_sentinel && dx_amax) ? dx_amax + 1 : nullptr;
+    if (const int S = (coop && ((dy_bs | y_bs) & 3) == 0) ? coop_slices(C, B, HW) : 1; S > 1) {
+        hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C * S), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
+                           save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                           dx_amax, beta, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop);
+        WSDL_LAUNCH_CHECK();
+        return WSDL_OK;
+    }
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW, true) : 0) {
         if (nt == 1024)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }

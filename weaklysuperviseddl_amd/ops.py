@@ -354,6 +354,23 @@ def _ws_bytes(query, *geom):
     return n
 
 
+_coop_cache = {}
+BN_COOP = [os.environ.get("WSDL_BN_COOP", "1") != "0"]
+
+
+def coop_counters(device):
+    """The zero-initialised counters of the several-workgroups-per-channel BatchNorm kernels (include/wsdl_hip.h
+    wsdl_bn_train_fwd ``coop``): one region per (device, stream) - launches of one stream never overlap, and every launch
+    leaves its counters zeroed.  None switches the form off (WSDL_BN_COOP=0)."""
+    if not BN_COOP[0] or torch.cuda.is_current_stream_capturing() and (device, raw_stream(device)) not in _coop_cache:
+        return None
+    key = (device, raw_stream(device))
+    buf = _coop_cache.get(key)
+    if buf is None:
+        buf = _coop_cache[key] = torch.zeros(2 * 4096, dtype=torch.int32, device=device)
+    return buf
+
+
 def conv_out_hw(H, W, k, stride, pad, dil):
     return ((H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1)
 
@@ -852,7 +869,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
         mask = torch.empty(x.numel() // 8, device=x.device, dtype=torch.uint8)
     check(lib().wsdl_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(invstd), _p(running_mean),
                                   _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
-                                  int(relu), y_bs, _p(y_amax), _p(mask), _p(ws), ws.numel(), _stream()))
+                                  int(relu), y_bs, _p(y_amax), _p(mask), _p(ws), ws.numel(), _p(coop_counters(x.device)), _stream()))
     if y_amax is not None:
         _publish_amax(out, y_amax)
     return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
@@ -890,7 +907,8 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if mode == 1 else None), _p(gamma),
                                   _p(_dense(beta) if mode == 2 else None), _p(mean), _p(invstd), _p(dx),
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, mode, int(acc), dy_bs, y_bs,
-                                  _p(dx_amax), _p(relu_mask if mode == 3 else None), _p(ws), ws.numel(), _stream()))
+                                  _p(dx_amax), _p(relu_mask if mode == 3 else None), _p(ws), ws.numel(),
+                                  _p(coop_counters(x.device)), _stream()))
     if dx_amax is not None:
         _publish_amax(dx, dx_amax)
     dx._wsdl_fresh = True
