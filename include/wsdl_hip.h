@@ -64,7 +64,7 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   group_tps10   20*  wsdl_conv2d_fwd_group: taps per K slice in tenths (20: a 9-tap problem in 4 slices, a 4-tap one in 2)
  *   group_interleave 1* ... with the workgroups of its (problem, slice) streams interleaved, one stream per XCD when there are 8
  *   ms_rowfast     1*  wsdl_conv2d_dgrad_multi: XCD-aware tile order taken row tile fastest;  ms_py 0* = 4 row groups (1 / 2 / 4 / 8)
- *   bn_coop       64*  channel-resident BatchNorm kernels with 4 / 2 workgroups per channel for layers of up to this many channels
+ *   bn_coop        0*  (64 = on for the 64-channel layers) channel-resident BatchNorm kernels with 4 / 2 workgroups per channel for layers of up to this many channels
  *                      (when the caller passes the `coop` counters): 64 channels at B=16, 64x64 forward 17.2 -> 13.8 us, backward
  *                      21.7 -> 16.2 us; two per channel at 128 / 256 channels LOSE 1-9 us to the hand-over (bn_coop_wide 0*)
  *   range_sentinel 0*  1 = the amax arguments of wsdl_bn_train_fwd / _bwd are (max, ~min channel maximum) pairs (wsdl_range_check)
@@ -275,7 +275,7 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                                             e/8 = [y > 0] for the dense element index e - for relu = 3 of the backward */,
                       void* ws, size_t ws_bytes,
                       int* coop /* optional: 2*C ZERO-INITIALISED ints that persist between calls, one region per stream.  Given
-                                   them, layers of few channels (option bn_coop, 64*) run several workgroups per channel, which
+                                   them, layers of few channels (option bn_coop: 0* = off, 64) run several workgroups per channel, which
                                    hand their partial sums over through the workspace (64 channels at B=16, 64x64: 17.2 -> 13.8 us;
                                    profiles/r05_notes.md); the kernel leaves the counters zeroed.  NULL: one workgroup per channel */,
                       wsdl_stream_t stream);

@@ -51,4 +51,4 @@ for C, H in ((64, 64), (128, 32), (256, 32), (512, 32)):
     print(f"C={C:4d} {H}x{H}: fwd {a[7]:.1f} -> {b[7]:.1f} us, bwd {a[8]:.1f} -> {b[8]:.1f} us; max rel diff y {rel(b[0], a[0]):.1e} mean {rel(b[1], a[1]):.1e} "
           f"invstd {rel(b[2], a[2]):.1e} dx {rel(b[3], a[3]):.1e} dgamma {rel(b[4], a[4]):.1e} dbeta {rel(b[5], a[5]):.1e}; reproducible {a[6]} / {b[6]}; "
           f"finite {bool(torch.isfinite(b[0]).all() and torch.isfinite(b[3]).all())}")
-ops.set_option("bn_coop", 256)
+ops.set_option("bn_coop", 0)

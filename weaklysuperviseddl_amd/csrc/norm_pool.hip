@@ -301,9 +301,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
 __device__ __forceinline__ void coop_exchange(double& a0, double& a1, unsigned long long* __restrict__ part, int* __restrict__ cnt,
                                               int c, int s, int S) {
     unsigned long long* mine = part + ((size_t)c * S + s) * 2;
-    __hip_atomic_store(mine, __builtin_bit_cast(unsigned long long, a0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(mine + 1, __builtin_bit_cast(unsigned long long, a1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials have landed before the arrival is counted
+    // Exchanges, not stores: a returning read-modify-write is performed where every XCD sees it, and its RETURN is the proof
+    // that it has been (the acknowledgement of a plain store only says the local L2 took it) - the arrival is counted after both
+    const unsigned long long r0 = __hip_atomic_exchange(mine, __builtin_bit_cast(unsigned long long, a0), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long r1 = __hip_atomic_exchange(mine + 1, __builtin_bit_cast(unsigned long long, a1), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(r0), "v"(r1) : "memory");
     __hip_atomic_fetch_add(cnt + 2 * c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
     while (__hip_atomic_load(cnt + 2 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S && spins < (1 << 21)) {
@@ -322,8 +326,9 @@ __device__ __forceinline__ void coop_exchange(double& a0, double& a1, unsigned l
 }
 __device__ __forceinline__ void coop_depart(int* __restrict__ cnt, int c, int S) {
     if (__hip_atomic_fetch_add(cnt + 2 * c + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {
-        __hip_atomic_store(cnt + 2 * c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 2 * c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int z0 = __hip_atomic_exchange(cnt + 2 * c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int z1 = __hip_atomic_exchange(cnt + 2 * c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(z0), "v"(z1) : "memory");
     }
 }
 
