@@ -81,6 +81,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      0 = the LDS-staged kernel everywhere
  *   wgrad_dyraw    1*  the direct-fragment kernel reads dY as fp32 and splits it while staging (no dy_split16 pre-pass) for 1x1 convolutions
  *                      with at most 10 N tiles (7-11 % faster there); 2 = for every launch of that kernel (3x3: 7-21 % slower), 0 = never
+ *   wgrad_chan_scale 0* the range guard of the weight gradient (conv_arith = 2 is the forward / input gradient's): the fp16x2 weight-gradient
+ *                      kernels scale x and dY by one power of two per CHANNEL instead of per tensor - a channel is a row / a column
+ *                      of that GEMM's output (K = pixels), so the inverse scales go onto the result's rows and columns: exact, no
+ *                      second accumulator set.  A pre-pass takes the per-channel maxima (one more read of x and dY per layer)
  *   stem_kernel    1*  7x7 stride-2 convolution of 3 -> 64 channels (ResNet's conv1) on its own kernel: input patch and all weights
  *                      in LDS, fp32 MFMA (0: the generic fp32 implicit-GEMM kernel, the A/B partner)
  *   ksplit_target 512* / ksplit_max 8* / ksplit_min_chunks 4*  small grids (CAM path at B=8): workgroups aimed at by the K split,

@@ -15,12 +15,12 @@ for (Cin, Cout, k, s, d, H, B) in [(1024, 256, 1, 1, 1, 16, 4), (1024, 256, 1, 1
         if what in ("dy", "both"):
             dy[0, 5, 0, 0] = 2.0 ** 20
         ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), s, pad, d)
-        for opts in ({}, dict(wgrad_direct=0), dict(wgrad_dyraw=0), dict(conv_arith=0), dict(wgrad_split=0)):
+        for opts in ({}, dict(wgrad_chan_scale=1), dict(wgrad_direct=0), dict(wgrad_dyraw=0), dict(conv_arith=0), dict(wgrad_split=0)):
             for o, v in opts.items():
                 ops.set_option(o, v)
             dw = ops.conv2d_wgrad(x, dy, (Cout, Cin, k, k), s, pad, d)
             for o, v in opts.items():
-                ops.set_option(o, {"wgrad_direct": 1, "wgrad_dyraw": 1, "conv_arith": 1, "wgrad_split": 1}[o])
+                ops.set_option(o, {"wgrad_direct": 1, "wgrad_dyraw": 1, "conv_arith": 1, "wgrad_split": 1, "wgrad_chan_scale": 0}[o])
             e = (dw.double() - ref).abs()
             rel_el = (e / (ref.abs() + 1e-3)).max().item()
             row = (e.amax(dim=(1, 2, 3)) / ref.abs().amax(dim=(1, 2, 3)))

@@ -1657,6 +1657,7 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
 int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
 int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
 int g_wgrad_dyraw = 1;       // direct-fragment kernel: dY read as fp32 and split while staged (no dy_split16_kernel pass)
+int g_wgrad_chan_scale = 0;  // fp16x2 weight-gradient kernels: one power-of-two scale per CHANNEL of x and of dY (a pre-pass takes the maxima)
 int g_wgrad_direct = 1;      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
 // (fp16x2: the split weight-gradient kernels run on v_mfma_f32_16x16x32_f16; the 32x32x16 form - "wgrad_mfma16 = 0", 2 % slower on
 // the step - was an A/B option until round 4.  conv_wgrad_split32_kernel remains as the bf16x3 path.)
@@ -1771,6 +1772,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_direct")) { g_wgrad_direct = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_chan_scale")) { g_wgrad_chan_scale = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_dyraw")) { g_wgrad_dyraw = value; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
@@ -2150,6 +2152,17 @@ size_t wsdl_conv2d_igemm_workspace(int B, int Cin, int H, int W, int Cout, int k
 }
 
 // bytes of the pre-split dY image of the 32-pixel-chunk weight-gradient kernel (0: kernel not used)
+// max |t| of every channel of t[B][C][HW] (batch stride bs) -> out[C] (zeroed by the caller); workgroup (c, image group)
+__global__ void channel_amax_kernel(const float* __restrict__ t, int B, int C, int HW, long long bs, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    float m = 0.f;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float* src = t + (long long)b * bs + (long long)c * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) m = fmaxf(m, fabsf(src[i]));
+    }
+    publish_amax(m, out + c);
+}
+
 static size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
     if (!wgrad_chunk32(Cout, Cin, N)) return 0;
     const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * w2row_bytes(g_conv_arith);
@@ -2179,7 +2192,8 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
     const int n_live = __builtin_popcountll(live_taps(H, W, OH, OW, kh, kw, stride, pad, dil)) * Cin;
     const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live) * Cout * N * sizeof(float);
-    return wsdl::align_up(slabs, 256) + wgrad_dys_bytes(Cout, Cin, N, B * OH * OW);
+    return wsdl::align_up(slabs, 256) + wsdl::align_up(wgrad_dys_bytes(Cout, Cin, N, B * OH * OW), 256) +
+           (g_wgrad_chan_scale ? wsdl::align_up((size_t)(Cin + Cout) * sizeof(float), 256) : 0);
 }
 
 int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
@@ -2299,6 +2313,24 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 dim3 grid(p.N / 128, Cout / 128, S);
                 p.xcd_order = ((long long)grid.x * grid.y * grid.z) % 8 == 0 ? g_wgrad_xcd : 0;
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
+                // the range guard of the weight gradient: a scale per channel (maxima taken here, one read of x and of dY)
+                const size_t cm_off = wsdl::align_up(dys_off + dys_bytes, 256);
+                const bool cs = g_wgrad_chan_scale && g_conv_arith &&
+                                ws_bytes >= cm_off + (size_t)(Cin + Cout) * sizeof(float);
+                int dy_stride = 0;
+                if (cs) {
+                    float* cm = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + cm_off);
+                    WSDL_HIP_CHECK(hipMemsetAsync(cm, 0, (size_t)(Cin + Cout) * sizeof(float), s));
+                    hipLaunchKernelGGL(channel_amax_kernel, dim3(Cin, std::min(B, std::max(1, 1024 / Cin))), dim3(256), 0, s, x, B, Cin,
+                                       H * W, p.x_bs, cm);
+                    WSDL_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(channel_amax_kernel, dim3(Cout, std::min(B, std::max(1, 1024 / Cout))), dim3(256), 0, s, dy, B,
+                                       Cout, OH * OW, p.dy_bs, cm + Cin);
+                    WSDL_LAUNCH_CHECK();
+                    p.x_amax = x_amax = cm;
+                    dy_amax = cm + Cin;
+                    dy_stride = 1;
+                }
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
                     // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
@@ -2315,20 +2347,32 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                                            (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
                                            reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
                         if (!dyraw) {
-                            hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                            hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
+                                               dy_stride);
                             WSDL_LAUNCH_CHECK();
                         }
-                        if (dyraw)
+                        if (dyraw && cs)
+                            hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else if (dyraw)
                             hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else if (cs)
+                            hipLaunchKernelGGL((conv_wgrad_split16d_kernel<0, false, true>), grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
                         else
                             hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
                     } else {
-                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax);
+                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
+                                           dy_stride);
                         WSDL_LAUNCH_CHECK();
-                        hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
-                                           (unsigned)dys_bytes, dy_amax);
+                        if (cs)
+                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128, true>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
+                        else
+                            hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128>), grid, dim3(kThreads), 0, s, p, dys,
+                                               (unsigned)dys_bytes, dy_amax);
                     }
                 } else {
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,

@@ -1051,14 +1051,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split32_kernel(WgradP 
 constexpr int kW16Row = 128;
 
 __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* __restrict__ out, int B, int Cout,
-                                  int OHOW, long long dy_bs, int P, const float* __restrict__ amax) {
-    int ex;
-    const float sc = pow2_scale(*amax, ex);
+                                  int OHOW, long long dy_bs, int P, const float* __restrict__ amax, int amax_stride) {
+    // amax_stride 0: one scale for the tensor; 1: amax[c] per channel (wsdl_set_option "wgrad_chan_scale")
     const int groups = 2 * ((P + 31) / 32);
     const long long total = (long long)groups * Cout;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         const int g = (int)(idx % groups), c = (int)(idx / groups);
+        int ex;
+        const float sc = pow2_scale(amax[c * amax_stride], ex);
         float v[16];
         const int p0 = g * 16;
         if (p0 >= P) {
@@ -1100,7 +1101,10 @@ __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* _
     }
 }
 
-template <int BM, int BN>
+// CS ("wgrad_chan_scale", the range guard of the weight gradient): p.x_amax / dy_amax are ARRAYS, one maximum per input / per
+// output channel.  A channel is a row or a column of this GEMM's OUTPUT (K = pixels), so a scale of its own per channel is
+// a power of two on the operand's rows and the inverse on the result's rows / columns: exact, and no second accumulator set.
+template <int BM, int BN, bool CS = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                         unsigned dys_bytes, const float* __restrict__ dy_amax) {
     static_assert(BM == 128 && BN == 128, "tile");
@@ -1137,14 +1141,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(dys), 0, (int)dys_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    int ex, ed;
-    const float xs = pow2_scale(*p.x_amax, ex);
-    (void)pow2_scale(*dy_amax, ed);
+    int ex = 0, ed = 0;
+    float xs = 1.f;
+    if constexpr (!CS) {
+        xs = pow2_scale(*p.x_amax, ex);
+        (void)pow2_scale(*dy_amax, ed);
+    }
     const float out_scale = pow2(-(ex + ed));
 
     const int tap0 = n0 / p.Cin, ci0 = n0 - tap0 * p.Cin;
     const int t_dh = (tap0 / p.KW) * p.dil - p.pad, t_dw = (tap0 % p.KW) * p.dil - p.pad;
     const unsigned b_row = (unsigned)((ci0 + 2 * hw) * HW);
+    // CS: the scales of the tile's 128 rows of x in LDS (eight registers per thread for them spilled)
+    __shared__ float xst[CS ? BN : 1];
+    if constexpr (CS) {
+        if (tid < BN) {
+            int e_;
+            xst[tid] = pow2_scale(p.x_amax[ci0 + tid], e_);
+        }
+        __syncthreads();
+    }
+    const float* xsr = xst + 2 * hw + (px & 1);
 
     unsigned voff_a[A_U];
 #pragma unroll
@@ -1222,7 +1239,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
             ph = x0;
             pl = x1;
 #else
-            split2h(__builtin_bit_cast(float, x0) * xs, __builtin_bit_cast(float, x1) * xs, ph, pl);
+            const float xsc = CS ? xsr[CS ? 16 * i : 0] : xs;
+            split2h(__builtin_bit_cast(float, x0) * xsc, __builtin_bit_cast(float, x1) * xsc, ph, pl);
 #endif
             unsigned char* d = Bs + st_row + i * 16 * ROW;
             *reinterpret_cast<unsigned*>(d + st_u0) = ph;
@@ -1296,6 +1314,23 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     }
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
+    if constexpr (CS) {
+        int en[TNI];
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) (void)pow2_scale(p.x_amax[ci0 + wn * (BN / 2) + j * 16 + l15], en[j]);
+#pragma unroll
+        for (int i = 0; i < TMI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
+                int edr;
+                (void)pow2_scale(dy_amax[co], edr);
+#pragma unroll
+                for (int j = 0; j < TNI; ++j)
+                    slab[(long long)co * p.N + n0 + wn * (BN / 2) + j * 16 + l15] = acc[i][j][r] * pow2(-(en[j] + edr));
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TMI; ++i)
 #pragma unroll
@@ -1326,7 +1361,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
 // DYRAW: dY is read as fp32 from the tensor itself (p.dy) and split by the staging threads on its way into LDS - no
 // dy_split16_kernel pre-pass for the launch (it re-reads and re-writes dY once per layer; here every N tile's workgroup
 // splits its 128 x 32 slice again: 8 splits per thread and chunk).
-template <int MODE, bool DYRAW = false>
+// CS: per-channel scales, as in conv_wgrad_split16_kernel.
+template <int MODE, bool DYRAW = false, bool CS = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP p, const unsigned char* __restrict__ dys,
                                                                          unsigned dys_bytes, const float* __restrict__ dy_amax) {
     constexpr int BM = 128, BN = 128, BK = 32, ROW = kW16Row;
@@ -1352,9 +1388,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(dys), 0, (int)dys_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    int ex, ed;
-    const float xs = pow2_scale(*p.x_amax, ex);
-    const float ds = pow2_scale(*dy_amax, ed);
+    int ex = 0, ed = 0;
+    float xs = 1.f, ds = 1.f;
+    if constexpr (!CS) {
+        xs = pow2_scale(*p.x_amax, ex);
+        ds = pow2_scale(*dy_amax, ed);
+    }
     const float out_scale = pow2(-(ex + ed));
     // DYRAW: eight lanes per row of dY (16 bytes = 4 pixels each), rows t / 8 + 32 e: full 128-byte lines per load instruction
     const __amdgpu_buffer_rsrc_t rdr =
@@ -1370,6 +1409,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
     unsigned vrow[TNI];
 #pragma unroll
     for (int j = 0; j < TNI; ++j) vrow[j] = (unsigned)((ci0 + wid * 32 + j * 16 + l15) * HW + lg * 8);
+    float xsr[CS ? TNI : 1], dsr[CS && DYRAW ? A_U : 1];       // CS: the scales of this lane's rows of x / of the rows of dY it stages
+    int exr[CS ? TNI : 1];
+    if constexpr (CS) {
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) xsr[j] = pow2_scale(p.x_amax[ci0 + wid * 32 + j * 16 + l15], exr[j]);
+        if constexpr (DYRAW) {
+#pragma unroll
+            for (int e = 0; e < A_U; ++e) {
+                int e_;
+                dsr[e] = pow2_scale(dy_amax[m0 + dr_row + 32 * e], e_);
+            }
+        }
+    }
 
     unsigned voff_a[A_U];
 #pragma unroll
@@ -1448,8 +1500,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
                     const int r = dr_row + 32 * e;
                     const unsigned u0 = ra[S][e][0], u1 = ra[S][e][1], u2 = ra[S][e][2], u3 = ra[S][e][3];
                     unsigned h0, l0, h1, l1;
-                    split2h(__builtin_bit_cast(float, u0) * ds, __builtin_bit_cast(float, u1) * ds, h0, l0);
-                    split2h(__builtin_bit_cast(float, u2) * ds, __builtin_bit_cast(float, u3) * ds, h1, l1);
+                    const float dsc = CS ? dsr[CS ? e : 0] : ds;
+                    split2h(__builtin_bit_cast(float, u0) * dsc, __builtin_bit_cast(float, u1) * dsc, h0, l0);
+                    split2h(__builtin_bit_cast(float, u2) * dsc, __builtin_bit_cast(float, u3) * dsc, h1, l1);
                     const unsigned sw = (unsigned)((r >> 1) & 7);
                     unsigned char* row = As[buf] + r * ROW + (dr_q & 1) * 8;
                     *reinterpret_cast<u32x2*>(row + ((((unsigned)(dr_q >> 1)) ^ sw) << 4)) = u32x2{h0, h1};
@@ -1497,10 +1550,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
                         v[e] = __builtin_bit_cast(float, u);
                     }
                     u32x4 ph, pl;
+                    const float xsc = CS ? xsr[CS ? j : 0] : xs;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x0 = (2 * e >= lo && 2 * e < hi) ? v[2 * e] * xs : 0.f;
-                        const float x1 = (2 * e + 1 >= lo && 2 * e + 1 < hi) ? v[2 * e + 1] * xs : 0.f;
+                        const float x0 = (2 * e >= lo && 2 * e < hi) ? v[2 * e] * xsc : 0.f;
+                        const float x1 = (2 * e + 1 >= lo && 2 * e + 1 < hi) ? v[2 * e + 1] * xsc : 0.f;
                         unsigned h, l;
                         split2h(x0, x1, h, l);
                         ph[e] = h;
@@ -1551,6 +1605,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
     run(std::integral_constant<int, 0>{});
 
     float* slab = p.slab + (long long)(p.slab0 + bz) * p.Cout * p.N;
+    if constexpr (CS) {
+#pragma unroll
+        for (int i = 0; i < TMI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = m0 + i * 16 + lg * 4 + r;
+                int edr;
+                (void)pow2_scale(dy_amax[co], edr);
+#pragma unroll
+                for (int j = 0; j < TNI; ++j)
+                    slab[(long long)co * p.N + n0 + wid * 32 + j * 16 + l15] = acc[i][j][r] * pow2(-(exr[j] + edr));
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TMI; ++i)
 #pragma unroll

@@ -278,7 +278,8 @@ class FlatAdam:
                 warnings.warn(f"weaklysuperviseddl_amd: {st['pairs_over_limit']} activation / gradient tensors of the last step span "
                               f"more than 2^{st['limit_log2']} between their largest and their smallest region (worst 2^{st['worst_log2']:.0f}):"
                               " the default convolution arithmetic (fp16x2, one scale per tensor) computes the small regions to "
-                              "fewer than 13 bits there - select the range guard: ops.set_option('conv_arith', 2)")
+                              "fewer than 13 bits there - select the range guards: ops.set_option('conv_arith', 2) (forward / input "
+                              "gradient) and ops.set_option('wgrad_chan_scale', 1) (weight gradient)")
             ops.range_check(self.flat_param.device)
         if self.post_step_hook is not None:
             self.post_step_hook()
