@@ -406,6 +406,17 @@ int wsdl_layercam_epilogue(const float* const* act, const float* const* grad, co
                            float alpha, int variant, float* cam, float thresh, uint8_t* mask,
                            void* ws, size_t ws_bytes, wsdl_stream_t stream);
 
+/* The class-logit head of the LayerCAM pass in one call (TraditionalModel/LayerCAM.py:41-48 - `logits, _ = model(images)`,
+ * `class_idx = argmax(logits)` when none is given, `logits.gather(1, class_idx).backward(ones)` - through
+ * ClassificationModel.py:35-37, `fc(avgpool(f4).view(B, -1))`): pooled (B,C) = wsdl_global_avgpool_fwd of layer4's output,
+ * weight (K,C), bias (K) or NULL, class_idx (B) int64 or NULL -> logits (B,K), cls (B) int32 (the class each image was
+ * differentiated for; -1 and a NaN gradient for an index outside [0,K)), dx (B,C,HW) = weight[cls[b]][c] / HW: the gradient of
+ * the chosen logit with respect to layer4's output (fc's backward followed by the average pool's, exactly: both are linear).
+ * The parameters' own gradients (fc.weight.grad, fc.bias.grad - a side effect of the reference's backward nothing reads)
+ * are not formed. */
+int wsdl_class_logit_head(const float* pooled, const float* weight, const float* bias, const long long* class_idx,
+                          float* logits, int* cls, float* dx, int B, int C, int K, int HW, wsdl_stream_t stream);
+
 /* keep_largest (TraditionalModel/PsuedoMasks.py:15-21: skimage label + regionprops, the largest area wins, the first
  * label on ties, an empty mask stays empty) for n masks (n,h,w) of uint8 (non-zero = foreground) -> out (n,h,w) in {0,1};
  * 8-connectivity, labels in raster order of a component's first pixel as skimage numbers them.  One workgroup per mask,

@@ -143,6 +143,50 @@ def test_layercam_end_to_end(dev, cam_models, variant):
     assert close_mod_relu_flips(gen_h.gradients["layer3"], gen_r.gradients["layer3"], what=f"layercam {variant} layer3 grad")
 
 
+def test_class_logit_head_equals_the_autograd_tail(dev, cam_models):
+    """ops.class_logit_head (wsdl_class_logit_head: LayerCAM.py:41-48 through ClassificationModel.py:35-37 as one call) against
+    torch: logits = fc(mean(h)), the class per image (given, or the first arg-max), and d logit[class] / d h = W[class] / HW -
+    exactly the quotient autograd's mean backward forms.  Then the generator: the fused head against fc and the pool as autograd
+    nodes (fc_param_grads=True: the same seed to the 22 bits of the fp16x2 fc input gradient) - and fc's parameters get no
+    gradient from the fused head."""
+    from weaklysuperviseddl_amd import ops
+    from weaklysuperviseddl_amd.TraditionalModel import LayerCAMGenerator
+    g = torch.Generator().manual_seed(19)
+    for (B, C, H, W, K) in [(3, 2048, 14, 14, 37), (2, 96, 7, 7, 5), (5, 256, 3, 5, 130)]:
+        h = torch.randn(B, C, H, W, generator=g)
+        w = torch.randn(K, C, generator=g) / C ** 0.5
+        b = torch.randn(K, generator=g)
+        want = h.double().mean(dim=(2, 3)) @ w.double().t() + b.double()
+        for cls in (None, torch.randint(0, K, (B,), generator=g)):
+            logits, got_cls, dh = ops.class_logit_head(h.to(dev), w.to(dev), b.to(dev), None if cls is None else cls.to(dev))
+            assert rel_err(logits, want) < 1e-5
+            pick = logits.cpu().argmax(dim=1) if cls is None else cls
+            assert torch.equal(got_cls.cpu().long(), pick)
+            seed = (w[pick] / float(H * W))[:, :, None, None].expand(B, C, H, W)
+            assert torch.equal(dh.cpu(), seed), (B, C, H, W, K)
+        bad = torch.full((B,), K, dtype=torch.long)
+        _, c_bad, dh_bad = ops.class_logit_head(h.to(dev), w.to(dev), None, bad.to(dev))
+        assert (c_bad.cpu() == -1).all() and torch.isnan(dh_bad).all()
+    _ref, mine = cam_models
+    imgs = torch.rand(3, 3, 224, 224, generator=g).to(dev)
+    cls = torch.tensor([3, 17, 30], device=dev)
+    mine.zero_grad(set_to_none=True)
+    gen_f = LayerCAMGenerator(mine, ["layer3", "layer4"], auto_graph=False)
+    cam_f, mask_f = gen_f.generate_batch(imgs, 1.0, cls, thresh=0.3)
+    assert mine.fc.weight.grad is None and mine.fc.bias.grad is None
+    g4 = gen_f.gradients["layer4"]
+    # (the quotient on the CPU: torch's GPU division by a scalar multiplies by the reciprocal)
+    assert torch.equal(g4.cpu(), (mine.fc.weight.detach().cpu()[cls.cpu()] / 196.0)[:, :, None, None].expand(3, 2048, 14, 14))
+    gen_a = LayerCAMGenerator(mine, ["layer3", "layer4"], auto_graph=False, fc_param_grads=True)
+    cam_a, mask_a = gen_a.generate_batch(imgs, 1.0, cls, thresh=0.3)
+    assert mine.fc.weight.grad is not None
+    mine.zero_grad(set_to_none=True)
+    assert rel_err(gen_a.gradients["layer4"], g4) < 2e-6
+    assert rel_err(cam_a, cam_f) < 1e-4 and (mask_a != mask_f).float().mean().item() < 1e-4
+    # default class (arg-max) through both
+    assert rel_err(gen_a.generate_batch(imgs), gen_f.generate_batch(imgs)) < 1e-4
+
+
 def test_generate_pseudo_masks_in_memory(dev, cam_models, tmp_path):
     import oracle
     from weaklysuperviseddl_amd.TraditionalModel import LayerCAMGenerator, generate_pseudo_masks, keep_largest

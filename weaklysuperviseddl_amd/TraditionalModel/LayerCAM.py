@@ -32,8 +32,12 @@ _ORDER = ["layer0", "layer1", "layer2", "layer3", "layer4"]
 
 class LayerCAMGenerator:
     def __init__(self, model, target_layer_names=("layer3", "layer4"), variant="modular", out_hw=(224, 224),
-                 staged=None, auto_graph=True):
+                 staged=None, auto_graph=True, fc_param_grads=False):
         self.model = model.eval()
+        # staged path: False = the class-logit head as ONE library call (ops.class_logit_head: logits, class choice and the
+        # gradient seed W[class] / HW) - fc.weight.grad / fc.bias.grad, which the reference's backward accumulates as a side
+        # effect and nothing reads, are not formed; True = fc and the pool as autograd nodes, parameter gradients included
+        self.fc_param_grads = bool(fc_param_grads) or os.environ.get("WSDL_CAM_FUSED_HEAD", "1") == "0"
         # staged path only: a repeated call (same shapes, same model state) replays a hipGraph of the batch (_lane_batch)
         self.auto_graph = bool(auto_graph) and os.environ.get("WSDL_CAM_GRAPH", "1") != "0" and \
             os.environ.get("WSDL_CAM_SELF_GRAPH", "1") != "0"
@@ -89,11 +93,17 @@ class LayerCAMGenerator:
                 if name in self.target_layer_names:
                     h.retain_grad()
                 feats[name] = h
-            logits = m.fc(m.avgpool(h).flatten(1))
-            if class_idx is None:
-                class_idx = logits.argmax(dim=1)
-            score = logits.gather(1, class_idx.view(-1, 1)).squeeze()
-            score.backward(torch.ones_like(score))
+            if self.fc_param_grads or not h.is_cuda:
+                logits = m.fc(m.avgpool(h).flatten(1))
+                if class_idx is None:
+                    class_idx = logits.argmax(dim=1)
+                score = logits.gather(1, class_idx.view(-1, 1)).squeeze()
+                score.backward(torch.ones_like(score))
+            else:
+                # ~20 launches of the tail (pool, fc on the matrix cores, gather, scatter, fc's weight / bias / input gradients,
+                # the pool's backward) as three: 160 -> ~25 us of a 2.6 ms batch of 8
+                logits, _cls, dh = ops.class_logit_head(h.detach(), m.fc.weight.detach(), m.fc.bias.detach(), class_idx)
+                h.backward(dh)
         for n in self.target_layer_names:
             self.activations[n] = feats[n]
             self.gradients[n] = feats[n].grad
@@ -231,7 +241,7 @@ class LayerCAMGenerator:
         while len(lanes) < n:
             lanes.append({"stream": ops.lane_stream(dev, len(lanes)), "graph": None, "key": None,
                           "gen": LayerCAMGenerator(self.model, self.target_layer_names, self.variant, self.out_hw, self.staged,
-                                                   auto_graph=False)})
+                                                   auto_graph=False, fc_param_grads=self.fc_param_grads)})
         return lanes
 
     @staticmethod

@@ -56,6 +56,7 @@ SIGNATURES = {
     "wsdl_maxpool3x3s2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "wsdl_global_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _vp]),
     "wsdl_global_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "wsdl_class_logit_head": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wsdl_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
     "wsdl_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _vp]),
     "wsdl_dropout_fwd": (_i, [_vp, _vp, _vp, _sz, _f, _u64, _i, _vp, _vp]),

@@ -361,9 +361,74 @@ int fill_layers(CamLayers& L, const float* const* act, const float* const* grad,
     return WSDL_OK;
 }
 
+
+// ---- the class-logit head of the LayerCAM pass (wsdl_class_logit_head) ------------------------------------------------
+// logits[b][k] = bias[k] + sum_c pooled[b][c] W[k][c];  cls[b] = class_idx ? class_idx[b] : argmax_k (the first maximum, as
+// torch.argmax).  One workgroup per image, a wave per class in turn, lanes strided over the channels.
+__global__ void class_logits_kernel(const float* __restrict__ pooled, const float* __restrict__ W, const float* __restrict__ bias,
+                                    const long long* __restrict__ class_idx, float* __restrict__ logits, int* __restrict__ cls,
+                                    int C, int K) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const float* pb = pooled + (long long)b * C;
+    for (int k = wid; k < K; k += nw) {
+        const float* wk = W + (long long)k * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(pb[c], wk[c], s);
+        s = wave_sum(s);
+        if (lane == 0) logits[(long long)b * K + k] = s + (bias ? bias[k] : 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        if (class_idx) {
+            const long long want = class_idx[b];
+            best = (want >= 0 && want < K) ? (int)want : -1;       // out of range: the seed kernel writes NaN (torch's gather raises)
+        } else {
+            float m = logits[(long long)b * K];
+            for (int k = 1; k < K; ++k) {
+                const float v = logits[(long long)b * K + k];
+                if (v > m) { m = v; best = k; }
+            }
+        }
+        cls[b] = best;
+    }
+}
+
+// d logits[b][cls[b]] / d x[b][c][i] through fc and the global average pool: W[cls[b]][c] / HW for every pixel i
+__global__ void class_grad_seed_kernel(const float* __restrict__ W, const int* __restrict__ cls, float* __restrict__ dx, int C,
+                                       int HW, int planes) {
+    for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+        const int b = plane / C, c = plane - b * C;
+        const int k = cls[b];
+        const float g = k >= 0 ? W[(long long)k * C + c] / (float)HW : __builtin_nanf("");
+        float* dp = dx + (long long)plane * HW;
+        if ((HW & 3) == 0) {
+            float4* dp4 = reinterpret_cast<float4*>(dp);
+            for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (HW >> 2); i += gridDim.x * blockDim.x)
+                dp4[i] = make_float4(g, g, g, g);
+            continue;
+        }
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) dp[i] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int wsdl_class_logit_head(const float* pooled, const float* weight, const float* bias, const long long* class_idx,
+                          float* logits, int* cls, float* dx, int B, int C, int K, int HW, wsdl_stream_t stream) {
+    WSDL_REQUIRE(pooled && weight && logits && cls && dx && B > 0 && C > 0 && K > 0 && HW > 0, "class_logit_head: bad arguments");
+    hipStream_t s = wsdl::as_stream(stream);
+    hipLaunchKernelGGL(class_logits_kernel, dim3(B), dim3(256), 0, s, pooled, weight, bias, class_idx, logits, cls, C, K);
+    WSDL_LAUNCH_CHECK();
+    const long long planes = (long long)B * C;
+    const int per = wsdl::cdiv(HW, 4 * 256);
+    hipLaunchKernelGGL(class_grad_seed_kernel, dim3(per, (unsigned)std::min<long long>(planes, 32768)), dim3(256), 0, s, weight, cls,
+                       dx, C, HW, (int)planes);
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
 
 size_t wsdl_layercam_workspace(int n_layers, int B, const int* C, const int* h, const int* w) {
     CamLayers L;

@@ -1635,6 +1635,30 @@ def global_avg_pool(x):
     return _GlobalAvgPool.apply(x)
 
 
+def class_logit_head(h, weight, bias=None, class_idx=None):
+    """LayerCAM's class-logit head on layer4's output h (B,C,H,W): logits = fc(avgpool(h)), the class per image (class_idx or the
+    arg-max) and d logit[class] / d h = weight[class] / HW per pixel - wsdl_class_logit_head; fc's own parameter gradients are
+    not formed.  Returns (logits (B,K), cls (B,) int32, dh like h)."""
+    h = _dense(h, "h")
+    B, Cc, H, W = h.shape
+    K = weight.shape[0]
+    if tuple(weight.shape) != (K, Cc) or not weight.is_contiguous() or weight.dtype != torch.float32:
+        raise WsdlError("class_logit_head: weight must be a contiguous float32 (classes, channels) tensor")
+    pooled = torch.empty(B, Cc, device=h.device, dtype=torch.float32)
+    check(lib().wsdl_global_avgpool_fwd(_p(h), _p(pooled), B * Cc, H * W, _stream()))
+    logits = torch.empty(B, K, device=h.device, dtype=torch.float32)
+    cls = torch.empty(B, device=h.device, dtype=torch.int32)
+    dh = torch.empty_like(h)
+    if class_idx is not None:
+        class_idx = class_idx.to(device=h.device, dtype=torch.int64).contiguous().view(-1)
+        if class_idx.numel() != B:
+            raise WsdlError("class_logit_head: one class index per image")
+    check(lib().wsdl_class_logit_head(_p(pooled), _p(weight), _p(bias) if bias is not None else None,
+                                      _p(class_idx) if class_idx is not None else None, _p(logits), _p(cls), _p(dh), B, Cc, K, H * W,
+                                      _stream()))
+    return logits, cls, dh
+
+
 def bilinear_resize(x, size):
     return _Bilinear.apply(x, int(size[0]), int(size[1]))
 
