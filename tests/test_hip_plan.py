@@ -318,3 +318,50 @@ def test_a_learning_rate_schedule_does_not_invalidate_the_plan(dev):
     # and the schedule really acted: a run at constant lr ends elsewhere
     m2, o2, _l, _s = _run(dev, False, 8, batches, seed=3)
     assert not torch.equal(o2.flat_param, o0.flat_param)
+
+
+@pytest.mark.parametrize("mode", ["warn", "auto"])
+def test_range_sentinel_speaks_under_replay_and_can_switch_the_guards_on(dev, mode):
+    """The sentinel's host side runs after every REPLAYED step too (the check kernel is part of the plan, FlatAdam.range_poll
+    reads what it wrote): a BatchNorm whose gamma falls by 2^44 across its channels is reported while the step replays.
+    WSDL_RANGE_GUARD=auto then switches both guards on (conv_arith = 2, wgrad_chan_scale = 1): the plan re-records under
+    the new options by itself, replays again, and the loss stays finite."""
+    import warnings
+    from weaklysuperviseddl_amd import ops, optim
+    from weaklysuperviseddl_amd.TraditionalModel import train_step
+    old_mode = optim.RANGE_GUARD[0]
+    optim.RANGE_GUARD[0] = mode
+    try:
+        model, opt = _model_and_opt(dev, 3)
+        bn = model.backbone.layer2[0].bn1
+        img, m = _batch(4, 64, dev, 11)
+        torch.manual_seed(5)
+        seen, losses = [], []
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for i in range(14):
+                if i == 6:          # the step is being replayed by now: the range leaves the safe span between two replays
+                    st = next(iter(opt.__dict__["_wsdl_planned"].values()))
+                    assert st.records == 1 and st.replays >= 2 and seen[-1] == 0, (st.records, st.replays, seen)
+                    with torch.no_grad():
+                        # (2^-44: every eighth channel is a candidate for the smallest maximum, and channels whose beta is negative
+                        # are dead behind the ReLU - the live candidates still span well over 2^25)
+                        bn.weight.mul_(torch.tensor([2.0 ** (-44.0 * c / (bn.num_features - 1)) for c in range(bn.num_features)],
+                                                    device=dev))
+                losses.append(float(train_step(model, opt, img, m)))
+                seen.append(len([w for w in caught if "range guards" in str(w.message)]))
+        torch.cuda.synchronize()
+        st = next(iter(opt.__dict__["_wsdl_planned"].values()))
+        assert seen[-1] == 1, seen                          # one warning, and it came
+        assert all(l == l and abs(l) < 1e4 for l in losses), losses
+        if mode == "warn":
+            assert st.records == 1 and st.replays >= 10 and not optim.RANGE_GUARD_ACTIVE[0], (st.records, st.replays)
+            assert seen[6] == 0 and seen[8] == 1, seen       # one step late: the check of replay 7 is read after replay 8
+        else:
+            # fired during the replays, re-recorded once under the guards, replayed again
+            assert optim.RANGE_GUARD_ACTIVE[0] and st.records == 2 and st.replays >= 6, (st.records, st.replays, seen)
+    finally:
+        optim.RANGE_GUARD[0] = old_mode
+        optim.RANGE_GUARD_ACTIVE[0] = False
+        ops.set_option("conv_arith", 1)
+        ops.set_option("wgrad_chan_scale", 0)

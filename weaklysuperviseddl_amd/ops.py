@@ -452,9 +452,9 @@ def range_status(device):
     out = _range_out.get(_norm_device(device))
     if out is None:
         return {"worst_log2": 0.0, "pairs_over_limit": 0, "pairs_seen": 0, "exceeded": False, "limit_log2": RANGE_LIMIT_LOG2}
-    worst = float(out[:, 0].max())
-    over = int(out[:, 1].sum())
-    return {"worst_log2": worst, "pairs_over_limit": over, "pairs_seen": int(out[:, 2].sum()), "exceeded": over > 0,
+    a = out.numpy()                      # a view of the pinned buffer (polled after every replayed step: a few microseconds)
+    over = int(a[:, 1].sum())
+    return {"worst_log2": float(a[:, 0].max()), "pairs_over_limit": over, "pairs_seen": int(a[:, 2].sum()), "exceeded": over > 0,
             "limit_log2": RANGE_LIMIT_LOG2}
 
 

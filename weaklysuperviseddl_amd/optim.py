@@ -24,6 +24,8 @@ from . import ops
 
 _ALIGN = 64   # floats; keeps every parameter 256-byte aligned inside the flat buffer
 import os as _os
+RANGE_GUARD = [_os.environ.get("WSDL_RANGE_GUARD", "warn")]   # what FlatAdam does when the sentinel fires: "warn" | "auto" (switch the guards on) | "off"
+RANGE_GUARD_ACTIVE = [False]                                  # "auto" has switched the guards on in this process
 RANGE_SENTINEL = [_os.environ.get("WSDL_RANGE_SENTINEL", "1") != "0"]      # FlatAdam.step() checks the step's tensors for regions below the fp16x2 arithmetic's safe range
 
 
@@ -242,6 +244,32 @@ class FlatAdam:
                 self.__dict__.setdefault("_tail_events", []).append((e0, e1))
         return self._step()
 
+    def range_poll(self):
+        """Host side of the range sentinel (no synchronisation: the check kernels of the step before write pinned host memory):
+        warn once when a tensor of the last step spanned more than the fp16x2 arithmetic's safe range - and, with
+        ``WSDL_RANGE_GUARD=auto``, switch both range guards on for the steps that follow (weight layouts and launch plans
+        re-form by themselves: ops.set_option bumps their epochs).  Called by the eager step and after every plan replay."""
+        if getattr(self, "_range_warned", False) or getattr(self, "_range_hold", False) or RANGE_GUARD[0] == "off" or \
+                not (RANGE_SENTINEL[0] and ops.CONV_ARITH[0] == 1):
+            return
+        st = ops.range_status(self.flat_param.device)
+        if not st["exceeded"]:
+            return
+        self._range_warned = True
+        import warnings
+        what = (f"weaklysuperviseddl_amd: {st['pairs_over_limit']} activation / gradient tensors of the last step span more than "
+                f"2^{st['limit_log2']} between their largest and their smallest region (worst 2^{st['worst_log2']:.0f}): the default "
+                "convolution arithmetic (fp16x2, one scale per tensor) computes the small regions to fewer than 13 bits there - ")
+        if RANGE_GUARD[0] == "auto":
+            ops.set_option("conv_arith", 2)
+            ops.set_option("wgrad_chan_scale", 1)
+            RANGE_GUARD_ACTIVE[0] = True
+            warnings.warn(what + "WSDL_RANGE_GUARD=auto: the range guards are on from the next step (conv_arith = 2, wgrad_chan_scale = 1; "
+                          "about 10 % slower)")
+        else:
+            warnings.warn(what + "select the range guards: ops.set_option('conv_arith', 2) (forward / input gradient) and "
+                          "ops.set_option('wgrad_chan_scale', 1) (weight gradient), or WSDL_RANGE_GUARD=auto")
+
     def _step(self):
         self.sync_hyper()
         if self.pre_step_hook is not None:
@@ -269,17 +297,8 @@ class FlatAdam:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
         self._dirty = False                     # (joined above)
         if self.flat_param.is_cuda and RANGE_SENTINEL[0] and ops.CONV_ARITH[0] == 1:
-            # range sentinel of the fp16x2 arithmetic: what the PREVIOUS step's tensors spanned (read from host memory the check
-            # kernel wrote - no synchronisation), then this step's check
-            st = ops.range_status(self.flat_param.device)
-            if st["exceeded"] and not getattr(self, "_range_warned", False):
-                self._range_warned = True
-                import warnings
-                warnings.warn(f"weaklysuperviseddl_amd: {st['pairs_over_limit']} activation / gradient tensors of the last step span "
-                              f"more than 2^{st['limit_log2']} between their largest and their smallest region (worst 2^{st['worst_log2']:.0f}):"
-                              " the default convolution arithmetic (fp16x2, one scale per tensor) computes the small regions to "
-                              "fewer than 13 bits there - select the range guards: ops.set_option('conv_arith', 2) (forward / input "
-                              "gradient) and ops.set_option('wgrad_chan_scale', 1) (weight gradient)")
+            # range sentinel of the fp16x2 arithmetic: what the PREVIOUS step's tensors spanned, then this step's check
+            self.range_poll()
             ops.range_check(self.flat_param.device)
         if self.post_step_hook is not None:
             self.post_step_hook()

@@ -196,6 +196,15 @@ class PlannedTrainStep:
         return ts
 
     def _record(self, images, masks, key=None):
+        # (the sentinel's host side stays quiet while a plan is recorded and verified: WSDL_RANGE_GUARD=auto changes library
+        # options, which must not happen between the steps that are compared)
+        self.opt._range_hold = True
+        try:
+            return self._record_held(images, masks, key)
+        finally:
+            self.opt._range_hold = False
+
+    def _record_held(self, images, masks, key=None):
         dev = images.device
         opt = self.opt
         self.records += 1
@@ -328,6 +337,7 @@ class PlannedTrainStep:
         ep = ops.PARAM_EPOCH[0]
         for cache, w, _prep in ent.sites:           # the replay re-laid the weights out in place: the caches stay valid
             cache["prep_key"] = (ep, w._version, w.data_ptr())
+        self.opt.range_poll()                   # the sentinel's host side (the check kernel itself is part of the plan)
         return ent.s_loss.clone()
 
 
