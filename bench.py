@@ -386,21 +386,28 @@ def cam_bench(device, iters=int(os.environ.get("WSDL_CAM_ITERS", "20")), rooflin
     out = {"ms_per_img": round(ms / n_img, 4), "batch": n_img, "size": 224,
            "launch": "hipGraph replay of the batch (LayerCAMGenerator.generate_batch, WSDL_CAM_SELF_GRAPH=0: eager)",
            "what": "FrozenResNetCAM fwd + class-logit bwd (to layer3 output) + LayerCAM epilogue + threshold"}
-    # stage 1 as generate_pseudo_masks runs it: the loader's batches of 8 merged into device batches of 32 images, three of
-    # those in flight on three streams (WSDL_CAM_DEVICE_BATCH=0: one launch sequence per loader batch, round 3's form)
+    # stage 1 with several batches in flight, both ways generate_pseudo_masks can run it: device_batch = 0 (its default: one
+    # launch sequence per loader batch, three of them in flight - the masks do not depend on how batches are merged) and
+    # device_batch = 32 (throughput option: the loader's batches of 8 merged into device batches of 32 images)
     nb, lanes = int(os.environ.get("WSDL_CAM_NB", "12")), int(os.environ.get("WSDL_CAM_LANES", "3"))
     db = int(os.environ.get("WSDL_CAM_DEVICE_BATCH", "32"))
-    for _ in range(3):
-        gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=db)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=db)
-    torch.cuda.synchronize()
-    out["ms_per_img_pipelined"] = round((time.perf_counter() - t0) / iters * 1e3 / (nb * n_img), 4)
+
+    def in_flight(dbatch):
+        for _ in range(3):
+            gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=dbatch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            gen.generate_coalesced([imgs] * nb, 1.0, [cls] * nb, 0.3, streams=lanes, device_batch=dbatch)
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / iters * 1e3 / (nb * n_img), 4)
+
+    out["ms_per_img_in_flight"] = in_flight(0)
+    out["in_flight"] = (f"{nb} loader batches of {n_img}, {lanes} in flight, one launch sequence each "
+                        "(generate_pseudo_masks' default, device_batch = 0)")
+    out["ms_per_img_pipelined"] = in_flight(db) if db > 0 else out["ms_per_img_in_flight"]
     out["pipelined"] = (f"{nb} loader batches of {n_img} merged into device batches of {db}, {lanes} in flight "
-                        "(LayerCAMGenerator.generate_coalesced, as generate_pseudo_masks)" if db > 0 else
-                        f"{nb} batches of {n_img}, {lanes} in flight (LayerCAMGenerator.generate_batches)")
+                        f"(LayerCAMGenerator.generate_coalesced; generate_pseudo_masks(device_batch={db}))" if db > 0 else out["in_flight"])
     if roofline:
         ops.prof_reset()
         ops.prof_enable(True)
