@@ -242,6 +242,43 @@ def rocprof_avg_us(kernel):
     return round(float(best["AverageNs"]) / 1e3, 3), int(best["Calls"]), os.path.relpath(files[-1], ROOT)
 
 
+# The 256 x 128 forward / input-gradient kernel has three ENTRY POINTS around one body (conv_split.h: conv_igemm_split_body<256, 128, 4, 16,
+# 512, AR>): the plain launch, the grouped launch of several convolutions (ASPP's forward) and the multi-source launch (ASPP's
+# input gradient).  Each has a timing class of its own (so that a class lines up with one row of `rocprofv3 --stats`); the
+# roofline line prices the BODY - all three together, the same set of convolutions the single class of rounds 1-4 held - and
+# lists the entry points beside it.
+BODY_256x128 = ("conv_igemm_split_kernel<256, 128, 4, BK, 512, AR, false, false>",
+                "conv_igemm_split_group_kernel<256, 128, 4, 16, 512, AR, false>",
+                "conv_igemm_split_kernel<256, 128, 4, 16, 512, AR, false, true>")
+BODY_256x128_NAME = "conv_igemm_split_body<256, 128, 4, 16, 512, AR> (entry points: conv_igemm_split_kernel<256, 128, 4, 16, 512, AR, false, false | true>, conv_igemm_split_group_kernel<256, 128, 4, 16, 512, AR, false>)"
+
+
+def merge_body_classes(kernels):
+    """kernels: the per-class records of the instrumented pass -> the same list with the three entry points of the 256 x 128 body
+    merged into one record (its parts kept under "entries")."""
+    parts = [k for k in kernels if k["kernel"] in BODY_256x128]
+    if len(parts) < 2:
+        return kernels
+    tot = {"kernel": BODY_256x128_NAME, "launches": sum(k["launches"] for k in parts),
+           "total_ms": round(sum(k["total_ms"] for k in parts), 3), "work": sum(k["work"] for k in parts),
+           "executed": sum(k["executed"] for k in parts), "alg_bytes": sum(k["alg_bytes"] for k in parts), "entries": parts}
+    tot["avg_us"] = round(tot["total_ms"] / tot["launches"] * 1e3, 3)
+    return [tot] + [k for k in kernels if k["kernel"] not in BODY_256x128]
+
+
+def rocprof_avg_us_many(kernels):
+    """rocprof_avg_us over several classes: (total duration / total calls, calls, file, per-class rows)."""
+    rows, f = [], None
+    for k in kernels:
+        us, calls, f = rocprof_avg_us(k)
+        if us is not None:
+            rows.append({"kernel": k, "avg_us": us, "calls": calls})
+    if not rows:
+        return None, None, f, rows
+    calls = sum(r["calls"] for r in rows)
+    return round(sum(r["avg_us"] * r["calls"] for r in rows) / calls, 3), calls, f, rows
+
+
 # ------------------------------------------------------------------------------------------ CPU baselines (oracle)
 def _timed(fn, warm, steps, what):
     for _ in range(warm):
@@ -950,7 +987,8 @@ def main():
                 kernels.append({"kernel": ops.prof_class_name(c), "launches": n, "avg_us": round(ms / n * 1e3, 3),
                                 "total_ms": round(ms, 3), "work": work, "executed": exe, "alg_bytes": byt})
         ops.prof_reset()
-        kernels.sort(key=lambda k: -k["total_ms"])
+        per_class = sorted(kernels, key=lambda k: -k["total_ms"])
+        kernels = sorted(merge_body_classes(kernels), key=lambda k: -k["total_ms"])
         if kernels:
             top = kernels[0]
             # `achieved` counts the MFMA work really issued (nominal dense FLOPs minus the K-chunks skipped because
@@ -971,7 +1009,13 @@ def main():
             else:
                 mfma, peak = ach, FP32_MFMA_PEAK_TFLOPS
                 note = "fp32-input MFMA (v_mfma_f32_32x32x2_f32) dense peak"
-            rp_us, rp_calls, rp_file = rocprof_avg_us(top["kernel"])
+            entries = top.get("entries")
+            if entries:
+                rp_us, rp_calls, rp_file, rp_rows = rocprof_avg_us_many([e["kernel"] for e in entries])
+                traffic_kernel = max(entries, key=lambda e: e["total_ms"])["kernel"]
+            else:
+                (rp_us, rp_calls, rp_file), rp_rows = rocprof_avg_us(top["kernel"]), None
+                traffic_kernel = top["kernel"]
             step_tf = value / world * GFLOP_PER_IMG_256 * (S / 256) ** 2 / 1e3          # per GPU, nominal dense fp32-equivalent
             result["roofline"] = {"bound": "mfma", "kernel": top["kernel"],
                                   # ALGORITHMIC flops per launch (2 * P * Cout * K dense fp32-equivalent, padding taps
@@ -997,8 +1041,9 @@ def main():
                                                  "this run",
                                   "achieved_fp32_equivalent_executed": round(ach, 3),
                                   "mfma_products_per_fp32_product": (nprod if split else 1),
-                                  "traffic": pmc_traffic(top["kernel"]),
-                                  "traffic_source": pmc_traffic(top["kernel"], with_source=True)[1],
+                                  "traffic": pmc_traffic(traffic_kernel),
+                                  "traffic_source": pmc_traffic(traffic_kernel, with_source=True)[1],
+                                  "traffic_is": "HBM bytes per launch of the plain entry point (the other two: profiles/r05_notes.md)" if entries else "HBM bytes per launch",
                                   "mfma_busy_3x3": mfma_busy_3x3(),
                                   "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
                                   "launches": top["launches"], "avg_launch_us": top["avg_us"],
@@ -1008,10 +1053,24 @@ def main():
                                   "method": "second pass of the same steps, HIP events around every launch, wgrad side stream "
                                             "serialised (the timed region overlaps it with the main chain)",
                                   "peak_note": note}
+            if entries:
+                # the body's entry points one by one: nominal / executed rate of each, its HIP-event and rocprofv3 averages
+                rp = {r["kernel"]: r for r in (rp_rows or [])}
+                result["roofline"]["entries"] = [
+                    {"kernel": e["kernel"], "launches": e["launches"], "avg_launch_us": e["avg_us"],
+                     "avg_launch_us_rocprof": rp.get(e["kernel"], {}).get("avg_us"), "rocprof_calls": rp.get(e["kernel"], {}).get("calls"),
+                     "flop_per_launch_avg": e["work"] / e["launches"],
+                     "frac": round(e["work"] / (e["total_ms"] * 1e-3) / 1e12 / peak, 4),
+                     "frac_algorithmic_executed": round(e["executed"] / (e["total_ms"] * 1e-3) / 1e12 / peak, 4)} for e in entries]
+                result["roofline"]["entries_note"] = (
+                    "one kernel body, three entry points (plain launch; ASPP's four forward branches as one grouped launch; ASPP's four "
+                    "input gradients as one multi-source launch).  `frac` above = sum of their nominal FLOPs / sum of their time: the set "
+                    "of convolutions that rounds 1-4 reported under the single class.  avg_launch_us_rocprof = sum of the three rows' "
+                    "total time / sum of their calls in rocprof_source")
             result["kernels"] = [{k: (round(v / 1e12, 3) if k in ("work", "executed") else (round(v / 1e9, 3) if k == "alg_bytes" else v))
                                   for k, v in kk.items()} |
                                  {"tflops": round(kk["executed"] / (kk["total_ms"] * 1e-3) / 1e12, 3),
-                                  "tflops_nominal": round(kk["work"] / (kk["total_ms"] * 1e-3) / 1e12, 3)} for kk in kernels]
+                                  "tflops_nominal": round(kk["work"] / (kk["total_ms"] * 1e-3) / 1e12, 3)} for kk in per_class]
             result["model_tflops_nominal"] = round(value * GFLOP_PER_IMG_256 * (S / 256) ** 2 / 1e3, 3)
 
     if world == 1 and cfg == "cfg2" and not args.no_full_width and not args.opt and not use_graph:

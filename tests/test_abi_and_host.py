@@ -310,3 +310,22 @@ def test_generate_coalesced_merges_and_splits_batches_on_the_host():
     gen.model.train()
     with pytest.raises(RuntimeError):
         gen.generate_coalesced(batches, 1.0, classes, 0.3, streams=3, device_batch=8)
+
+
+def test_bench_roofline_prices_the_kernel_body_over_its_three_entry_points():
+    """bench.py's roofline line: the 256 x 128 forward / input-gradient body has three entry points (plain, grouped, multi-source),
+    each a timing class of its own; the line merges them (sum of nominal FLOPs / sum of time) and looks the rocprofv3 average up
+    as sum of the three rows' time / sum of their calls in the committed kernel-stats file."""
+    import bench
+    recs = [{"kernel": bench.BODY_256x128[0], "launches": 66, "total_ms": 6.6, "work": 1.5e12, "executed": 1.45e12, "alg_bytes": 6e9, "avg_us": 100.0},
+            {"kernel": bench.BODY_256x128[1], "launches": 1, "total_ms": 0.7, "work": 0.4e12, "executed": 0.1e12, "alg_bytes": 1e9, "avg_us": 700.0},
+            {"kernel": bench.BODY_256x128[2], "launches": 1, "total_ms": 0.7, "work": 0.4e12, "executed": 0.1e12, "alg_bytes": 1e9, "avg_us": 700.0},
+            {"kernel": "bn_fwd_resident_kernel<256, 16>", "launches": 11, "total_ms": 0.6, "work": 0.0, "executed": 0.0, "alg_bytes": 3e9, "avg_us": 54.5}]
+    merged = bench.merge_body_classes(list(recs))
+    assert len(merged) == 2 and merged[0]["kernel"] == bench.BODY_256x128_NAME and merged[0]["launches"] == 68
+    assert abs(merged[0]["total_ms"] - 8.0) < 1e-9 and merged[0]["work"] == 2.3e12 and len(merged[0]["entries"]) == 3
+    assert bench.merge_body_classes(recs[:1] + recs[3:]) == recs[:1] + recs[3:]          # one entry point only: nothing to merge
+    us, calls, f, rows = bench.rocprof_avg_us_many(list(bench.BODY_256x128))
+    assert f and f.startswith("profiles/") and rows and calls == sum(r["calls"] for r in rows)
+    assert abs(us - sum(r["avg_us"] * r["calls"] for r in rows) / calls) < 1e-3
+    assert min(r["avg_us"] for r in rows) <= us <= max(r["avg_us"] for r in rows)

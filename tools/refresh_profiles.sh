@@ -56,7 +56,7 @@ $R/tools/mfma_busy_3x3.sh > $O/mfma_busy_3x3.txt 2> $O/mfma_busy_3x3.err || exit
 cd /tmp
 
 step "other BASELINE configs through bench.py, 2-rank rehearsal, bf16x3 A/B, hipGraph A/B"
-for c in cfg3 cfg4 cfg5; do python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_$c.json 2> $O/bench_$c.err || exit 1; done
+for c in cfg3 cfg4 cfg5; do python3 $R/bench.py --config $c --steps 10 --warmup 3 > $O/bench_$c.json 2> $O/bench_$c.err || exit 1; done
 python3 $R/bench.py --gpus 2 --steps 4 --warmup 2 --no-cpu-baseline > $O/bench_n2_gloo_one_gpu.json 2> $O/bench_n2.err || exit 1
 WSDL_FORCE_DIST=1 python3 $R/bench.py --no-cpu-baseline --no-cam --no-roofline --no-full-width > $O/bench_n1_rccl_single_rank.json 2> /dev/null || exit 1
 python3 $R/bench.py --no-cpu-baseline --no-cam --opt conv_arith=0 > $O/bench_n1_bf16x3.json 2> /dev/null || exit 1
