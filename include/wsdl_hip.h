@@ -74,6 +74,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *                      (half of it for the backward): 16 waves per CU loading at once where one workgroup per channel would
  *                      leave a CU with 4 - forward -20..23 %, backward -7 % at 256 channels (profiles/r03_bn_kernels.txt)
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
+ *   wgrad_imbalance_split 1*  one more pixel split for the fp16x2 weight gradient of a dilated convolution whose outer taps do less
+ *                      than 70 % of the centre tap's work (padding-only chunks are skipped): ASPP d12 463 -> 442 us, d24 357 -> 287
  *   wgrad_bk      16*  pixel chunk of the fp32 weight-gradient kernel (16 | 32)
  *   wgrad_direct   1*  fp16x2 weight-gradient kernel with the x operand's MFMA fragments loaded straight from global memory (no LDS, no
  *                      lane exchange for x; dY double-buffered in LDS, one barrier per chunk) where OW % 32 == 0, stride 1 and every

@@ -1686,8 +1686,24 @@ unsigned long long live_taps(int H, int W, int OH, int OW, int kh, int kw, int s
     return m;
 }
 
-// n_live: N counted over live taps only (the split kernel's dead-tap workgroups exit at once)
-int wgrad_splits(int Cout, int Cin, int N, int P, int n_live) {
+// The share of a tap's pixel chunks (output rows) that read anything but padding, lightest live tap over heaviest: 1 for an
+// undilated or small-dilation convolution, 20 / 32 for dilation 12 on a 32 x 32 map, 8 / 32 for dilation 24.
+double wgrad_tap_balance(int H, int OH, int kh, int stride, int pad, int dil) {
+    int lo = OH, hi = 0;
+    for (int i = 0; i < kh; ++i) {
+        int cnt = 0;
+        for (int oh = 0; oh < OH; ++oh) {
+            const int ih = oh * stride + i * dil - pad;
+            cnt += ih >= 0 && ih < H;
+        }
+        if (cnt > 0) { lo = std::min(lo, cnt); hi = std::max(hi, cnt); }
+    }
+    return hi > 0 ? (double)lo / (double)hi : 1.0;
+}
+
+int g_wgrad_imbalance_split = 1;   // one more pixel split for tap-imbalanced launches (wgrad_splits)
+// n_live: N counted over live taps only (the split kernel's dead-tap workgroups exit at once); tap_balance: wgrad_tap_balance
+int wgrad_splits(int Cout, int Cin, int N, int P, int n_live, double tap_balance = 1.0) {
     int BM, BN;
     bool fast;
     wgrad_tile(Cout, Cin, &BM, &BN, &fast);
@@ -1707,6 +1723,11 @@ int wgrad_splits(int Cout, int Cin, int N, int P, int n_live) {
             if (blocks < slots) eff *= 0.9;      // a partly filled single round also loses the co-resident partner
             if (eff > best + 0.03) { best = eff; best_s = c; }
         }
+        // Workgroups of a dilated convolution's outer taps skip the chunks that read only padding: with taps at 25-62 % of the
+        // centre tap's work the round model above (equal workgroups) picks too few, too long workgroups - one more split lets
+        // the dispatcher even them out (same box: ASPP d12 463 -> 442 us, d24 357 -> 287 at 32 x 32; d24 895 -> 819, d36 714 ->
+        // 541 at 64 x 64; the balanced shapes lose 5-20 % with it)
+        if (g_wgrad_imbalance_split && tap_balance < 0.7 && n_live > BN && best_s + 1 <= smax) ++best_s;
         return (int)best_s;
     }
     long long s0 = (g_wgrad_blocks + tiles - 1) / tiles;
@@ -1772,6 +1793,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_direct")) { g_wgrad_direct = value; return WSDL_OK; }
+    if (!strcmp(name, "wgrad_imbalance_split")) { g_wgrad_imbalance_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_chan_scale")) { g_wgrad_chan_scale = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_dyraw")) { g_wgrad_dyraw = value; return WSDL_OK; }
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
@@ -2191,7 +2213,8 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     Band bands[8];
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
     const int n_live = __builtin_popcountll(live_taps(H, W, OH, OW, kh, kw, stride, pad, dil)) * Cin;
-    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live) * Cout * N * sizeof(float);
+    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live, wgrad_tap_balance(H, OH, kh, stride, pad, dil)) *
+                         Cout * N * sizeof(float);
     return wsdl::align_up(slabs, 256) + wsdl::align_up(wgrad_dys_bytes(Cout, Cin, N, B * OH * OW), 256) +
            (g_wgrad_chan_scale ? wsdl::align_up((size_t)(Cin + Cout) * sizeof(float), 256) : 0);
 }
@@ -2225,7 +2248,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
     p.x_amax = x_amax;
     const unsigned long long live_all = live_taps(H, W, OH, OW, kh, kw, stride, pad, dil);
-    const int S = wgrad_splits(Cout, Cin, p.N, p.P, __builtin_popcountll(live_all) * Cin);
+    const int S = wgrad_splits(Cout, Cin, p.N, p.P, __builtin_popcountll(live_all) * Cin, wgrad_tap_balance(H, OH, kh, stride, pad, dil));
     Band bands[8];
     const int nb = (g_wgrad_bk == 32) ? 1 : wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
     if (nb == 1) bands[0] = Band{0, OW};
