@@ -35,6 +35,11 @@ def main():
         ws = [torch.randn(256, 2048, k, k, device=dev) * 0.02 for k in ks]
         preps = [ops.prep_weights(w) for w in ws]
         dys = [torch.randn(B, 256, H, H, device=dev) for _ in ks]
+        if a.zeros:
+            x.zero_()
+            ws = [w.zero_() for w in ws]
+            dys = [d.zero_() for d in dys]
+            preps = [ops.prep_weights(w) for w in ws]
         shapes = [tuple(w.shape) for w in ws]
         order = [1, 2, 3, 0]
         for _ in range(a.reps):
