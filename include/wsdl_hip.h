@@ -73,6 +73,10 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   bn_wide_c    512*  resident BatchNorm kernels as 1024 threads x 4 float4 (instead of 256 x 16) up to this channel count
  *                      (half of it for the backward): 16 waves per CU loading at once where one workgroup per channel would
  *                      leave a CU with 4 - forward -20..23 %, backward -7 % at 256 channels (profiles/r03_bn_kernels.txt)
+ *   conv_il        1*  256x128 forward / input-gradient form (all three entry points): steady-state K loop with every wave's MFMAs
+ *                      and staging instructions interleaved (branch-free body + scheduling directives) - both waves of a SIMD run
+ *                      the same phase, so staging otherwise never overlaps the other wave's MFMAs; bit-identical, 2-8 % faster
+ *                      per launch in isolation, +0.5 % on the (power-bound) step
  *   wgrad_blocks 768*  target workgroups of a weight-gradient launch;  wgrad_force_s 0*  fixed number of pixel splits
  *   wgrad_imbalance_split 1*  one more pixel split for the fp16x2 weight gradient of a dilated convolution whose outer taps do less
  *                      than 70 % of the centre tap's work (padding-only chunks are skipped): ASPP d12 463 -> 442 us, d24 357 -> 287

@@ -1311,6 +1311,7 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     return WSDL_OK;
 }
 
+int g_conv_il = 1;        // 256x128 form: MFMAs and staging instructions interleaved in every wave's stream (conv_split.h, IL)
 int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
 // (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
@@ -1338,12 +1339,16 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     }
     if (p.nsrc > 0) {        // several convolutions accumulated into one output (conv_split.h, MS)
         if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2, false, true>), grid, dim3(512), 0, s, p);
+        else if (g_conv_arith && g_conv_il)
+            hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1, false, true, true>), grid, dim3(512), 0, s, p);
         else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1, false, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0, false, true>), grid, dim3(512), 0, s, p);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
     if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2>), grid, dim3(512), 0, s, p);
+    else if (g_conv_arith && g_conv_il)
+        hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1, false, false, true>), grid, dim3(512), 0, s, p);
     else if (g_conv_arith) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 1>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 0>), grid, dim3(512), 0, s, p);
     WSDL_LAUNCH_CHECK();
@@ -1799,6 +1804,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
+    if (!strcmp(name, "conv_il")) { g_conv_il = value != 0; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
@@ -2078,6 +2084,8 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
         wsdl::ProfScope prof(WSDL_PROF_SPLIT_GROUP, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
         if (g_conv_arith == 2)
             hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 2>), dim3(start), dim3(512), 0, s, grp);
+        else if (g_conv_arith && g_conv_il)
+            hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 1, false, true>), dim3(start), dim3(512), 0, s, grp);
         else if (g_conv_arith)
             hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 1>), dim3(start), dim3(512), 0, s, grp);
         else

@@ -163,7 +163,14 @@ __host__ __device__ constexpr long long split_layout_bytes(int AR, long long k_t
 //
 // The body is a device function of (problem, tile indices, grid extent): conv_igemm_split_kernel runs it on its own grid,
 // conv_igemm_split_group_kernel (round 5) on a grid that strings several problems together (ASPP's four branches in one launch).
-template <int BM, int BN, int WM, int BK, int NT, int AR, bool MF, bool MS>
+// IL (interleaved steady state; 32x32x16 form, K chunk 16, AR = 1): counters of the 256 x 128 kernel (profiles/r05_notes.md) show its
+// waves issuing 29 % of their cycles, waiting for the issue port 41 % (the SIMD's other wave holds the matrix pipe) and parked 30 %,
+// with the pipe busy 40 %: both waves of a SIMD run the SAME phase (they meet at the chunk's barrier), so staging never falls
+// into the other wave's MFMAs.  IL makes every wave's instruction stream alternate - one MFMA, a few staging instructions
+// (the next chunk's split and LDS stores, the loads of the one after) - so that whichever wave does not hold the pipe has
+// non-matrix work to issue.  Branch-free steady state (the scheduler cannot interleave across branches); the last two chunks
+// run the plain loop.
+template <int BM, int BN, int WM, int BK, int NT, int AR, bool MF, bool MS, bool IL>
 __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int bx_in, const int by_in, const int bz,
                                                       const int grid_x, const int grid_y) {
     static_assert(!MF || (AR >= 1 && BK == 32), "16x16x32 form: fp16x2, K chunk 32");
@@ -504,7 +511,65 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     if (nq > 1) store_tiles(1);
     __syncthreads();
 #endif
-    for (int q = 0; q < nq; ++q) {
+    int q_start = 0;
+    if constexpr (IL) {
+        static_assert(!IL || (!MF && KS == 1 && AR == 1), "interleaved loop: 32x32x16 form, K chunk 16, fp16x2");
+        // the loads of load_next() split in two: `advance` (which chunk comes next: scalar bookkeeping, a branch) at the END of an
+        // iteration, `issue` (the loads themselves) inside the interleaved block
+        unsigned il_soff_a = 0, il_soff_b = 0;
+        auto advance = [&]() {
+            if (ld_c == cpt) {
+                ld_c = 0;
+                ++ld_vi;
+                set_tap(ld_vi);
+            }
+            il_soff_a = (unsigned)(((ld_tap * s_Cin + ld_c * BK) / 16) * p.Cout * K16B);
+            il_soff_b = (unsigned)(ld_c * BK * HW) * 4u;
+            ++ld_c;
+        };
+        const unsigned fra = (unsigned)((wm * (MI * 32) + l31) * ROW + lh * 16), frb = (unsigned)((wn * (NI * 32) + l31) * ROW + lh * 16);
+        int q = 0;
+        if (nq > 2) advance();                           // chunk 2's offsets
+        for (; q + 2 < nq; ++q) {
+            const int cur = q & 1;
+            frag a[MI][NP], b[NI][NP];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int c = 0; c < NP; ++c) a[i][c] = *reinterpret_cast<const frag*>(&As[cur][fra + i * 32 * ROW + c * 32]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int c = 0; c < NP; ++c) b[j][c] = *reinterpret_cast<const frag*>(&Bs[cur][frb + j * 32 * ROW + c * 32]);
+            store_tiles(cur ^ 1);                        // the registers hold chunk q + 1
+#pragma unroll
+            for (int e = 0; e < A_U; ++e) ra[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, voff_a[e], il_soff_a, 0);
+#pragma unroll
+            for (int e = 0; e < B_PER; ++e)
+                rb[e] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff_b, il_soff_b + (unsigned)(e * HW) * 4u, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = split_products<AR>(a[i], b[j], acc[i][j]);
+            // the order wanted: the fragment reads, a first piece of the staging arithmetic while they arrive, then MFMAs with the
+            // rest of the staging, the LDS stores and the loads between them
+            __builtin_amdgcn_sched_group_barrier(0x100, (MI + NI) * NP, 0);          // DS reads
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                       // VALU
+#pragma unroll
+            for (int k = 0; k < MI * NI * 3; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                   // VALU
+                if (k < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        // an LDS store
+                else if (k < 4 + A_U + B_PER) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // a load
+            }
+            lds_barrier();
+            if (q + 3 < nq) advance();                   // offsets of chunk q + 3 (its loads are issued in the next iteration)
+        }
+        q_start = q;
+        // hand over to the plain loop: it expects ld_c / ld_tap to describe the NEXT chunk to load - nothing is left to load
+        // (chunks up to nq - 1 have been issued: the registers hold chunk q_start + 1 if it exists)
+    }
+    for (int q = q_start; q < nq; ++q) {
         const int cur = q & 1;
 #ifndef WSDL_EXP_NOSTAGE
         if (q + 1 < nq) {
@@ -576,9 +641,9 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     if (p.y_amax) publish_amax(vmax, p.y_amax);
 }
 
-template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false, bool MS = false>
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false, bool MS = false, bool IL = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_kernel(ConvP p) {
-    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, MS>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, MS, IL>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
 }
 
 // Several convolutions in ONE launch: workgroups [start[g], start[g + 1]) of the 1-D grid work on problem g, as its
@@ -598,13 +663,13 @@ struct ConvGroup {
     int s_prob[8], s_slice[8];
     ConvP p[4];
 };
-template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false>
+template <int BM, int BN, int WM, int BK, int NT = kThreads, int AR = 1, bool MF = false, bool IL = false>
 __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_group_kernel(ConvGroup grp) {
     const int L = blockIdx.x;
     if (grp.ns > 0) {
         const int s = L % grp.ns, r = L / grp.ns;
         const int g = grp.s_prob[s], gx = grp.gx[g], gy = grp.gy[g];
-        conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false>(grp.p[g], r % gx, r / gx, grp.s_slice[s], gx, gy);
+        conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false, IL>(grp.p[g], r % gx, r / gx, grp.s_slice[s], gx, gy);
         return;
     }
     int g = 0;
@@ -613,7 +678,7 @@ __global__ __launch_bounds__(NT, NT == kThreads ? 2 : 1) void conv_igemm_split_g
         if (i < grp.n && L >= grp.start[i]) g = i;
     const int local = L - grp.start[g], gx = grp.gx[g], gy = grp.gy[g];
     const int plane = gx * gy, bz = local / plane, r = local - bz * plane;
-    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false>(grp.p[g], r % gx, r / gx, bz, gx, gy);
+    conv_igemm_split_body<BM, BN, WM, BK, NT, AR, MF, false, IL>(grp.p[g], r % gx, r / gx, bz, gx, gy);
 }
 
 // ---------------------------------------------------------------------------------------------
