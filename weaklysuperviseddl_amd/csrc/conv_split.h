@@ -512,7 +512,12 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     __syncthreads();
 #endif
     int q_start = 0;
-    if constexpr (IL) {
+#if defined(WSDL_EXP_NOSTAGE) || defined(WSDL_EXP_NOMFMA)
+    constexpr bool kTimingBuild = true;                  // the timing-only builds take the plain loop apart, not this one
+#else
+    constexpr bool kTimingBuild = false;
+#endif
+    if constexpr (IL && !kTimingBuild) {
         static_assert(!IL || (!MF && KS == 1 && AR == 1), "interleaved loop: 32x32x16 form, K chunk 16, fp16x2");
         // the loads of load_next() split in two: `advance` (which chunk comes next: scalar bookkeeping, a branch) at the END of an
         // iteration, `issue` (the loads themselves) inside the interleaved block
