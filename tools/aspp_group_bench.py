@@ -64,7 +64,7 @@ for i, (w, d) in enumerate(zip(ws, dils)):
     print(f"branch k={w.shape[2]} d={d}: fwd {t:.1f} us, dgrad (accumulating) {t2:.1f} us")
 print(f"forward: four launches {timeit(fwd_single):.1f} us, grouped {timeit(fwd_group):.1f} us")
 print(f"input gradient: chain of four {timeit(dgrad_chain):.1f} us, multi-source {timeit(dgrad_multi):.1f} us")
-for tps in (20, 30, 45):
+for tps in (20, 30, 45, 90):
     ops.set_option("group_tps10", tps)
     print(f"group_tps10 = {tps}: grouped forward {timeit(fwd_group):.1f} us")
 ops.set_option("group_tps10", 20)
