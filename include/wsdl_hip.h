@@ -39,9 +39,11 @@ const char* wsdl_last_error(void);
 int wsdl_version(void);               /* 10000*major + 100*minor + patch */
 const char* wsdl_target_arch(void);   /* "gfx950" */
 
-/* Process-wide options (plain globals: set them before launching work, not while another thread is inside the
- * library - calls are re-entrant across streams only for a fixed option set).  Changing "conv_split" /
- * "conv_arith" changes what the weight layout buffers hold: re-run wsdl_conv2d_prep_weights afterwards.
+/* Process-wide options.  Each is an int read with relaxed atomic loads by every entry point: a call that runs while another
+ * host thread sets an option sees the old or the new value, never a torn one.  wsdl_set_option is serialised and REFUSES
+ * (WSDL_EINVAL) while any host thread is recording a launch plan - a plan freezes the tile choices of the option set it was
+ * recorded under.  Changing "conv_split" / "conv_arith" changes what the weight layout buffers hold: re-run
+ * wsdl_conv2d_prep_weights afterwards (callers that cache layouts key them on the option set: ops.LAYOUT_EPOCH).
  *   conv_arith     1*  arithmetic of the split kernels: 1 = fp16x2 (three 16-bit MFMAs per fp32 product, per-tensor
  *                      power-of-two scales from the amax arguments), 0 = bf16x3 (six MFMAs, no scales),
  *                      2 = fp16x2 with the low piece carried at 2^11 and the cross products in a second accumulator
@@ -474,7 +476,9 @@ int wsdl_softmax_bwd(const float* y, const float* dy, float* dx, int B, int C, i
  * cross-stream dependencies made through the wsdl_event_* / wsdl_stream_wait_* calls below - while the sequence runs in the
  * ordinary way, and wsdl_plan_replay issues them again from one C loop (csrc/plan.hip).  Same kernels, same arguments,
  * same order per stream: the results are the recorded sequence's, bit for bit.
- *   - one recording at a time, process-wide; the recording thread is the only one that may call into the library meanwhile;
+ *   - one recording at a time PER HOST THREAD (the recording state is thread-local): other threads may call into the
+ *     library meanwhile - their launches run normally and are not part of this thread's plan - and may record plans of
+ *     their own; wsdl_set_option is refused while any thread records;
  *   - the caller keeps every buffer the sequence touched alive and at its address for the plan's lifetime, and anything
  *     that varies from replay to replay on the device (wsdl_adam_step's step_dev, wsdl_dropout_fwd's counter);
  *   - wsdl_lovasz_softmax_fwd_bwd (rocPRIM launches kernels of its own) poisons a recording: wsdl_plan_end fails;

@@ -329,3 +329,52 @@ def test_bench_roofline_prices_the_kernel_body_over_its_three_entry_points():
     assert f and f.startswith("profiles/") and rows and calls == sum(r["calls"] for r in rows)
     assert abs(us - sum(r["avg_us"] * r["calls"] for r in rows) / calls) < 1e-3
     assert min(r["avg_us"] for r in rows) <= us <= max(r["avg_us"] for r in rows)
+
+
+def test_plan_recording_is_per_host_thread_and_options_are_guarded():
+    """"no global state other than a lazily-built kernel table ... re-entrant".  The recording state of the launch
+    plans is thread-local on both sides of the ABI (csrc/plan.hip `thread_local g_plan_rec`, ops.PLAN_REC): a second host
+    thread that calls into the library while the first one records is NOT written into the first one's plan, can record a
+    plan of its own, and the process-wide options cannot be changed under a recording (a plan freezes the tile choices made
+    under the option set it was recorded with).  No kernel is launched: begin / end / abort / stats / set_option only."""
+    import ctypes as C
+    import threading
+    from weaklysuperviseddl_amd import lib, ops
+    L = lib()
+    seen = {}
+
+    assert L.wsdl_plan_recording() == 0
+    assert L.wsdl_plan_begin() == 0 and L.wsdl_plan_recording() == 1
+    ops.PLAN_REC[0] = "thread-A recording"
+
+    def other():
+        seen["recording_seen_by_b"] = L.wsdl_plan_recording()
+        seen["slot_seen_by_b"] = ops.PLAN_REC[0]
+        seen["begin_b"] = L.wsdl_plan_begin()                 # its own recording
+        seen["recording_b"] = L.wsdl_plan_recording()
+        seen["set_option_b"] = L.wsdl_set_option(b"ksplit_max", 8)
+        seen["set_option_err"] = L.wsdl_last_error().decode()
+        h = C.c_void_p()
+        seen["end_b"] = L.wsdl_plan_end(C.byref(h))
+        n = C.c_longlong(-1)
+        seen["stats_b"] = L.wsdl_plan_stats(h, C.byref(n), None, None, None, None)
+        seen["kernels_b"] = n.value
+        L.wsdl_plan_destroy(h)
+        seen["after_b"] = L.wsdl_plan_recording()
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    try:
+        assert seen["recording_seen_by_b"] == 0 and seen["slot_seen_by_b"] is None
+        assert seen["begin_b"] == 0 and seen["recording_b"] == 1 and seen["end_b"] == 0 and seen["after_b"] == 0
+        assert seen["stats_b"] == 0 and seen["kernels_b"] == 0
+        assert seen["set_option_b"] != 0 and "being recorded" in seen["set_option_err"]
+        assert L.wsdl_plan_recording() == 1 and ops.PLAN_REC[0] == "thread-A recording"     # thread A's is untouched
+        assert L.wsdl_set_option(b"ksplit_max", 8) != 0                                      # ... and still guards the options
+        assert L.wsdl_plan_begin() != 0                                                      # one recording per thread
+    finally:
+        ops.PLAN_REC[0] = None
+        assert L.wsdl_plan_abort() == 0
+    assert L.wsdl_plan_recording() == 0
+    assert L.wsdl_set_option(b"ksplit_max", 8) == 0

@@ -349,6 +349,46 @@ def test_hipgraph_replay_equals_eager_steps(dev):
     assert len(set(le)) == 6 and all(np.isfinite(le))
 
 
+def test_hipgraph_replay_follows_a_learning_rate_schedule(dev):
+    """Adam's lr / betas / eps / grad_scale are device floats (FlatAdam.hyper_dev): a schedule that changes lr BETWEEN graphed
+    steps changes memory, not the captured node - no new capture, and never a host-to-device copy inside a capture.  Eight steps
+    with the rate halved after every second one: graphed == eager bit for bit, one capture in all."""
+    import bench
+    from weaklysuperviseddl_amd.graph import GraphedTrainStep
+    from weaklysuperviseddl_amd.TraditionalModel import build_segmentation_model, train_step
+    from weaklysuperviseddl_amd.TraditionalModel.SegmentationModel import make_optimizer
+
+    def run(graphed):
+        torch.manual_seed(0)
+        model = build_segmentation_model().to(dev).train()
+        opt = make_optimizer(model, lr=1e-3)
+        img, masks = bench.synthetic_batch(2, 64, 64, dev, 1)
+        step = GraphedTrainStep(model, opt, warmup=2) if graphed else (lambda i, m: train_step(model, opt, i, m))
+        captures, losses = 0, []
+        if graphed:
+            orig = step._capture
+
+            def counting(*a):
+                nonlocal captures
+                captures += 1
+                return orig(*a)
+            step._capture = counting
+        for k in range(8):
+            if k and k % 2 == 0:
+                opt.lr *= 0.5
+            if k == 5:
+                opt.eps = 1e-6
+            losses.append(step(img, masks).item())
+        torch.cuda.synchronize()
+        return losses, opt.flat_param.clone(), opt.exp_avg.clone(), captures
+
+    le, pe, me, _ = run(False)
+    lg, pg, mg, captures = run(True)
+    assert captures == 1, captures
+    assert le == lg, (le, lg)
+    assert torch.equal(pe, pg) and torch.equal(me, mg)
+
+
 def test_cfg4_two_stage_chain_at_full_per_gpu_size(dev):
     """BASELINE configs[3], one GPU's share, as ONE chain: LayerCAM on (16,3,224,224) -> threshold -> keep_largest ->
     in-memory hand-off (NEAREST 224 -> 256, ImageNet normalise) -> two training steps at B=16 256 x 256.

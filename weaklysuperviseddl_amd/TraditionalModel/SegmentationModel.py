@@ -328,9 +328,11 @@ def train_step(model, optimizer, images, masks, extra_loss=None, loss_fn="cross_
     occurrence on (``plan.PlannedTrainStep``: the launches of an eager iteration recorded behind the C ABI, verified to
     reproduce it bit for bit, then replayed); WSDL_PLAN_STEP=0 keeps every iteration eager."""
     if isinstance(optimizer, FlatAdam) and images.is_cuda and plan.PLAN_STEP[0]:
-        tag = (id(extra_loss) if extra_loss is not None else None, loss_fn, id(criterion) if criterion is not None else None)
+        tag = (plan.loss_tag(extra_loss), loss_fn, plan.loss_tag(criterion))
         st = plan.planned_step_for(model, optimizer,
                                    lambda i, m: _train_step_eager(model, optimizer, i, m, extra_loss, loss_fn, criterion), tag)
+        # host scalars inside the loss objects (weights, window sizes, sigmas) are kernel arguments a plan freezes: part of its key
+        st.loss_scalars = (plan.host_scalars(extra_loss), plan.host_scalars(criterion)) if (extra_loss is not None or criterion is not None) else None
         return st(images, masks)
     return _train_step_eager(model, optimizer, images, masks, extra_loss, loss_fn, criterion)
 

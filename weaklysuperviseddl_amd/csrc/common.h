@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <memory>
 #include <tuple>
 #include <utility>
@@ -55,13 +56,27 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// A process-wide option (wsdl_set_option): an int that any host thread may read while another one sets it - relaxed atomic
+// accesses (plain moves on x86), so a call sees the old or the new value, never a torn one.  wsdl_set_option itself is
+// serialised and refuses to run while ANY thread records a launch plan (a plan freezes the tile choices made under the
+// option set it was recorded with).  What an option means for cached weight LAYOUTS is the caller's to track: changing
+// "conv_split" / "conv_arith" requires wsdl_conv2d_prep_weights again (the Python host keys its caches on a layout epoch).
+struct Opt {
+    std::atomic<int> v;
+    explicit constexpr Opt(int x) : v(x) {}
+    operator int() const { return v.load(std::memory_order_relaxed); }
+    Opt& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+    Opt(const Opt&) = delete;
+};
+extern std::atomic<int> g_plans_recording;     // host threads between wsdl_plan_begin and wsdl_plan_end / _abort
+
 // A/B switch (wsdl_set_option "bn_resident"): channel-resident fused BatchNorm kernels (norm_pool.hip)
-extern int g_bn_resident;
-extern int g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
-extern int g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
-extern int g_bn_coop;             // "bn_coop": several workgroups per channel in the resident BatchNorm kernels up to this channel count (0 off)
-extern int g_bn_coop_wide;        // "bn_coop_wide": ... and two per channel at 256 channels
-extern int g_range_sentinel;      // "range_sentinel": the amax pointers of the BatchNorm entry points are (max, ~min piece max) PAIRS
+extern Opt g_bn_resident;
+extern Opt g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
+extern Opt g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
+extern Opt g_bn_coop;             // "bn_coop": several workgroups per channel in the resident BatchNorm kernels up to this channel count (0 off)
+extern Opt g_bn_coop_wide;        // "bn_coop_wide": ... and two per channel at 256 channels
+extern Opt g_range_sentinel;      // "range_sentinel": the amax pointers of the BatchNorm entry points are (max, ~min piece max) PAIRS
 
 // deterministic two-stage sum: stage 1 kernels write `n` float partials, stage 2 adds them in order.
 constexpr int kReduceSlots = 4096;
@@ -73,7 +88,10 @@ constexpr int kReduceSlots = 4096;
 // values - so that wsdl_plan_replay can issue the same sequence again from one C loop, without the host logic of the
 // entry points (tile choice, workspace carving, option look-ups) and without the caller's per-call overhead.
 struct Plan;
-extern Plan* g_plan_rec;            // the plan being recorded (one at a time, process-wide), else nullptr
+// the plan THIS host thread is recording (one per thread), else nullptr.  Thread-local: a second host thread that calls into
+// the library meanwhile (a loader worker, a second model) launches normally and is not written into the first thread's plan;
+// it may record a plan of its own.
+extern thread_local Plan* g_plan_rec;
 void plan_add_kernel(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, std::shared_ptr<void> storage,
                      void* const* argv, int argc);
 void plan_poison(const char* why);  // an entry point that cannot be replayed (library code launching kernels of its own)

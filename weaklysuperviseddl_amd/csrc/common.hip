@@ -9,8 +9,8 @@
 namespace wsdl {
 
 static thread_local char g_err[512] = "";
-int g_range_sentinel = 0;
-int g_bn_coop = 0, g_bn_coop_wide = 0;      // off by default: four workgroups per channel pay at 64 channels only (0.3 % of the step), and
+Opt g_range_sentinel{0};
+Opt g_bn_coop{0}, g_bn_coop_wide{0};      // off by default: four workgroups per channel pay at 64 channels only (0.3 % of the step), and
                                             // workgroups that wait for each other are not something to have on by default (r05_notes.md)
 
 void set_error(const char* fmt, ...) {

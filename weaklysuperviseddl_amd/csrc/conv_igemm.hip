@@ -1239,16 +1239,16 @@ double wgrad_executed_fraction(int P, int OH, int ow0, int own, int H, int W, in
     return all ? (double)done / (double)all : 1.0;
 }
 
-int g_tile_threshold = 400;   // blocks below which the half-size pixel tile is used
-int g_xcd_rowfast = 0;               // experiment: row-tile-fastest XCD order for every XCD-mapped launch of the split kernels
-int g_ms_rowfast = 1, g_ms_py = 0;   // multi-source launches: row-tile-fastest XCD order; forced number of row groups (0 = auto)
-int g_group_interleave = 1;          // grouped forward: stream-interleaved workgroup order when the streams fill the XCDs evenly
-int g_group_tps10 = 20;       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (20: d12 in 4 slices, d24 in 2 = eight
+wsdl::Opt g_tile_threshold{400};   // blocks below which the half-size pixel tile is used
+wsdl::Opt g_xcd_rowfast{0};               // experiment: row-tile-fastest XCD order for every XCD-mapped launch of the split kernels
+wsdl::Opt g_ms_rowfast{1}, g_ms_py{0};   // multi-source launches: row-tile-fastest XCD order; forced number of row groups (0 = auto)
+wsdl::Opt g_group_interleave{1};          // grouped forward: stream-interleaved workgroup order when the streams fill the XCDs evenly
+wsdl::Opt g_group_tps10{20};       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (20: d12 in 4 slices, d24 in 2 = eight
                               // streams, one per XCD.  648 / 623 / 636 us at 20 / 30 / 45 on one box, 662 / 713 at 20 / 30 on another)
 constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
 
-int g_wgrad_bk = 16;   // pixel chunk of the fast weight-gradient kernel: 16 or 32
-int g_bk32 = 1;        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
+wsdl::Opt g_wgrad_bk{16};   // pixel chunk of the fast weight-gradient kernel: 16 or 32
+wsdl::Opt g_bk32{1};        // K-chunk of 32 for the small-tile configurations (half the barriers per MFMA)
 
 template <int BM, int BN, int WM, int BK>
 int launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
@@ -1266,15 +1266,15 @@ int launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
 
 // bf16x3-split kernels (conv_split.h): which (rows, K-channels, taps) shapes use them.  A function of the
 // weight shape alone, so the layout kernel and the convolution agree on what the layout buffer holds.
-int g_conv_split = 1;
-int g_conv_arith = 1;    // arithmetic of the split kernels: 1 = fp16x2 (three MFMAs per product, per-tensor power-of-two
+wsdl::Opt g_conv_split{1};
+wsdl::Opt g_conv_arith{1};    // arithmetic of the split kernels: 1 = fp16x2 (three MFMAs per product, per-tensor power-of-two
                          // scales), 0 = bf16x3 (six MFMAs, no scales) - see conv_split.h
-int g_split_bk32 = 1;    // K chunk 32 on the small-tile split configurations
+wsdl::Opt g_split_bk32{1};    // K chunk 32 on the small-tile split configurations
 bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
-int g_xcd_map = 1;        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
+wsdl::Opt g_xcd_map{1};        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
 int choose_xcd_py(const ConvP& p, int gx, int gy) {
@@ -1311,8 +1311,8 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     return WSDL_OK;
 }
 
-int g_conv_il = 1;        // 256x128 form: MFMAs and staging instructions interleaved in every wave's stream (conv_split.h, IL)
-int g_tile256 = 1;        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
+wsdl::Opt g_conv_il{1};        // 256x128 form: MFMAs and staging instructions interleaved in every wave's stream (conv_split.h, IL)
+wsdl::Opt g_tile256{1};        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
 // (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
 // alone (+3.5 % per kernel), 1-2.6 % slower on the STEP, where it leaves no room for the weight-gradient workgroups beside it
@@ -1384,9 +1384,9 @@ int launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
 // the tap-skipping imbalance averages out.  Cout <= 64: 64x256 / 64x128.
 // Split-K for grids that cannot fill the chip (small batches of small maps, e.g. the CAM path at B=8: 14x14 maps
 // give 25 pixel tiles): returns the number of K slices (1 = no split).  Only the fast path supports it.
-int g_ksplit_big = 1;   // 128x128 tiles + 2 K slices for grids of 200..399 such tiles with K >= 2048 (instead of 128x64
+wsdl::Opt g_ksplit_big{1};   // 128x128 tiles + 2 K slices for grids of 200..399 such tiles with K >= 2048 (instead of 128x64
                         // tiles): aux 3x3 505 -> 435 us, layer3 3x3 139 -> 128 us; shorter K loses to the slab reduce
-int g_ksplit_target = 512, g_ksplit_max = 8, g_ksplit_min_chunks = 4;   // small grids: workgroups aimed at, most K slices, fewest 32-deep chunks per slice
+wsdl::Opt g_ksplit_target{512}, g_ksplit_max{8}, g_ksplit_min_chunks{4};   // small grids: workgroups aimed at, most K slices, fewest 32-deep chunks per slice
 int igemm_ksplit(int P, int Cout, int Cin, int T, int dil) {
     if (Cin % 32 != 0 || Cout % 4 != 0 || Cout <= 64) return 1;
     const long long blocks = (long long)wsdl::cdiv(P, 64) * wsdl::cdiv(Cout, 128);       // 128x64 tile
@@ -1402,7 +1402,7 @@ int igemm_ksplit(int P, int Cout, int Cin, int T, int dil) {
     return s < 2 ? 1 : (int)s;
 }
 
-int g_col_bands = 1;   // launch dilated convs per output-column band (see column_bands)
+wsdl::Opt g_col_bands{1};   // launch dilated convs per output-column band (see column_bands)
 
 int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_t ws_bytes) {
     ConvP p = p_in;
@@ -1532,7 +1532,7 @@ constexpr int kStemHalf = kStemTW + 3;              // 35 columns of one parity 
 constexpr int kStemIW = 2 * kStemHalf;              // row stride in LDS
 constexpr int kStemPlane = kStemIH * kStemIW;
 constexpr int kStemK = 148;                         // 147 + one zero row: K steps of 2
-int g_stem_kernel = 1;
+wsdl::Opt g_stem_kernel{1};
 
 __global__ __launch_bounds__(256, 2) void stem_conv7x7s2_kernel(ConvP p, int tiles_w, int tiles_h) {
     __shared__ float w_s[kStemK * 64];              // [k][cout]
@@ -1648,7 +1648,7 @@ int launch_igemm_sliced(const ConvP& p, int img_out_pixels, long long img_in_ele
 }
 
 // split count for wgrad: enough blocks to fill 256 CUs twice, at least 8 pixel chunks per split
-int g_wgrad_blocks = 768;   // target number of workgroups of a weight-gradient launch (tiles x pixel splits)
+wsdl::Opt g_wgrad_blocks{768};   // target number of workgroups of a weight-gradient launch (tiles x pixel splits)
 
 // tile of the weight-gradient GEMM: the buffer-descriptor kernel needs Cout % BM == 0 and Cin % BN == 0
 void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
@@ -1659,23 +1659,23 @@ void wgrad_tile(int Cout, int Cin, int* BM, int* BN, bool* fast) {
     *BN = *fast ? bn : 128;
 }
 
-int g_wgrad_split = 1;       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
-int g_wgrad_force_s = 0;     // experiments: fixed number of pixel splits
-int g_wgrad_dyraw = 1;       // direct-fragment kernel: dY read as fp32 and split while staged (no dy_split16_kernel pass)
-int g_wgrad_chan_scale = 0;  // fp16x2 weight-gradient kernels: one power-of-two scale per CHANNEL of x and of dY (a pre-pass takes the maxima)
-int g_wgrad_direct = 1;      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
+wsdl::Opt g_wgrad_split{1};       // weight gradients on the bf16x3-split 32-pixel-chunk kernel where the shape allows (conv_split.h)
+wsdl::Opt g_wgrad_force_s{0};     // experiments: fixed number of pixel splits
+wsdl::Opt g_wgrad_dyraw{1};       // direct-fragment kernel: dY read as fp32 and split while staged (no dy_split16_kernel pass)
+wsdl::Opt g_wgrad_chan_scale{0};  // fp16x2 weight-gradient kernels: one power-of-two scale per CHANNEL of x and of dY (a pre-pass takes the maxima)
+wsdl::Opt g_wgrad_direct{1};      // x fragments of the split weight-gradient kernel straight from global memory (conv_wgrad_split16d_kernel)
 // (fp16x2: the split weight-gradient kernels run on v_mfma_f32_16x16x32_f16; the 32x32x16 form - "wgrad_mfma16 = 0", 2 % slower on
 // the step - was an A/B option until round 4.  conv_wgrad_split32_kernel remains as the bf16x3 path.)
-int g_wgrad_xcd = 1;         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
+wsdl::Opt g_wgrad_xcd{1};         // XCD-aware tile order of the split weight-gradient kernel (0 off, 1 contiguous, 2 blocked)
 // dY is split once per launch, which pays off from about six 128-wide N tiles on (measured per shape: 1x1 convs with
 // Cin <= 512 are faster on the fp32 kernel)
 // (that was the bf16x3 kernel; the fp16x2 kernel on 16x16x32 MFMAs wins from ONE N tile on: 1x1 convs of layer2 / layer3.0
 // 76 -> 61, 41 -> 31, 63 -> 43 us.  64-row / 64-column tiles for the 64-channel layers of layer1 lost to the fp32 kernels there -
 // 87 -> 121 us on the 64 -> 64 3x3: few tiles, hundreds of slabs - and were removed in round 3.)
-int g_wgrad_min_tiles = 6;     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
+wsdl::Opt g_wgrad_min_tiles{6};     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
 bool wgrad_chunk32(int Cout, int Cin, int N) {
     if (!g_wgrad_split || Cout % 128 != 0 || Cin % 128 != 0) return false;
-    return N / 128 >= (g_conv_arith ? g_wgrad_min_tiles : std::max(g_wgrad_min_tiles, 6));
+    return N / 128 >= (g_conv_arith ? g_wgrad_min_tiles : std::max((int)g_wgrad_min_tiles, 6));
 }
 
 // taps that read at least one in-range input pixel for some output pixel (bit t of the result); the others (dilation
@@ -1706,7 +1706,7 @@ double wgrad_tap_balance(int H, int OH, int kh, int stride, int pad, int dil) {
     return hi > 0 ? (double)lo / (double)hi : 1.0;
 }
 
-int g_wgrad_imbalance_split = 1;   // one more pixel split for tap-imbalanced launches (wgrad_splits)
+wsdl::Opt g_wgrad_imbalance_split{1};   // one more pixel split for tap-imbalanced launches (wgrad_splits)
 // n_live: N counted over live taps only (the split kernel's dead-tap workgroups exit at once); tap_balance: wgrad_tap_balance
 int wgrad_splits(int Cout, int Cin, int N, int P, int n_live, double tap_balance = 1.0) {
     int BM, BN;
@@ -1792,6 +1792,10 @@ extern "C" {
 
 int wsdl_set_option(const char* name, int value) {
     WSDL_REQUIRE(name, "set_option: null name");
+    static std::mutex mu;                       // one writer at a time; readers see the old or the new value (wsdl::Opt)
+    std::lock_guard<std::mutex> lock(mu);
+    WSDL_REQUIRE(wsdl::g_plans_recording.load() == 0,
+                 "set_option(%s): a launch plan is being recorded (its launches are chosen under ONE option set)", name);
     if (!strcmp(name, "tile_threshold")) { g_tile_threshold = value; return WSDL_OK; }
     if (!strcmp(name, "bk32")) { g_bk32 = value; return WSDL_OK; }
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }

@@ -40,7 +40,7 @@
 
 #pragma clang fp contract(off)
 
-int wsdl::g_layercam_tail_mod = 32;   // "layercam_tail_mod" option (wsdl_set_option): see above
+wsdl::Opt wsdl::g_layercam_tail_mod{32};   // "layercam_tail_mod" option (wsdl_set_option): see above
 
 namespace {
 

@@ -6,8 +6,8 @@
 #include <algorithm>
 #include <cstdint>
 
-int wsdl::g_bn_resident = 1;
-int wsdl::g_bn_wide_c = 512;      // channel counts up to which the resident kernels run 1024 threads x 4 float4 ("bn_wide_c" option, 0 = never)
+wsdl::Opt wsdl::g_bn_resident{1};
+wsdl::Opt wsdl::g_bn_wide_c{512};      // channel counts up to which the resident kernels run 1024 threads x 4 float4 ("bn_wide_c" option, 0 = never)
 
 namespace {
 // i / d for the (b, hw) decompositions of the BatchNorm kernels: the plane sizes of the networks are powers of two, and

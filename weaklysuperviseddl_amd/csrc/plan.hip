@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <deque>
+#include <mutex>
 #include <vector>
 
 namespace wsdl {
@@ -51,8 +52,9 @@ struct Plan {
     }
 };
 
-Plan* g_plan_rec = nullptr;
-static Plan* g_plan_paused = nullptr;      // wsdl_plan_pause: the recording a host section interrupted
+thread_local Plan* g_plan_rec = nullptr;
+std::atomic<int> g_plans_recording{0};
+static thread_local Plan* g_plan_paused = nullptr;      // wsdl_plan_pause: the recording a host section interrupted
 
 void plan_add_kernel(const void* fn, dim3 grid, dim3 block, size_t shmem, hipStream_t s, std::shared_ptr<void> storage,
                      void* const* argv, int argc) {
@@ -96,9 +98,11 @@ hipError_t memset_async(void* dst, int value, size_t bytes, hipStream_t s) {
 // stream-waits-for-stream outside a plan: events from a ring (a wait holds on to the record it saw; re-recording the event
 // later does not disturb it)
 static hipEvent_t ring_event() {
+    static std::mutex mu;                   // the ring is shared by every host thread
     static std::vector<hipEvent_t> ring;
     static size_t next = 0;
     constexpr size_t kRing = 512;
+    std::lock_guard<std::mutex> lock(mu);
     if (ring.size() < kRing) {
         hipEvent_t e = nullptr;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
@@ -209,8 +213,9 @@ using wsdl::PlanOp;
 extern "C" {
 
 int wsdl_plan_begin(void) {
-    WSDL_REQUIRE(wsdl::g_plan_rec == nullptr, "plan_begin: a plan is already being recorded (one at a time)");
+    WSDL_REQUIRE(wsdl::g_plan_rec == nullptr, "plan_begin: this thread is already recording a plan (one at a time per host thread)");
     wsdl::g_plan_rec = new Plan();
+    wsdl::g_plans_recording.fetch_add(1);
     return WSDL_OK;
 }
 
@@ -220,6 +225,7 @@ int wsdl_plan_end(void** plan_out) {
     Plan* p = wsdl::g_plan_rec;
     WSDL_REQUIRE(p != nullptr, "plan_end: no plan is being recorded");
     wsdl::g_plan_rec = nullptr;
+    wsdl::g_plans_recording.fetch_sub(1);
     if (p->poisoned || !plan_out) {
         wsdl::set_error("plan_end: the recorded sequence cannot be replayed: %s", p->poisoned ? p->why : "no output argument");
         delete p;
@@ -231,6 +237,7 @@ int wsdl_plan_end(void** plan_out) {
 }
 
 int wsdl_plan_abort(void) {
+    if (wsdl::g_plan_rec || wsdl::g_plan_paused) wsdl::g_plans_recording.fetch_sub(1);
     delete wsdl::g_plan_rec;
     delete wsdl::g_plan_paused;
     wsdl::g_plan_paused = nullptr;

@@ -8,6 +8,8 @@ and replays it: one host call per step.
 
 What makes the step capturable (everything that used to be a host value per step now lives on the device):
   * Adam's step number           -> ``FlatAdam.step_dev`` (bias corrections computed in the kernel),
+  * Adam's lr / betas / eps / grad_scale -> ``FlatAdam.hyper_dev`` (five device floats the kernel reads; the wrapper copies
+                                    changed values there before the capture and before every replay: a schedule needs no new capture),
   * dropout masks                -> per-module device call counters mixed into a seed drawn once (``nn.Dropout``),
   * the convolutions' amax slots -> a pool allocated (and therefore re-zeroed) inside the captured region,
   * weight layouts               -> re-written IN PLACE at the end of the step, the main stream joins the side stream
@@ -74,13 +76,14 @@ class GraphedTrainStep:
     def __call__(self, images, masks):
         """One training iteration on (images, masks); returns the (device) loss, like ``train_step``."""
         self.calls += 1
-        # the Adam launch takes lr / betas / eps / grad_scale as kernel ARGUMENTS, frozen into the captured node: a scheduler,
-        # a manual decay or a data-parallel reducer changing one of them must trigger a new capture, not be ignored
+        # the Adam kernel reads lr / betas / eps / grad_scale from device memory (FlatAdam.hyper_dev): a scheduler, a manual
+        # decay or a data-parallel reducer changing one of them changes memory, not the captured node - no new capture, but the
+        # copy has to happen OUTSIDE the capture and before each replay (sync_hyper refuses to run inside one)
         opt = self.opt
-        key = (tuple(images.shape), tuple(masks.shape), images.device, self.model.training,
-               float(opt.lr), tuple(float(b) for b in opt.betas), float(opt.eps), float(opt.grad_scale))
+        key = (tuple(images.shape), tuple(masks.shape), images.device, self.model.training)
         if self.calls <= self.warmup or not self.model.training:
             return self._eager(images, masks)
+        opt.sync_hyper()
         if self.graph is None or key != self.key:
             self.key = key
             self._capture(images, masks)

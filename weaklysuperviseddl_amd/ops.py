@@ -6,6 +6,8 @@ import ctypes as C
 
 import os
 
+import threading
+
 import torch
 
 from ._lib import lib, check, WsdlError
@@ -33,10 +35,26 @@ def _stream():
 # While a plan is being recorded, PLAN_REC[0] is the recording.  Everything the recorded launches touch must outlive the
 # plan AT ITS ADDRESS: every tensor whose pointer is handed to the library meanwhile is kept by the recording (``_p``), so
 # the caching allocator can never give its block to anybody else - no private memory pool needed.
-PLAN_REC = [None]
+# Both are PER HOST THREAD (as the C side's recording is: csrc/plan.hip): a second thread that uses the library while this
+# one records - a loader worker, a second model - launches normally, pins nothing into this thread's recording and may
+# record a plan of its own.
+class _ThreadSlot(threading.local):
+    """``slot[0]`` with one value per host thread."""
+
+    def __init__(self, default):            # (threading.local calls this once per thread that touches the slot)
+        self.v = default
+
+    def __getitem__(self, i):
+        return self.v
+
+    def __setitem__(self, i, value):
+        self.v = value
 
 
-PLAN_REPLAYING = [False]     # a plan with host sections is being replayed (the sections run live, in their places)
+PLAN_REC = _ThreadSlot(None)
+
+
+PLAN_REPLAYING = _ThreadSlot(False)     # a plan with host sections is being replayed (the sections run live, in their places)
 
 
 def host_section(fn, *args):

@@ -191,9 +191,17 @@ class FlatAdam:
         self._backward_pending = False
 
     def sync_hyper(self):
-        """Copy (lr, beta1, beta2, eps, grad_scale) to the device when one of them changed since the last call."""
+        """Copy (lr, beta1, beta2, eps, grad_scale) to the device when one of them changed since the last call.
+
+        Never inside a stream capture: the copy is a pageable host-to-device transfer (illegal in a hipGraph capture, and a
+        captured copy would freeze the values anyway).  ``GraphedTrainStep`` calls this BEFORE it captures and before every
+        replay, so the captured Adam node reads current values from ``hyper_dev``; a change that turns up while a capture is
+        running is an error, not something to skip silently."""
         cur = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.grad_scale))
         if self.hyper_dev is not None and cur != self._hyper_host:
+            if self.hyper_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdam.sync_hyper: lr / betas / eps / grad_scale changed inside a stream capture; change "
+                                   "them between steps (GraphedTrainStep copies them to the device before each replay)")
             self.hyper_dev.copy_(torch.tensor(cur, dtype=torch.float32))
             self._hyper_host = cur
 

@@ -160,15 +160,21 @@ class PlannedTrainStep:
         self._convs = [m for m in model.modules() if isinstance(m, wnn.Conv2d)]
         self._dropouts = [m for m in model.modules() if isinstance(m, wnn.Dropout)]
         self._hooks = _hook_tables(model)
+        self.loss_scalars = None        # host scalars of the step's loss objects (train_step sets it per call: ``host_scalars``)
 
-    # -- what must be equal for a recorded plan to stand for the call
+    # -- what must be equal for a recorded plan to stand for the call: a plan freezes every HOST scalar that was a kernel
+    # argument when it was recorded - BatchNorm's momentum / eps, a dropout's p, a loss object's weights and window sizes.  They
+    # are all part of the key, so changing one records a new plan instead of being ignored; what changes every step belongs in
+    # device memory (as Adam's hyper-parameters are), or the step falls back to eager ("the step's key keeps changing").
     def _key(self, images, masks):
         opt = self.opt
         red = getattr(opt, "_wsdl_reducer", None)
         # (lr, betas, eps, grad_scale are NOT part of the key: the Adam kernel reads them from device memory - optim.FlatAdam.hyper_dev)
         return (tuple(images.shape), images.dtype, tuple(masks.shape), images.device,
                 None if red is None else (id(red), id(red._steady_set)),
-                tuple(b.training for b in self._bns), tuple(p.requires_grad for p in opt.params), ops.LAYOUT_EPOCH[0],
+                tuple((b.training, b.momentum, b.eps) for b in self._bns),
+                tuple((d.training, float(d.p)) for d in self._dropouts), self.loss_scalars,
+                tuple(p.requires_grad for p in opt.params), ops.LAYOUT_EPOCH[0],
                 ops.CONV_ARITH[0], ops.OVERLAP_WGRAD[0], ops.WGRAD_AFTER_DGRAD[0], ops.BN_RELU_BITS[0], ops.IDENTITY_LINK[0], ops.ASPP_MULTI[0], ops.ASPP_GROUP_FWD[0],
                 ops.raw_stream(images.device))
 
@@ -216,11 +222,34 @@ class PlannedTrainStep:
         pend0 = [b._pending_steps for b in self._bns]
         torch.cuda.synchronize(dev)
         ops.reset_amax_pool(dev)            # the first slot request inside the recording allocates a pool and memsets it there
+
+        def restore(snap):
+            for t, b in zip(state, snap):
+                t.copy_(b)
+            self._relayout()                # the layouts the step's forward reads belong to the restored parameters
+
+        def reset_host(count, pend):
+            opt.step_count = count
+            for b, p in zip(self._bns, pend):
+                b._pending_steps = p
+
+        count0 = opt.step_count
         try:
             plan, loss = record(self.eager, self.s_images, self.s_masks)
         except PlanError as e:              # (the recorded call itself ran normally: a real training step was taken)
             self.disabled = f"recording failed: {e}"
             return e.result
+        except Exception as e:              # the step itself failed while every tensor it touched was pinned by the recording
+            # (out of memory first of all: a recording keeps all activations AND all normally transient gradients / workspaces
+            # alive).  The step may be half done: back to the state before it, the recording's memory released, and the step
+            # is taken eagerly - if it fails there too that error is the caller's.
+            self.disabled = f"recording failed: {type(e).__name__}: {e}"
+            del e
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
+            restore(before)
+            reset_host(count0, pend0)
+            return self.eager(images, masks)
         finally:
             ops.reset_amax_pool(dev)        # eager code must not hand out the plan's slots
         self._bn_delta = [(b, b._pending_steps - p0) for b, p0 in zip(self._bns, pend0) if b._pending_steps != p0]
@@ -230,21 +259,20 @@ class PlannedTrainStep:
         # ---- verification (bit for bit), on a PROBE batch: with the recorded inputs a kernel the plan did not see would go
         # unnoticed - its output from the recorded run is still in memory and still right.  So: (1) back to the state before
         # the step, one EAGER step on a different batch -> reference; (2) back again, the same batch through the REPLAY ->
-        # must equal the reference; (3) forward to the state the real step left.
+        # must equal the reference; (3) forward to the state the real step left.  Step (3) and the host counters are restored
+        # WHATEVER happens in between (an out-of-memory error in the probe step - it runs on top of the recording's pinned
+        # tensors, about twice an eager step's peak - must not cost the caller the real step it has already taken).
         after = [t.clone() for t in state]
+        grad_after = opt.flat_grad.clone()
         loss_real = loss.detach().clone()
         host1 = (opt.step_count, [b._pending_steps for b in self._bns])
-
-        def restore(snap):
-            for t, b in zip(state, snap):
-                t.copy_(b)
-            self._relayout()                # the layouts the step's forward reads belong to the restored parameters
 
         probe_img = self.s_images * 0.75 + 0.1
         probe_masks = 1 - torch.clamp(self.s_masks, max=1)
         red = getattr(opt, "_wsdl_reducer", None)
         if red is not None:
             red._local_only = True          # data parallel: the two verification steps exchange nothing (dp.GradBucketReducer)
+        bad, loss_same, failure = None, False, None
         try:
             restore(before)
             ref_loss = self.eager(probe_img, probe_masks).clone()
@@ -253,15 +281,24 @@ class PlannedTrainStep:
             self.s_images.copy_(probe_img)
             self.s_masks.copy_(probe_masks)
             plan.replay()
+            bad = [i for i, (t, a) in enumerate(zip(state, ref)) if not torch.equal(t, a)]
+            loss_same = torch.equal(loss.detach(), ref_loss)
+        except Exception as e:
+            failure = f"{type(e).__name__}: {e}"
         finally:
             if red is not None:
                 red._local_only = False
-        bad = [i for i, (t, a) in enumerate(zip(state, ref)) if not torch.equal(t, a)]
-        loss_same = torch.equal(loss.detach(), ref_loss)
-        restore(after)
-        opt.step_count = host1[0]
-        for b, p1 in zip(self._bns, host1[1]):
-            b._pending_steps = p1
+            if failure is not None:
+                torch.cuda.synchronize(dev)
+                ref = ref_loss = None       # (what the failed attempt still holds)
+                torch.cuda.empty_cache()
+            restore(after)
+            reset_host(*host1)
+            opt.flat_grad.copy_(grad_after)     # p.grad holds the REAL step's gradients again, not the probe batch's
+        if failure is not None:
+            self.disabled = "verification could not run (" + failure + "): the step stays eager"
+            del plan
+            return loss_real
         if bad or not loss_same:
             self.disabled = ("verification failed: the replayed step differs from the eager one ("
                              + (f"{len(bad)} of {len(state)} state tensors" if bad else "the loss value")
@@ -339,6 +376,51 @@ class PlannedTrainStep:
             cache["prep_key"] = (ep, w._version, w.data_ptr())
         self.opt.range_poll()                   # the sentinel's host side (the check kernel itself is part of the plan)
         return ent.s_loss.clone()
+
+
+_SCALARS = (bool, int, float, str, type(None))
+
+
+def host_scalars(obj, _depth=0):
+    """The host scalars a loss object would turn into kernel arguments - hashable.  Objects: their own (and, for torch modules,
+    their sub-modules') int / float / bool / str attributes; functions: their defaults and the scalars in their closure cells
+    (objects in cells one level deep).  Part of a plan's key: a loss weight ramped per epoch records a new plan instead of being
+    frozen at the value of the recorded step.  A loss that wants a value to change WITHOUT a new plan keeps it in a device
+    tensor."""
+    if obj is None or _depth > 2:
+        return None
+    if isinstance(obj, _SCALARS):
+        return obj
+    if torch.is_tensor(obj):
+        return ("tensor", obj.data_ptr(), tuple(obj.shape)) if obj.is_cuda else ("host-tensor", tuple(obj.flatten().tolist()[:16]))
+    if isinstance(obj, (tuple, list)):
+        return tuple(host_scalars(v, _depth + 1) for v in obj[:16])
+    code = getattr(obj, "__code__", None)
+    if code is not None:                    # a function / lambda
+        cells = tuple(host_scalars(c.cell_contents, _depth + 1) for c in (obj.__closure__ or ()))
+        return ("fn", tuple(host_scalars(d, _depth + 1) for d in (obj.__defaults__ or ())), cells)
+    d = getattr(obj, "__dict__", None)
+    if d is None:
+        return None
+    own = tuple(sorted((k, v) for k, v in d.items() if isinstance(v, _SCALARS) and not k.startswith("__")))
+    if isinstance(obj, torch.nn.Module):
+        own += tuple(host_scalars(m, _depth + 1) for m in obj.children())
+    return (type(obj).__name__, own)
+
+
+def loss_tag(obj):
+    """Which PlannedTrainStep a loss object belongs to.  An object: itself (``id``).  A plain function or lambda: its CODE and
+    the identities of what it captured - a ``lambda o, i: 0.1 * ncut(o, i)`` written inline in the training loop is a new
+    function object on every call, but the same step (keyed on ``id`` it would never get past the warm-up calls and would
+    churn PlannedTrainStep objects without a word)."""
+    if obj is None:
+        return None
+    code = getattr(obj, "__code__", None)
+    if code is None:
+        return id(obj)
+    cells = tuple(c.cell_contents if isinstance(c.cell_contents, _SCALARS) else id(c.cell_contents) for c in (obj.__closure__ or ()))
+    return (code, id(getattr(obj, "__self__", None)), tuple(type(x).__name__ for x in cells),
+            tuple(x for x in cells if not isinstance(x, (int, float)) or isinstance(x, bool)))
 
 
 def planned_step_for(model, optimizer, eager, tag):
