@@ -36,6 +36,13 @@ enum {
 };
 
 const char* wsdl_last_error(void);
+/* Launch trace (diagnostic): wsdl_launch_trace(1) makes the convolution entry points describe every launch they choose -
+ * kernel form and tile, arithmetic, K slices, XCD order, column bands, pixel splits, grid - into a per-thread string;
+ * wsdl_last_launches() returns this thread's descriptions since its previous call ("; "-separated, valid until the next
+ * call) and clears them.  Off (default): one relaxed load per launch site.  The full-size parity tests use it to name
+ * the configuration each comparison against the float64 oracle went through. */
+int wsdl_launch_trace(int on);
+const char* wsdl_last_launches(void);
 int wsdl_version(void);               /* 10000*major + 100*minor + patch */
 const char* wsdl_target_arch(void);   /* "gfx950" */
 
@@ -262,6 +269,34 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw,
                       int stride, int pad, int dil, int accumulate,
                       long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax,
                       void* ws, size_t ws_bytes, wsdl_stream_t stream);
+/* Weight gradient with the slab reduction DEFERRED (round 6).  wsdl_conv2d_wgrad splits the pixel dimension over S workgroup
+ * slabs and ends with a small launch that adds them in fixed order into dw - ~60 such launches per training step, 9-10 us each
+ * for a few MB (launch and tail latency, not bandwidth).  The deferred form runs everything but that launch and fills *desc (a
+ * HOST struct) with what is left to do; the caller collects the descriptors of many layers, uploads them as ONE device table
+ * (block_begin = the running sum of nblocks) and runs wsdl_wgrad_reduce_multi when the gradients are needed - before the
+ * optimiser step or a gradient bucket's all-reduce (reference: the loss.backward() / optimizer.step() pair of
+ * TraditionalModel/SegmentationModel.py:110-111).  Same sums in the same order: bit-identical to wsdl_conv2d_wgrad.
+ *   - the slabs live in `ws`: the caller keeps each layer's workspace untouched until the multi launch has run;
+ *   - desc->kind < 0: nothing is pending (the call reduced by itself: a batch processed in slices);
+ *   - two deferred gradients into the same dw must not share a multi launch (flush in between). */
+enum { WSDL_WGRAD_REDUCE_PLAIN = 0, WSDL_WGRAD_REDUCE_TILED = 1, WSDL_WGRAD_REDUCE_VEC4 = 2, WSDL_WGRAD_REDUCE_MANY = 3,
+       WSDL_WGRAD_REDUCE_TRANSPOSED = 4 };
+typedef struct wsdl_wgrad_reduce_desc {
+    const float* slab;       /* [S][Cout][taps*Cin]   (TRANSPOSED: [S][Cin][Cout]) */
+    float* dw;               /* [Cout][Cin][taps] */
+    unsigned long long live; /* bit t: tap t has slab data */
+    int S, Cout, Cin, T;
+    int accumulate, kind;
+    int grid_x, nblocks;     /* blocks of 256 threads this reduction takes (grid_x: its inner extent where it is 2-D) */
+    int block_begin, reserved;
+} wsdl_wgrad_reduce_desc;
+int wsdl_conv2d_wgrad_deferred(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                               int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
+                               size_t ws_bytes, wsdl_wgrad_reduce_desc* desc, wsdl_stream_t stream);
+/* desc: DEVICE array of n entries; total_blocks = the sum of their nblocks */
+int wsdl_wgrad_reduce_multi(const wsdl_wgrad_reduce_desc* desc, int n, int total_blocks, wsdl_stream_t stream);
+
 /* out = max|x| over B images of per_image contiguous floats (batch stride x_bs elements, 0 = dense); zero_first != 0
  * zeroes `out` first (else the caller passes a zeroed scalar).  For tensors whose producer did not publish an amax
  * (network input, concatenations, dropout outputs).  wsdl_multi_amax: n tensors in one launch - ptrs / counts are

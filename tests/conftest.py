@@ -68,3 +68,25 @@ def smooth_image(B, H, W, seed):
                 img[b, c] += 0.25 * torch.sin(6.28 * (fy * yy + fx * xx) + ph)
     img = img * 0.5 + 0.5 + 0.01 * torch.randn(B, 3, H, W, generator=g)
     return img.clamp(0, 1)
+
+
+@pytest.fixture(autouse=True)
+def _range_guard_is_pinned_inside_tests():
+    """WSDL_RANGE_GUARD=auto (the product's default since round 6) switches process-wide library options on when a step's tensors
+    leave the fp16x2 arithmetic's safe range - small random-init test networks do that now and then (GPUTEST_r05: 2^28 at B = 4,
+    64 x 64).  The tests compare runs bit for bit under ONE option set, so inside a test the sentinel only warns; the tests
+    of the guard itself select "auto" explicitly, and nothing a test switched on survives it."""
+    try:
+        from weaklysuperviseddl_amd import optim
+    except Exception:
+        yield
+        return
+    old = optim.RANGE_GUARD[0]
+    optim.RANGE_GUARD[0] = "warn"
+    yield
+    optim.RANGE_GUARD[0] = old
+    if optim.RANGE_GUARD_ACTIVE[0]:
+        from weaklysuperviseddl_amd import ops
+        ops.set_option("conv_arith", 1)
+        ops.set_option("wgrad_chan_scale", 0)
+        optim.RANGE_GUARD_ACTIVE[0] = False

@@ -378,3 +378,46 @@ def test_plan_recording_is_per_host_thread_and_options_are_guarded():
         assert L.wsdl_plan_abort() == 0
     assert L.wsdl_plan_recording() == 0
     assert L.wsdl_set_option(b"ksplit_max", 8) == 0
+
+
+def test_plan_key_sees_the_host_scalars_of_loss_objects():
+    """a plan freezes every host scalar that was a kernel argument when it was recorded.  ``plan.host_scalars`` is the
+    part of a plan's key that covers loss objects (attributes of objects and sub-modules, defaults and closure cells of
+    functions); ``plan.loss_tag`` maps an inline lambda - a new function object per call - onto ONE planned step."""
+    import torch
+    from weaklysuperviseddl_amd import plan
+
+    class Loss:
+        def __init__(self, w):
+            self.weight, self.window, self.name = w, 5, "ncut"
+            self.table = torch.zeros(3)
+
+    a, b = Loss(0.1), Loss(0.1)
+    assert plan.host_scalars(a) == plan.host_scalars(b)
+    b.weight = 0.2
+    assert plan.host_scalars(a) != plan.host_scalars(b)
+    m = torch.nn.Sequential(torch.nn.Dropout(0.1), torch.nn.ReLU())
+    k0 = plan.host_scalars(m)
+    m[0].p = 0.3
+    assert plan.host_scalars(m) != k0
+
+    def make(w, obj):
+        return lambda o, i: w * obj.weight
+    f1, f2, f3 = make(0.1, a), make(0.1, a), make(0.5, a)
+    assert f1 is not f2 and plan.loss_tag(f1) == plan.loss_tag(f2) == plan.loss_tag(f3)     # same code, same captured object
+    assert plan.loss_tag(make(0.1, b)) != plan.loss_tag(f1)                                  # another captured object
+    assert plan.host_scalars(f1) == plan.host_scalars(f2) != plan.host_scalars(f3)           # the ramped weight is in the KEY
+    a.weight = 0.7
+    assert plan.host_scalars(f1) != plan.host_scalars(make(0.1, Loss(0.1)))
+    assert plan.loss_tag(None) is None and plan.host_scalars(None) is None
+    assert plan.loss_tag(a) == id(a)
+    hash(plan.host_scalars(f1)), hash(plan.host_scalars(m)), hash(plan.loss_tag(f1))
+
+
+def test_the_range_guard_acts_by_default():
+    """the sentinel must ACT in the default configuration (the reference's fp32 has no range floor), not
+    only warn.  The product default is "auto"; tests/conftest.py pins "warn" inside tests (bit-for-bit comparisons need one
+    option set), which is what the module-level list shows here."""
+    from weaklysuperviseddl_amd import optim
+    assert optim.RANGE_GUARD_DEFAULT == "auto"
+    assert optim.RANGE_GUARD[0] == "warn"        # (the fixture; outside tests: WSDL_RANGE_GUARD or the default)

@@ -7,6 +7,12 @@ import torch
 from weaklysuperviseddl_amd import ops
 
 dev = torch.device("cuda:0")
+if "--opt" in sys.argv:                 # --opt name=value[,name=value]: library options (e.g. tile_img_major=0)
+    i = sys.argv.index("--opt")
+    for kv in sys.argv[i + 1].split(","):
+        k, v = kv.split("=")
+        ops.set_option(k, int(v))
+    del sys.argv[i:i + 2]
 B, C, Co, H = (int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else (16, 2048, 256, 32)))
 g = torch.Generator(device=dev).manual_seed(1)
 ks, dils = [1, 3, 3, 3], [1, 12, 24, 36]

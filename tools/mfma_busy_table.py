@@ -1,13 +1,36 @@
-"""Summarise tools/mfma_busy_3x3.sh: per (3x3 shape, pass) the MFMA-busy fraction of the MFMA kernel of that pass.
-busy = SQ_VALU_MFMA_BUSY_CYCLES (summed over the chip's SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
+"""Summarise tools/mfma_busy_3x3.sh: MFMA-busy fraction of the 3x3 convolutions AS THE TRAINING STEP RUNS THEM.
+
+Per (3x3 shape, pass) one rocprofv3 --pmc run of tools/one_conv.py gives, per kernel, SQ_VALU_MFMA_BUSY_CYCLES (summed over
+the chip's SIMDs) and GRBM_GUI_ACTIVE (summed over the 8 XCDs).  busy = MFMA-busy cycles / SIMD-cycles, SIMD-cycles =
+GRBM_GUI_ACTIVE / 8 x 1024.
+
+VERDICT r5 weak 4 corrected two things in the aggregate:
+  * every (shape, pass) is weighted by its LAUNCHES PER STEP (layer3's conv2 runs five times, layer4's d4 twice,
+    layer1 / layer2's three times, layer3.0 + the head's 3x3 twice) - rounds 3-5 added every unique shape once;
+  * a pass's denominator holds the cycles of its SATELLITE launches too - the dY pre-split, the slab reduces, the split-K reduce,
+    the per-channel maxima of the range guard: kernels whose only job is to feed or finish the matrix kernel - not only "the conv
+    kernel with the most busy cycles".
+The per-row figure stays the matrix kernel's own busy fraction (a property of the kernel); the column `with satellites` and the
+totals are the step-weighted ones - the number north_star's ">= 40 % MFMA util on the 3x3 convs" is read against.
+"""
 import collections
 import csv
 import glob
 import sys
 
 O = sys.argv[1]
-print(f"{'shape':22s} {'pass':6s} {'kernel':58s} {'launches':>8s} {'MFMA busy':>10s} {'cycles/launch':>14s}")
-tot = collections.defaultdict(lambda: [0.0, 0.0])
+# launches per training step of each measured shape (DeepLabV3-ResNet50 with the aux head computed)
+PER_STEP = {"l1.conv2": 3, "l2.0.conv2_s2": 1, "l2.conv2": 3, "l3.0.conv2/head3x3": 2, "l3.conv2_d2": 5, "l4.0.conv2_d2": 1,
+            "l4.conv2_d4": 2, "aspp_d12": 1, "aspp_d24": 1, "aspp_d36": 1, "aux3x3": 1, "aspp_4branches": 1}
+SATELLITES = ("dy_split", "wgrad_reduce", "conv_splitk_reduce", "channel_amax", "transpose_add", "wgrad_multi_reduce")
+
+
+def short(k):
+    return k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+
+
+print(f"{'shape':20s} {'pass':6s} {'x/step':>6s} {'matrix kernel':62s} {'busy':>6s} {'with satellites':>15s} {'cycles/launch':>13s} {'+satellite cycles':>17s}")
+tot = collections.defaultdict(lambda: [0.0, 0.0, 0.0])      # pass -> [busy cycles, matrix-kernel SIMD cycles, all SIMD cycles], step-weighted
 lines = [l.split() for l in open(O + "/index.txt")]
 grouped = {ps for name, ps, _g in lines if name == "aspp_4branches"}       # passes the step runs as one launch for all ASPP branches
 for name, ps, geo in lines:
@@ -15,23 +38,30 @@ for name, ps, geo in lines:
     f = glob.glob(f"{O}/{tag}_{ps}/**/*_counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
-        c = acc[k][r["Counter_Name"]]
+        c = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
         c[0] += 1
         c[1] += float(r["Counter_Value"])
-    # the pass's MFMA kernel = the conv kernel with the most MFMA-busy cycles
+    # the pass's matrix kernel = the conv kernel with the most MFMA-busy cycles; its satellites by name
     best = max((k for k in acc if k.startswith("conv_") and "reduce" not in k), key=lambda k: acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1])
     n, busy = acc[best]["SQ_VALU_MFMA_BUSY_CYCLES"]
     _, gui = acc[best]["GRBM_GUI_ACTIVE"]
-    simd_cycles = gui / 8.0 * 1024.0
+    simd = gui / 8.0 * 1024.0
+    # satellites run once per launch of the matrix kernel: their cycles per matrix launch
+    sat_gui = sum(acc[k]["GRBM_GUI_ACTIVE"][1] for k in acc if any(s in k for s in SATELLITES))
+    sat_busy = sum(acc[k]["SQ_VALU_MFMA_BUSY_CYCLES"][1] for k in acc if any(s in k for s in SATELLITES))
+    sat_simd = sat_gui / 8.0 * 1024.0
     single = name in ("aspp_d12", "aspp_d24", "aspp_d36") and ps in grouped
-    print(f"{name:22s} {ps:6s} {best:58s} {n:8d} {busy / simd_cycles:10.3f} {gui / 8.0 / n:14.0f}"
-          + ("   (single launch: not in the step, not in the totals)" if single else ""))
+    w = PER_STEP.get(name, 1)
+    print(f"{name:20s} {ps:6s} {w:6d} {best:62s} {busy / simd:6.3f} {(busy + sat_busy) / (simd + sat_simd):15.3f} {gui / 8.0 / n:13.0f} "
+          f"{sat_gui / 8.0 / n:17.0f}" + ("   (single launch: the step runs the 4-branch launch below; not in the totals)" if single else ""))
     if single:
         continue
-    tot[ps][0] += busy
-    tot[ps][1] += simd_cycles
-    tot["all"][0] += busy
-    tot["all"][1] += simd_cycles
-for ps, (b, c) in tot.items():
-    print(f"{'3x3 convolutions':22s} {ps:6s} {'(cycle-weighted over the shapes above, one launch each)':58s} {'':8s} {b / c:10.3f}")
+    for key in (ps, "all"):
+        tot[key][0] += w * (busy + sat_busy) / n
+        tot[key][1] += w * simd / n
+        tot[key][2] += w * (simd + sat_simd) / n
+print()
+for ps in ("fwd", "dgrad", "wgrad", "all"):
+    if ps in tot:
+        b, c, call = tot[ps]
+        print(f"3x3 convolutions {ps:6s} step-weighted (launches per step): matrix kernels alone {b / c:6.3f}   with their satellite launches {b / call:6.3f}")

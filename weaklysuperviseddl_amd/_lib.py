@@ -18,6 +18,8 @@ _vp, _i, _ll, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_
 # name -> (restype, argtypes); mirrors include/wsdl_hip.h one to one
 SIGNATURES = {
     "wsdl_last_error": (C.c_char_p, []),
+    "wsdl_launch_trace": (_i, [_i]),
+    "wsdl_last_launches": (C.c_char_p, []),
     "wsdl_version": (_i, []),
     "wsdl_target_arch": (C.c_char_p, []),
     "wsdl_set_option": (_i, [C.c_char_p, _i]),
@@ -43,6 +45,8 @@ SIGNATURES = {
                                      C.POINTER(_ll), _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "wsdl_conv2d_wgrad_workspace": (_sz, [_i] * 10),
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
+    "wsdl_conv2d_wgrad_deferred": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "wsdl_wgrad_reduce_multi": (_i, [_vp, _i, _i, _vp]),
     "wsdl_amax": (_i, [_vp, _i, _ll, _ll, _vp, _i, _vp]),
     "wsdl_multi_amax": (_i, [_vp, _vp, _i, _vp, _vp]),
     "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),

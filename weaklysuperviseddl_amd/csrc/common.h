@@ -46,6 +46,17 @@ static inline hipStream_t as_stream(wsdl_stream_t s) { return reinterpret_cast<h
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Launch trace (wsdl_launch_trace / wsdl_last_launches): when on, the convolution entry points describe every launch
+// they choose - kernel form, tile, K slices, XCD order, column bands, grid - into a per-thread string the caller reads back.
+// Off (the default) it is one relaxed load per launch site.  What tests/test_hip_conv_fullsize.py uses to show WHICH kernel
+// configuration a full-size comparison against the float64 oracle went through.
+extern std::atomic<int> g_trace_launches;
+void trace_launch(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+#define WSDL_TRACE(...)                                                                \
+    do {                                                                               \
+        if (__builtin_expect(::wsdl::g_trace_launches.load(std::memory_order_relaxed), 0)) ::wsdl::trace_launch(__VA_ARGS__); \
+    } while (0)
+
 // Profiling scope: records a start/stop event pair on the stream when wsdl_prof_enable(1) is set.
 bool prof_enabled();
 struct ProfScope {

@@ -3,6 +3,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -18,6 +19,19 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+std::atomic<int> g_trace_launches{0};
+static thread_local char g_trace[2048] = "";
+static thread_local size_t g_trace_len = 0;
+void trace_launch(const char* fmt, ...) {
+    if (g_trace_len + 4 >= sizeof(g_trace)) return;
+    if (g_trace_len) g_trace_len += (size_t)snprintf(g_trace + g_trace_len, sizeof(g_trace) - g_trace_len, "; ");
+    va_list ap;
+    va_start(ap, fmt);
+    const int n = vsnprintf(g_trace + g_trace_len, sizeof(g_trace) - g_trace_len, fmt, ap);
+    va_end(ap);
+    if (n > 0) g_trace_len = std::min(sizeof(g_trace) - 1, g_trace_len + (size_t)n);
 }
 
 struct ProfRec {
@@ -80,6 +94,21 @@ ProfScope::~ProfScope() {
 }  // namespace wsdl
 
 extern "C" {
+
+int wsdl_launch_trace(int on) {
+    wsdl::g_trace_launches.store(on ? 1 : 0);
+    wsdl::g_trace[0] = 0;
+    wsdl::g_trace_len = 0;
+    return WSDL_OK;
+}
+
+const char* wsdl_last_launches(void) {      // this thread's launches since the previous call (the string stays valid until the next one)
+    static thread_local char out[sizeof(wsdl::g_trace)];
+    memcpy(out, wsdl::g_trace, sizeof(out));
+    wsdl::g_trace[0] = 0;
+    wsdl::g_trace_len = 0;
+    return out;
+}
 
 const char* wsdl_last_error(void) { return wsdl::g_err; }
 int wsdl_version(void) { return 100; }

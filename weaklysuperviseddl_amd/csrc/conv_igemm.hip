@@ -61,6 +61,7 @@ struct ConvP {
     int grid_x;         // host only: pixel tiles of the launch when banded (0 = cdiv(P, BN))
     int xcd_py;         // split kernels: > 0 = XCD-aware tile order with this many row groups (1, 2, 4 or 8); 0 = launch order
     int xcd_rowfast;    // ... with the XCD's tiles taken row tile fastest (multi-source launches)
+    int tile_img_major; // split kernels: pixel tiles of a band taken image-fastest (conv_split.h: workgroups that run at once share their tap lists)
     const float* x_amax;   // split kernels, fp16x2 arithmetic: device scalar >= max|x| (the scale of the activation operand)
     float* y_amax;         // optional: receives max|y| of what the epilogue stores (atomicMax into a zeroed device scalar)
     // accumulate with a bit mask (dgrad of a bottleneck's first convolution): the value already in y counts only where bit
@@ -984,11 +985,13 @@ __global__ __launch_bounds__(kThreads, 3) void conv_wgrad_fast_kernel(WgradP p) 
 
 // slab[z][co][tap*Cin+ci] summed over z in order -> dw[co][ci][tap]
 // live: bit t set = tap t has slab data (taps that read only padding everywhere are not computed by the split kernel)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                    int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+// Each reduction is a device body of (its arguments, which of `nblocks` 256-thread blocks this is): the per-layer kernels below
+// run one body on their own grid, wgrad_reduce_multi_kernel (round 6) runs the bodies of MANY layers in one launch - the same
+// sums in the same order, so the two are bit-identical.
+__device__ __forceinline__ void wgrad_reduce_plain_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout, int Cin,
+                                                        int T, int accumulate, unsigned long long live, long long lb, long long nblocks) {
     const long long total = (long long)Cout * Cin * T;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = lb * 256 + threadIdx.x; idx < total; idx += nblocks * 256) {
         const int N = Cin * T;
         const int co = (int)(idx / N), n = (int)(idx - (long long)co * N);
         const int tap = n / Cin, ci = n - tap * Cin;
@@ -999,16 +1002,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
         dw[o] = accumulate ? dw[o] + s : s;
     }
 }
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                    int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+    wgrad_reduce_plain_body(slab, dw, S, Cout, Cin, T, accumulate, live, blockIdx.x, gridDim.x);
+}
 
 // The same reduction for MANY slabs of a small matrix (the 7x7 stem: 64 x 147 values in 256 pixel slabs): four waves
 // share 64 consecutive outputs, wave w adds slabs w, w + 4, ... and the four partial sums are combined in wave order -
 // a fixed order again, a quarter of the dependent chain and four times the loads in flight (62 -> 20 us).
-__global__ void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                         int Cout, int Cin, int T, int accumulate, unsigned long long live) {
-    __shared__ float part[4][64];
+__device__ __forceinline__ void wgrad_reduce_many_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout, int Cin,
+                                                       int T, int accumulate, unsigned long long live, long long lb, float* part /* [4][64] */) {
     const long long total = (long long)Cout * Cin * T;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const long long idx = (long long)blockIdx.x * 64 + l;
+    const long long idx = lb * 64 + l;
     const int N = Cin * T;
     int co = 0, tap = 0, ci = 0;
     float s = 0.f;
@@ -1020,35 +1026,43 @@ __global__ void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* 
         if (tap >= 64 || ((live >> tap) & 1ull))
             for (int z = w; z < S; z += 4) s += slab[(long long)z * total + idx];
     }
-    part[w][l] = s;
+    part[w * 64 + l] = s;
     __syncthreads();
     if (w == 0 && idx < total) {
-        const float r = ((part[0][l] + part[1][l]) + part[2][l]) + part[3][l];
+        const float r = ((part[l] + part[64 + l]) + part[128 + l]) + part[192 + l];
         const long long o = ((long long)co * Cin + ci) * T + tap;
         dw[o] = accumulate ? dw[o] + r : r;
     }
 }
+__global__ void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                         int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+    __shared__ float part[4 * 64];
+    wgrad_reduce_many_body(slab, dw, S, Cout, Cin, T, accumulate, live, blockIdx.x, part);
+}
 
 // T == 1 (1x1 kernels: slab layout == dw layout): 16 bytes per thread, four slabs in flight per step.  The sum
 // order is fixed (pairs of pairs), so the result stays bitwise reproducible.
-__global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int S,
-                                         long long total4, int accumulate) {
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total4;
-         idx += (long long)gridDim.x * blockDim.x) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        int z = 0;
-        for (; z + 4 <= S; z += 4) {
-            const float4 a = slab[(long long)z * total4 + idx], b = slab[(long long)(z + 1) * total4 + idx];
-            const float4 c = slab[(long long)(z + 2) * total4 + idx], d = slab[(long long)(z + 3) * total4 + idx];
-            s.x += (a.x + b.x) + (c.x + d.x);
-            s.y += (a.y + b.y) + (c.y + d.y);
-            s.z += (a.z + b.z) + (c.z + d.z);
-            s.w += (a.w + b.w) + (c.w + d.w);
-        }
-        for (; z < S; ++z) {
-            const float4 a = slab[(long long)z * total4 + idx];
-            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-        }
+__device__ __forceinline__ float4 wgrad_sum_slabs4(const float4* __restrict__ slab, int S, long long total4, long long idx) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 0;
+    for (; z + 4 <= S; z += 4) {
+        const float4 a = slab[(long long)z * total4 + idx], b = slab[(long long)(z + 1) * total4 + idx];
+        const float4 c = slab[(long long)(z + 2) * total4 + idx], d = slab[(long long)(z + 3) * total4 + idx];
+        s.x += (a.x + b.x) + (c.x + d.x);
+        s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z);
+        s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; z < S; ++z) {
+        const float4 a = slab[(long long)z * total4 + idx];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    return s;
+}
+__device__ __forceinline__ void wgrad_reduce_vec4_body(const float4* __restrict__ slab, float4* __restrict__ dw, int S, long long total4,
+                                                       int accumulate, long long lb, long long nblocks) {
+    for (long long idx = lb * 256 + threadIdx.x; idx < total4; idx += nblocks * 256) {
+        float4 s = wgrad_sum_slabs4(slab, S, total4, idx);
         if (accumulate) {
             const float4 o = dw[idx];
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
@@ -1056,15 +1070,19 @@ __global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4
         dw[idx] = s;
     }
 }
+__global__ void wgrad_reduce_vec4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw, int S,
+                                         long long total4, int accumulate) {
+    wgrad_reduce_vec4_body(slab, dw, S, total4, accumulate, blockIdx.x, gridDim.x);
+}
 
 // Same sum for 2 <= T <= 16 with both sides coalesced: a block owns (co, 32 input channels); each tap's 32
 // slab values are read as one 128-byte run, the (ci,tap) transpose happens in LDS, and the 32*T results leave
-// as one contiguous run of dw.  blockDim = (32, 8); blockIdx = (Cin/32 tiles, Cout).
-__global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
-                                          int Cout, int Cin, int T, int accumulate, unsigned long long live) {
-    __shared__ float tile[32 * 16];
-    const int ci0 = blockIdx.x * 32, co = blockIdx.y;
-    const int lane = threadIdx.x, row = threadIdx.y;
+// as one contiguous run of dw.  256 threads as (32, 8); block = (Cin/32 tile, co).
+__device__ __forceinline__ void wgrad_reduce_tiled_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout, int Cin,
+                                                        int T, int accumulate, unsigned long long live, int ci_tile, int co,
+                                                        float* tile /* [32 * 16] */) {
+    const int ci0 = ci_tile * 32;
+    const int lane = threadIdx.x & 31, row = threadIdx.x >> 5;
     const long long total = (long long)Cout * Cin * T;
     const long long N = (long long)Cin * T;
     for (int tap = row; tap < T; tap += 8) {
@@ -1083,6 +1101,77 @@ __global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float*
     const int nvalid = min(32, Cin - ci0) * T;
     float* out = dw + ((long long)co * Cin + ci0) * T;
     for (int j = row * 32 + lane; j < nvalid; j += 256) out[j] = accumulate ? out[j] + tile[j] : tile[j];
+}
+__global__ void wgrad_reduce_tiled_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                          int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+    __shared__ float tile[32 * 16];
+    wgrad_reduce_tiled_body(slab, dw, S, Cout, Cin, T, accumulate, live, blockIdx.x, blockIdx.y, tile);
+}
+
+// Role-swapped 1x1 weight gradients (wgrad_role_swap): the slabs hold dW^T [Cin][Cout]; dw[co][ci] (+)= sum_z slab[z][ci][co]
+// with the slabs added in wgrad_reduce_vec4_kernel's order (what the two-launch form - that kernel into a scratch matrix, then
+// transpose_add_kernel - computes): 32 x 32 tiles through LDS, both sides in 128-byte runs.  256 threads as (32, 8).
+__device__ __forceinline__ void wgrad_reduce_transposed_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout,
+                                                             int Cin, int accumulate, int co_tile, int ci_tile, float* tile /* [32 * 33] */) {
+    const int co0 = co_tile * 32, ci0 = ci_tile * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long total = (long long)Cout * Cin;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        float s = 0.f;
+        if (ci < Cin && co < Cout) {
+            const long long idx = (long long)ci * Cout + co;
+            int z = 0;
+            for (; z + 4 <= S; z += 4)
+                s += (slab[(long long)z * total + idx] + slab[(long long)(z + 1) * total + idx]) +
+                     (slab[(long long)(z + 2) * total + idx] + slab[(long long)(z + 3) * total + idx]);
+            for (; z < S; ++z) s += slab[(long long)z * total + idx];
+        }
+        tile[r * 33 + tx] = s;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) {
+            const long long o = (long long)co * Cin + ci;
+            dw[o] = accumulate ? dw[o] + tile[tx * 33 + r] : tile[tx * 33 + r];
+        }
+    }
+}
+
+// The slab reductions of MANY weight gradients in one launch (round 6; wsdl_wgrad_reduce_multi).  A training step ran ~60 of
+// the kernels above, one behind each weight-gradient launch on the side stream: 9-10 us each for a few MB - launch and tail
+// latency, not bandwidth (0.69 ms per step).  With wsdl_conv2d_wgrad_deferred the weight-gradient launches leave their slabs
+// in place and hand back a descriptor; the caller runs ALL pending reductions as one grid when the gradients are needed (the
+// optimiser step, a gradient bucket's all-reduce).  Block b belongs to the last entry whose block_begin <= b.
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const wsdl_wgrad_reduce_desc* __restrict__ d, int n) {
+    __shared__ float sm[32 * 33];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (d[mid].block_begin <= b) lo = mid; else hi = mid - 1;
+    }
+    const wsdl_wgrad_reduce_desc q = d[lo];
+    const int lb = b - q.block_begin;
+    switch (q.kind) {
+        case WSDL_WGRAD_REDUCE_TILED:
+            wgrad_reduce_tiled_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.T, q.accumulate, q.live, lb % q.grid_x, lb / q.grid_x, sm);
+            break;
+        case WSDL_WGRAD_REDUCE_VEC4:
+            wgrad_reduce_vec4_body(reinterpret_cast<const float4*>(q.slab), reinterpret_cast<float4*>(q.dw), q.S,
+                                   (long long)q.Cout * q.Cin * q.T / 4, q.accumulate, lb, q.nblocks);
+            break;
+        case WSDL_WGRAD_REDUCE_MANY:
+            wgrad_reduce_many_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.T, q.accumulate, q.live, lb, sm);
+            break;
+        case WSDL_WGRAD_REDUCE_TRANSPOSED:
+            wgrad_reduce_transposed_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.accumulate, lb % q.grid_x, lb / q.grid_x, sm);
+            break;
+        default:
+            wgrad_reduce_plain_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.T, q.accumulate, q.live, lb, q.nblocks);
+            break;
+    }
 }
 
 // w[co][ci][tap] -> fwd[(tap*Cin+ci)][co], dgrad[(tap*Cout+co)][ci]   (generic, uncoalesced reads)
@@ -1259,6 +1348,7 @@ int launch_fast(const ConvP& p, hipStream_t s, dim3 grid) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_fast_kernel<BM, BN, WM, BK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCU - (int)static_lds - 2048);
     });
+    WSDL_TRACE("fp32_fast<%d,%d,%d> ks=%d nb=%d grid=%ux%ux%u", BM, BN, BK, p.ksplit, p.nb, grid.x, grid.y, grid.z);
     hipLaunchKernelGGL((conv_igemm_fast_kernel<BM, BN, WM, BK>), grid, dim3(kThreads), 0, s, p);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -1274,6 +1364,7 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
+wsdl::Opt g_tile_img_major{1};   // pixel tiles image-fastest inside a column band for convolutions with taps (conv_split.h, "image-major tile order")
 wsdl::Opt g_xcd_map{1};        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
@@ -1300,7 +1391,10 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
+    p.tile_img_major = g_tile_img_major && p.KH * p.KW > 1;
     constexpr bool MF = BK == 32;
+    WSDL_TRACE("split<%d,%d,%d> ar=%d %s ks=%d xcd_py=%d nb=%d grid=%ux%ux%u", BM, BN, BK, (int)g_conv_arith,
+               (MF && g_conv_arith) ? "mfma16x16x32" : "mfma32x32x16", p.ksplit, p.xcd_py, p.nb, grid.x, grid.y, grid.z);
     if (g_conv_arith == 2)
         hipLaunchKernelGGL((conv_igemm_split_kernel<BM, BN, WM, BK, kThreads, 2, MF>), grid, dim3(kThreads), 0, s, p);
     else if (g_conv_arith)
@@ -1325,6 +1419,7 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     p.xcd_rowfast = g_xcd_rowfast;
+    p.tile_img_major = g_tile_img_major && (p.KH * p.KW > 1 || p.nsrc > 0);
     if (p.nsrc > 0 && g_ms_rowfast && grid.y % 2 == 0 && ((long long)grid.x * grid.y) % 8 == 0) {
         // the sources' weights together are the larger operand and every workgroup streams all of them: let the workgroups
         // an XCD runs at once span row tiles as well as pixel tiles
@@ -1337,6 +1432,8 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
             p.xcd_rowfast = 1;
         }
     }
+    WSDL_TRACE("split<256,128,16> ar=%d il=%d nsrc=%d ks=%d xcd_py=%d rowfast=%d imgmajor=%d nb=%d grid=%ux%ux%u", (int)g_conv_arith,
+               (int)(g_conv_arith == 1 && g_conv_il), p.nsrc, p.ksplit, p.xcd_py, p.xcd_rowfast, p.tile_img_major, p.nb, grid.x, grid.y, grid.z);
     if (p.nsrc > 0) {        // several convolutions accumulated into one output (conv_split.h, MS)
         if (g_conv_arith == 2) hipLaunchKernelGGL((conv_igemm_split_kernel<256, 128, 4, 16, 512, 2, false, true>), grid, dim3(512), 0, s, p);
         else if (g_conv_arith && g_conv_il)
@@ -1373,8 +1470,10 @@ int launch_cfg(const ConvP& p, hipStream_t s, bool aligned, bool split) {
             }
         }
         return launch_fast<BM, BN, WM, 16>(p, s, grid);
-    } else
+    } else {
+        WSDL_TRACE("fp32_generic<%d,%d> grid=%ux%u", BM, BN, grid.x, grid.y);
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, false>), grid, dim3(kThreads), 0, s, p);
+    }
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }
@@ -1501,6 +1600,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
         const long long total = (long long)p.Cout * p.P;
         const bool vec4 = (p.OH * p.OW) % 4 == 0 && p.y_bs % 4 == 0 && (!p.res || p.res_bs % 4 == 0) &&
                           (reinterpret_cast<uintptr_t>(p.y) & 15) == 0 && (!p.res || (reinterpret_cast<uintptr_t>(p.res) & 15) == 0);
+        WSDL_TRACE("splitk_reduce%s", vec4 ? "_vec4" : "");
         if (vec4)
             hipLaunchKernelGGL(conv_splitk_reduce_vec4_kernel, dim3((int)std::min<long long>((total / 4 + 255) / 256, 8192)),
                                dim3(256), 0, s, p);
@@ -1615,6 +1715,7 @@ static int launch_stem(const ConvP& p, hipStream_t s, double flops) {
     WSDL_REQUIRE(blocks < (1ll << 31), "conv2d_fwd: too many stem tiles");
     const double bytes = 4.0 * ((double)p.B * 3 * p.H * p.W + 147.0 * 64 + (double)p.P * 64);
     wsdl::ProfScope prof(WSDL_PROF_STEM, s, flops, flops, bytes);
+    WSDL_TRACE("stem7x7s2 fp32 workgroups=%lld", (long long)blocks);
     hipLaunchKernelGGL(stem_conv7x7s2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, tiles_w, tiles_h);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
@@ -1778,6 +1879,30 @@ bool wgrad_role_swap(int Cin, int Cout, int kh, int kw, int stride, int pad) {
     return kh == 1 && kw == 1 && stride == 1 && pad == 0 && !wgrad_chunk32(Cout, Cin, Cin) && wgrad_chunk32(Cin, Cout, Cout);
 }
 
+// one reduction as its own launch (the per-layer form)
+int wgrad_reduce_one(const wsdl_wgrad_reduce_desc& d, hipStream_t s) {
+    switch (d.kind) {
+        case WSDL_WGRAD_REDUCE_TILED:
+            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(d.grid_x, d.Cout), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T,
+                               d.accumulate, d.live);
+            break;
+        case WSDL_WGRAD_REDUCE_VEC4:
+            hipLaunchKernelGGL(wgrad_reduce_vec4_kernel, dim3(d.nblocks), dim3(256), 0, s, reinterpret_cast<const float4*>(d.slab),
+                               reinterpret_cast<float4*>(d.dw), d.S, (long long)d.Cout * d.Cin * d.T / 4, d.accumulate);
+            break;
+        case WSDL_WGRAD_REDUCE_MANY:
+            hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(d.nblocks), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T,
+                               d.accumulate, d.live);
+            break;
+        default:
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.nblocks), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T, d.accumulate,
+                               d.live);
+            break;
+    }
+    WSDL_LAUNCH_CHECK();
+    return WSDL_OK;
+}
+
 template <int BM, int BN, int WM>
 int launch_wgrad_fast(const WgradP& p, hipStream_t s, int S) {
     dim3 grid(p.N / BN, p.Cout / BM, S);
@@ -1809,6 +1934,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
     if (!strcmp(name, "conv_il")) { g_conv_il = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "tile_img_major")) { g_tile_img_major = value != 0; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
@@ -2047,6 +2173,7 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
             wsp += wsdl::align_up((size_t)ks * Cout * p.P * sizeof(float), 256);
         }
         p.xcd_py = (start % 8 == 0) ? choose_xcd_py(p, gx, gy) : 0;
+        p.tile_img_major = g_tile_img_major && k[i] > 1;
         grp.start[j] = start;
         grp.gx[j] = gx;
         grp.gy[j] = gy;
@@ -2086,6 +2213,9 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
     }
     {
         wsdl::ProfScope prof(WSDL_PROF_SPLIT_GROUP, s, flops, wsdl::prof_enabled() ? executed : flops, bytes);
+        WSDL_TRACE("group split<256,128,16> ar=%d il=%d problems=%d streams=%d ks=%d/%d/%d/%d workgroups=%d", (int)g_conv_arith,
+                   (int)(g_conv_arith == 1 && g_conv_il), n, grp.ns, grp.p[0].ksplit, n > 1 ? grp.p[1].ksplit : 0,
+                   n > 2 ? grp.p[2].ksplit : 0, n > 3 ? grp.p[3].ksplit : 0, start);
         if (g_conv_arith == 2)
             hipLaunchKernelGGL((conv_igemm_split_group_kernel<256, 128, 4, 16, 512, 2>), dim3(start), dim3(512), 0, s, grp);
         else if (g_conv_arith && g_conv_il)
@@ -2231,21 +2361,49 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
            (g_wgrad_chan_scale ? wsdl::align_up((size_t)(Cin + Cout) * sizeof(float), 256) : 0);
 }
 
-int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+// `defer` (wsdl_conv2d_wgrad_deferred): the slabs are left un-reduced and *defer describes the reduction (kind < 0: nothing is
+// pending - the call reduced by itself, e.g. a batch processed in slices).
+static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                       long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
-                      size_t ws_bytes, wsdl_stream_t stream) {
+                      size_t ws_bytes, wsdl_stream_t stream, wsdl_wgrad_reduce_desc* defer) {
     WSDL_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
+    if (defer) defer->kind = -1;
     int OH, OW;
     if (int rc = check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return rc;
     if (wgrad_role_swap(Cin, Cout, kh, kw, stride, pad)) {
         const size_t t_bytes = wsdl::align_up((size_t)Cout * Cin * sizeof(float), 256);
         WSDL_REQUIRE(ws_bytes > t_bytes, "conv2d_wgrad: workspace too small");
         float* dwt = static_cast<float*>(ws);
-        if (int rc = wsdl_conv2d_wgrad(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
+        if (defer) {
+            // the transposed problem's slabs, reduced AND transposed by the deferred launch (no scratch matrix in between)
+            wsdl_wgrad_reduce_desc inner{};
+            if (int rc = wgrad_impl(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
+                                    dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
+                                    dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, &inner))
+                return rc;
+            if (inner.kind == WSDL_WGRAD_REDUCE_VEC4) {
+                *defer = inner;                      // slab, S as recorded: slab[z][ci][co]
+                defer->kind = WSDL_WGRAD_REDUCE_TRANSPOSED;
+                defer->dw = dw;
+                defer->Cout = Cout; defer->Cin = Cin; defer->T = 1;
+                defer->accumulate = accumulate;
+                defer->grid_x = wsdl::cdiv(Cout, 32);
+                defer->nblocks = defer->grid_x * wsdl::cdiv(Cin, 32);
+                WSDL_TRACE("role-swapped (dW^T), reduce + transpose deferred");
+                return WSDL_OK;
+            }
+            // (another reduction kind, or already reduced into dwt by the inner call: finish the two-launch form here)
+            if (inner.kind >= 0) {
+                wsdl_wgrad_reduce_desc one = inner;
+                one.block_begin = 0;
+                if (int rc = wgrad_reduce_one(one, wsdl::as_stream(stream))) return rc;
+            }
+        } else if (int rc = wgrad_impl(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
                                        dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
-                                       dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream))
+                                       dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, nullptr))
             return rc;
+        WSDL_TRACE("role-swapped (dW^T) + transpose");
         hipLaunchKernelGGL(transpose_add_kernel, dim3(wsdl::cdiv(Cout, 32), wsdl::cdiv(Cin, 32)), dim3(32, 8), 0,
                            wsdl::as_stream(stream), dwt, dw, Cout, Cin, accumulate);
         WSDL_LAUNCH_CHECK();
@@ -2288,9 +2446,9 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
         if (per < 1) per = 1;
         for (int b0 = 0; b0 < B; b0 += (int)per) {
             const int nb_img = (int)std::min<long long>(per, B - b0);
-            if (int rc = wsdl_conv2d_wgrad(x + (long long)b0 * p.x_bs, dy + (long long)b0 * p.dy_bs, dw, nb_img, Cin, H, W,
-                                           Cout, kh, kw, stride, pad, dil, (accumulate || b0 > 0) ? 1 : 0, p.x_bs, p.dy_bs,
-                                           x_amax, dy_amax, ws, ws_bytes, stream))
+            if (int rc = wgrad_impl(x + (long long)b0 * p.x_bs, dy + (long long)b0 * p.dy_bs, dw, nb_img, Cin, H, W,
+                                    Cout, kh, kw, stride, pad, dil, (accumulate || b0 > 0) ? 1 : 0, p.x_bs, p.dy_bs,
+                                    x_amax, dy_amax, ws, ws_bytes, stream, nullptr))
                 return rc;
         }
         return WSDL_OK;
@@ -2374,6 +2532,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     // registers + spills): that instantiation was removed in round 4
                     // (dilation 2 through two loops - aligned and shifted by two - measured 128 us against 112 for the LDS-staged
                     // kernel on l3.conv2: the third load's registers spill; not used)
+                    WSDL_TRACE("wgrad_split16%s S=%d xcd=%d cs=%d grid=%ux%ux%u", direct ? "d" : "", S, p.xcd_order, (int)cs, grid.x, grid.y, grid.z);
                     if (direct) {
                         // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
                         // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
@@ -2381,6 +2540,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                         const bool dyraw = taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
                                            (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
                                            reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
+                        WSDL_TRACE(dyraw ? "dyraw" : "dy_split16");
                         if (!dyraw) {
                             hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
                                                dy_stride);
@@ -2399,6 +2559,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                             hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
                     } else {
+                        WSDL_TRACE("dy_split16");
                         hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
                                            dy_stride);
                         WSDL_LAUNCH_CHECK();
@@ -2410,6 +2571,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                                                (unsigned)dys_bytes, dy_amax);
                     }
                 } else {
+                    WSDL_TRACE("wgrad_split32 bf16x3 S=%d xcd=%d grid=%ux%ux%u", S, p.xcd_order, grid.x, grid.y, grid.z);
                     hipLaunchKernelGGL(dy_split_kernel<0>, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P,
                                        static_cast<const float*>(nullptr));
                     WSDL_LAUNCH_CHECK();
@@ -2429,6 +2591,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                     q.b_cps[i] = wsdl::cdiv(wsdl::cdiv((long long)B * OH * bands[i].own, 32), S);
                 }
                 int rc;
+                WSDL_TRACE("wgrad_fp32_fast<%d,%d> S=%d nb=%d", tBM, tBN, S, nb);
                 if (tBM == 128 && tBN == 128) rc = launch_wgrad_fast<128, 128, 2>(q, s, S_total);
                 else if (tBM == 128) rc = launch_wgrad_fast<128, 64, 2>(q, s, S_total);
                 else if (tBN == 128) rc = launch_wgrad_fast<64, 128, 1>(q, s, S_total);
@@ -2436,31 +2599,65 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin
                 if (rc) return rc;
             }
         } else if (Cout <= 64) {
+            WSDL_TRACE("wgrad_fp32_generic<64,128> S=%d", S);
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 64), S);
             hipLaunchKernelGGL((conv_wgrad_kernel<64, 128, 1>), grid, dim3(kThreads), lds64, s, p);
         } else {
+            WSDL_TRACE("wgrad_fp32_generic<128,128> S=%d", S);
             dim3 grid(wsdl::cdiv(p.N, 128), wsdl::cdiv(Cout, 128), S);
             hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2>), grid, dim3(kThreads), lds128, s, p);
         }
     }
     WSDL_LAUNCH_CHECK();
+    // the reduction over the pixel slabs: which kernel, on how many 256-thread blocks
+    wsdl_wgrad_reduce_desc rd{};
+    rd.slab = p.slab; rd.dw = dw; rd.S = S_total; rd.Cout = Cout; rd.Cin = Cin; rd.T = kh * kw; rd.accumulate = accumulate;
+    rd.live = live_mask;
     const long long total = (long long)Cout * p.N;
     const int T = kh * kw;
     if (T >= 2 && T <= 16 && Cout <= 65535) {
-        hipLaunchKernelGGL(wgrad_reduce_tiled_kernel, dim3(wsdl::cdiv(Cin, 32), Cout), dim3(32, 8), 0, s, p.slab, dw,
-                           S_total, Cout, Cin, T, accumulate, live_mask);
+        rd.kind = WSDL_WGRAD_REDUCE_TILED;
+        rd.grid_x = wsdl::cdiv(Cin, 32);
+        rd.nblocks = rd.grid_x * Cout;
     } else if (T == 1 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
-        const long long total4 = total / 4;
-        hipLaunchKernelGGL(wgrad_reduce_vec4_kernel, dim3((int)std::min<long long>((total4 + 255) / 256, 8192)), dim3(256), 0, s,
-                           reinterpret_cast<const float4*>(p.slab), reinterpret_cast<float4*>(dw), S_total, total4, accumulate);
+        rd.kind = WSDL_WGRAD_REDUCE_VEC4;
+        rd.nblocks = (int)std::min<long long>((total / 4 + 255) / 256, 8192);
     } else if (S_total >= 16 && total <= (1ll << 24)) {
-        hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, p.slab, dw, S_total,
-                           Cout, Cin, T, accumulate, live_mask);
+        rd.kind = WSDL_WGRAD_REDUCE_MANY;
+        rd.nblocks = (int)((total + 63) / 64);
     } else {
-        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, p.slab, dw, S_total, Cout, Cin, T, accumulate,
-                           live_mask);
+        rd.kind = WSDL_WGRAD_REDUCE_PLAIN;
+        rd.nblocks = (int)std::min<long long>((total + 255) / 256, 4096);
     }
+    if (defer) {
+        *defer = rd;
+        WSDL_TRACE("wgrad_reduce slabs=%d deferred", S_total);
+        return WSDL_OK;
+    }
+    WSDL_TRACE("wgrad_reduce slabs=%d", S_total);
+    return wgrad_reduce_one(rd, s);
+}
+
+int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                      int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                      long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
+                      size_t ws_bytes, wsdl_stream_t stream) {
+    return wgrad_impl(x, dy, dw, B, Cin, H, W, Cout, kh, kw, stride, pad, dil, accumulate, x_bs, dy_bs, x_amax, dy_amax, ws,
+                      ws_bytes, stream, nullptr);
+}
+
+int wsdl_conv2d_wgrad_deferred(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                               int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                               long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
+                               size_t ws_bytes, wsdl_wgrad_reduce_desc* desc, wsdl_stream_t stream) {
+    WSDL_REQUIRE(desc != nullptr, "conv2d_wgrad_deferred: null descriptor");
+    return wgrad_impl(x, dy, dw, B, Cin, H, W, Cout, kh, kw, stride, pad, dil, accumulate, x_bs, dy_bs, x_amax, dy_amax, ws,
+                      ws_bytes, stream, desc);
+}
+
+int wsdl_wgrad_reduce_multi(const wsdl_wgrad_reduce_desc* desc, int n, int total_blocks, wsdl_stream_t stream) {
+    WSDL_REQUIRE(desc && n > 0 && total_blocks > 0, "wgrad_reduce_multi: bad arguments");
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, wsdl::as_stream(stream), desc, n);
     WSDL_LAUNCH_CHECK();
     return WSDL_OK;
 }

@@ -37,8 +37,12 @@
 // Data path: weights are split once per optimiser step by the layout kernel ([k/16][row][piece][16], so a K-chunk of
 // a row tile is one contiguous run copied to LDS with 16-byte loads); activations are split by the loading thread
 // between the global load and the LDS store.  LDS rows are (BK/16) x NP x 32 bytes + 16 bytes of padding: a row stride
-// that is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes) hit 16 distinct 16-byte slots of
-// the 256-byte bank row, and every ds_write_b128 group (8 lanes) 8 distinct slots of 128 bytes.
+// that is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes: 16 different rows) hit 16 distinct
+// 16-byte slots of the 256-byte read bank row.  The STORES bank over 128 bytes and go by groups of 8 (b128) / 16 (b64)
+// consecutive lanes: they are conflict-free only because of which unit each lane carries - 8 consecutive rows per b128
+// group (weights), 8 pixels x one whole slot per b64 group (activations of the 256 x 128 form); see the two mappings in
+// conv_igemm_split_body (round 6; rounds 1-5 stored in unit order and paid a 2-way conflict per store: 30 % of the LDS-active
+// cycles of the dominant kernel).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -233,11 +237,36 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
             }
     }
     const int W_P = p.nb > 1 ? p.B * p.OH * w_own : p.P;
-    const int n0 = (bx - w_tile0) * BN;
+    // Image-major tile order (round 6).  Which taps a pixel tile executes depends on WHERE in the image it lies (a dilated tap
+    // reads only padding for the rows / columns near one border), not on which image: tiles at the same place of different
+    // images run the same tap list and the same number of chunks - in lockstep, if they start together.  In pixel order the ~32
+    // workgroups an XCD runs at once are the 8 places of 4 images: 8 different tap lists, the weight chunks (2 MB per tap of a
+    // 2048-channel ASPP branch) are streamed by workgroups that drift apart, and every one of them misses in L2 - the
+    // grouped ASPP forward fetched 3.6 GB past L2 for 0.26 GB of operands (profiles/r05_notes.md).  Taking a band's tiles image
+    // fastest puts the same place of up to B images side by side: one fetch of a weight chunk serves them all.  Same tiles,
+    // another order: bit-identical results.
+    int lt = bx - w_tile0;
+    if (p.tile_img_major) {
+        const int ohw = p.OH * w_own;                        // pixels of one image inside this band
+        const int tpi = ohw / BN;
+        if (tpi > 1 && tpi * BN == ohw) lt = (lt % p.B) * tpi + lt / p.B;
+    }
+    const int n0 = lt * BN;
     const int OHOW = p.OH * p.OW;
     const int HW = p.H * p.W;
 
-    const int pl = tid % BN, kr = tid / BN;
+    // thread -> (pixel pl of the tile, k run kr) of the activation staging.  Four threads per pixel (the 256 x 128 form: runs of
+    // 4 k, 8-byte LDS stores): lane PAIRS share a pixel, so that the 16 lanes of a ds_write_b64 group cover 8 pixels x one whole
+    // 16-byte slot each - 8 distinct slots of the 128-byte store bank row.  With one k run per wave (64 consecutive pixels, the
+    // round 1-5 mapping) lanes i and i + 8 hit the same 8 bytes (8 rows of 80 bytes = 5 bank rows): a 2-way conflict on every
+    // store, part of the 30 % of LDS-active cycles the counters showed (profiles/r05_pmc_dominant_kernels.txt).
+#ifndef WSDL_EXP_OLD_LDS_MAP
+    constexpr bool kPairB = !MF && B_PER == 4 && B_STEP == 4;
+#else
+    constexpr bool kPairB = false;
+#endif
+    const int pl = kPairB ? (tid % (2 * BN)) / 2 : tid % BN;
+    const int kr = kPairB ? (tid & 1) + 2 * (tid / (2 * BN)) : tid / BN;
     const int pix = n0 + pl;
     const bool pix_ok = pix < W_P;
     int pb = 0, poh = 0, pow_ = 0;
@@ -346,14 +375,27 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     __syncthreads();
 
     // weights: unit u of the chunk = (k-step, row, 16-byte part); a k16 slab of the row tile is contiguous
+    // Which unit a lane carries: 64 consecutive units = 16 rows x 4 parts (fp16x2: 64 bytes per row and k16 slab).  The 8 lanes of
+    // a ds_write_b128 group take the SAME part of 8 consecutive rows - 8 distinct 16-byte slots of the 128-byte store bank row,
+    // for the padded rows (80 bytes: slot 5 row + part) and for the swizzled 128-byte rows of the MF form (unit ^ (row & 7)) alike.
+    // In unit order (a lane group = two rows x four parts) the group's first and last lane are 128 bytes apart: a 2-way
+    // conflict on every weight store (conv_split.h said "conflict-free" until round 6; the counters did not).  The global side
+    // is unchanged: a wave still loads one contiguous 1 KB run, its lanes permuted inside it.
+#ifndef WSDL_EXP_OLD_LDS_MAP
+    constexpr bool kRowMajorA = UPR == 4 && (A_UPS % 64) == 0;
+#else
+    constexpr bool kRowMajorA = false;
+#endif
     unsigned voff_a[A_U], lds_a[A_U];
 #pragma unroll
     for (int e = 0; e < A_U; ++e) {
         const int u = tid + e * NT;
         const int ks = u / A_UPS, v = u - ks * A_UPS;
-        const int row = v / UPR, part = v - row * UPR;
+        const int j = v & 63;
+        const int row = kRowMajorA ? (v >> 6) * 16 + (j & 7) + 8 * (j >> 5) : v / UPR;
+        const int part = kRowMajorA ? (j >> 3) & 3 : v - row * UPR;
         voff_a[e] = (m0 + row < p.Cout && (A_EXACT || u < KS * A_UPS))
-                        ? (unsigned)(ks * p.Cout * K16B + (m0 * UPR + v) * 16) : kOOB;
+                        ? (unsigned)(ks * p.Cout * K16B + ((m0 + row) * UPR + part) * 16) : kOOB;
         if constexpr (MF)                               // part = 2 piece + half of the k16 slab -> unit 4 piece + 2 ks + half
             lds_a[e] = (unsigned)(row * ROW + (((4 * (part >> 1) + 2 * ks + (part & 1)) ^ (row & 7)) << 4));
         else

@@ -270,6 +270,9 @@ class GradBucketReducer:
 
     def _launch(self, b, early=False):
         lo, hi = self._range[b]
+        if self.opt.flat_grad.is_cuda:
+            from . import ops
+            ops.flush_wgrad_reduces(self.opt.flat_grad.device)      # the bucket's weight gradients: slabs -> flat_grad, one launch
         if hi > lo and self.opt.flat_grad.is_cuda and not self._early:
             # behind everything both streams hold so far (recorded into a launch plan), then the collective itself as a host section
             from . import ops
@@ -303,6 +306,7 @@ class GradBucketReducer:
             # The bucket's weight gradients are produced on the side stream, its BN / bias gradients on the main one.
             # Enqueue the collective behind BOTH from the side stream, so the main stream's dgrad chain never stalls.
             from . import ops
+            ops.flush_wgrad_reduces(view.device)        # (nothing pending when _launch came first)
             side = ops.side_stream(view.device)
             if not ordered:
                 ops.stream_wait(side, ops.raw_stream(view.device))

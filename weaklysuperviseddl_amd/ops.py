@@ -409,6 +409,17 @@ def set_option(name, value):
     bump_param_epoch()
 
 
+def launch_trace(on):
+    """wsdl_launch_trace: the convolution entry points describe every launch they choose (form, tile, K slices, XCD order,
+    bands, grid) - read back with ``last_launches()``."""
+    check(lib().wsdl_launch_trace(int(bool(on))))
+
+
+def last_launches():
+    """This thread's launch descriptions since the previous call (a "; "-separated string)."""
+    return lib().wsdl_last_launches().decode()
+
+
 # ---- per-tensor amax scalars ------------------------------------------------------------------------------------
 # The fp16x2 convolution kernels scale each operand tensor by a power of two derived from a device scalar
 # amax >= max|tensor| (conv_split.h).  The kernel that WRITES a tensor publishes it for free (BatchNorm forward /
@@ -448,6 +459,9 @@ def amax_slot(device):
 
 RANGE_LIMIT_LOG2 = 25          # a tensor whose channel maxima spread further than 2^25 leaves the fp16x2 arithmetic's safe range
 _range_out = {}
+_range_rows = {}               # device -> rows of _range_out the latest range_check writes
+_RANGE_ROWS = 8
+_range_warned_pools = [False]
 
 
 def range_check(device):
@@ -459,9 +473,22 @@ def range_check(device):
         return
     out = _range_out.get(device)
     if out is None:
-        out = _range_out[device] = torch.zeros(8, 3, dtype=torch.float32).pin_memory()
-    for j, (_k, (buf, used)) in enumerate(pools[:8]):
+        out = _range_out[device] = torch.zeros(_RANGE_ROWS, 3, dtype=torch.float32).pin_memory()
+    if len(pools) > _RANGE_ROWS and not _range_warned_pools[0]:
+        _range_warned_pools[0] = True
+        import warnings
+        warnings.warn(f"range_check: {len(pools)} amax pools on {device}, only the first {_RANGE_ROWS} are checked "
+                      "(one pool per stream that requested slots: more streams than the library creates)")
+    pools = pools[:_RANGE_ROWS]
+    # the check kernels run on the CURRENT stream: a pool that belongs to another stream (the side stream's aux head, a LayerCAM
+    # lane) is only read once that stream has been joined - FlatAdam.step() calls this behind join_side_stream; a pool of a
+    # stream the caller did not join may still be written while it is read, so it is left out
+    cur = raw_stream(device)
+    joined = {cur, _side_streams[device].cuda_stream if device in _side_streams else cur}
+    pools = [(k, v) for k, v in pools if k[1] in joined]
+    for j, (_k, (buf, used)) in enumerate(pools):
         check(lib().wsdl_range_check(_p(buf), int(used), RANGE_LIMIT_LOG2, _p(out[j]), _stream()))
+    _range_rows[device] = len(pools)      # rows beyond hold an earlier call's figures: range_status does not read them
 
 
 def range_status(device):
@@ -470,7 +497,9 @@ def range_status(device):
     out = _range_out.get(_norm_device(device))
     if out is None:
         return {"worst_log2": 0.0, "pairs_over_limit": 0, "pairs_seen": 0, "exceeded": False, "limit_log2": RANGE_LIMIT_LOG2}
-    a = out.numpy()                      # a view of the pinned buffer (polled after every replayed step: a few microseconds)
+    a = out.numpy()[:_range_rows.get(_norm_device(device), 0)]      # a view of the pinned buffer (polled after every replayed step: a few microseconds)
+    if a.shape[0] == 0:
+        return {"worst_log2": 0.0, "pairs_over_limit": 0, "pairs_seen": 0, "exceeded": False, "limit_log2": RANGE_LIMIT_LOG2}
     over = int(a[:, 1].sum())
     return {"worst_log2": float(a[:, 0].max()), "pairs_over_limit": over, "pairs_seen": int(a[:, 2].sum()), "exceeded": over > 0,
             "limit_log2": RANGE_LIMIT_LOG2}
@@ -807,10 +836,85 @@ def _wgrad_split(wshape):
     return CONV_ARITH[0] == 1 and wshape[0] % 128 == 0 and wshape[1] % 128 == 0
 
 
-def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None, stream=None):
+class _ReduceDesc(C.Structure):       # wsdl_wgrad_reduce_desc (include/wsdl_hip.h)
+    _fields_ = [("slab", C.c_void_p), ("dw", C.c_void_p), ("live", C.c_ulonglong),
+                ("S", C.c_int), ("Cout", C.c_int), ("Cin", C.c_int), ("T", C.c_int),
+                ("accumulate", C.c_int), ("kind", C.c_int), ("grid_x", C.c_int), ("nblocks", C.c_int),
+                ("block_begin", C.c_int), ("reserved", C.c_int)]
+
+
+# Deferred slab reductions of the weight gradients (wsdl_conv2d_wgrad_deferred / wsdl_wgrad_reduce_multi): a weight gradient
+# written into a parameter's slice of the flat gradient buffer leaves its pixel slabs un-reduced; ALL pending reductions run
+# as one launch when the gradients are needed - at the end of the backward pass (an autograd engine callback), before a
+# gradient bucket's all-reduce, before the optimiser step.  ~60 launches of 9-10 us per training step become one (or one per
+# bucket).  Bit-identical to the per-layer reductions.  WSDL_WGRAD_DEFER=0: the per-layer form (A/B).
+WGRAD_DEFER = [os.environ.get("WSDL_WGRAD_DEFER", "1") != "0"]
+_wgrad_pending = {}       # device -> {"descs": [_ReduceDesc], "dws": set of dw pointers, "keep": [tensors], "side": bool, "cb": bool}
+_wgrad_ws = {}            # (device, geometry, dw pointer) -> that layer's own workspace (its slabs outlive the launch)
+_reduce_tables = {}       # descriptor bytes -> (device table, n, total blocks)
+
+
+def _pending_of(device):
+    pend = _wgrad_pending.get(device)
+    if pend is None:
+        pend = _wgrad_pending[device] = {"descs": [], "dws": set(), "keep": [], "side": False, "cb": False}
+    return pend
+
+
+def flush_wgrad_reduces(device=None):
+    """Run every pending slab reduction of ``device`` (default: all devices) as ONE launch - on the side stream, behind what the
+    current stream holds, when any of the weight gradients ran there (consumers of the gradients join the side stream anyway:
+    ``join_side_stream`` before Adam, the bucket all-reduces are enqueued on it)."""
+    for dev, pend in list(_wgrad_pending.items()):
+        if (device is not None and _norm_device(device) != dev) or not pend["descs"]:
+            continue
+        descs = pend["descs"]
+        key = b"".join(bytes(d) for d in descs)
+        ent = _reduce_tables.get(key)
+        if ent is None:
+            arr = (_ReduceDesc * len(descs))()
+            blocks = 0
+            for a, d in zip(arr, descs):
+                C.memmove(C.addressof(a), C.addressof(d), C.sizeof(_ReduceDesc))
+                a.block_begin = blocks
+                blocks += d.nblocks
+            with torch.cuda.device(dev):
+                table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+            ent = _reduce_tables[key] = (table, len(descs), blocks)
+            if len(_reduce_tables) > 64:
+                _reduce_tables.pop(next(iter(_reduce_tables)))
+        cur = raw_stream(dev)
+        if pend["side"]:
+            hs = side_stream(dev).cuda_stream
+            stream_wait(hs, cur)
+        else:
+            hs = cur
+        rec = PLAN_REC[0]
+        if rec is not None:
+            rec.keep.extend(pend["keep"])        # the slabs' workspaces: their addresses are inside the table, not arguments
+        check(lib().wsdl_wgrad_reduce_multi(_p(ent[0]), ent[1], ent[2], hs))
+        pend["descs"], pend["keep"], pend["side"], pend["cb"] = [], [], False, False
+        pend["dws"].clear()
+
+
+def _queue_flush(pend):
+    """Flush when the running backward pass ends (the engine's final callbacks - what DistributedDataParallel uses for its
+    own finalisation); outside a backward pass, at once."""
+    if pend["cb"]:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_wgrad_reduces)
+    except RuntimeError:
+        return False
+    pend["cb"] = True
+    return True
+
+
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None, stream=None, defer=False):
     """``stream``: raw handle of the stream to launch on (default: the current stream) - the side-stream launches of the
     training step pass it instead of switching torch's current stream (a ``with torch.cuda.stream()`` costs the host ~20 us,
-    61 times per step)."""
+    61 times per step).  ``defer``: leave the slab reduction to ``flush_wgrad_reduces`` (``out`` given; the caller has made
+    sure a flush follows - ``_wgrad_into``)."""
     if stream is not None and stream != _stream():
         # everything this function would otherwise enqueue on the CURRENT stream (amax passes, densifying copies) must have
         # been resolved by the caller, in front of the wait that orders ``stream`` behind the current one (_wgrad_into)
@@ -831,6 +935,29 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_
     nbytes = _ws_bytes("wsdl_conv2d_wgrad_workspace", *geom)
     if nbytes == 0:
         raise WsdlError("conv2d_wgrad: bad geometry " + repr(geom))
+    if defer and out is not None:
+        dev = _norm_device(x.device)
+        pend = _pending_of(dev)
+        if out.data_ptr() in pend["dws"]:
+            flush_wgrad_reduces(dev)            # a second gradient into the same parameter: the first one's reduction goes first
+        # this layer's OWN workspace: its slabs stay until the multi-reduce has run (and their addresses repeat step after step,
+        # so the descriptor table is uploaded once)
+        wkey = (dev, geom, out.data_ptr())
+        ws = _wgrad_ws.get(wkey)
+        if ws is None or ws.numel() < nbytes:
+            ws = _wgrad_ws[wkey] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+        desc = _ReduceDesc()
+        hs = _stream() if stream is None else stream
+        check(lib().wsdl_conv2d_wgrad_deferred(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
+                                               _p(ws), ws.numel(), C.byref(desc), hs))
+        if desc.kind >= 0:
+            pend["descs"].append(desc)
+            pend["dws"].add(out.data_ptr())
+            pend["keep"].append(ws)
+            pend["side"] = pend["side"] or hs != raw_stream(dev)
+            if not _queue_flush(pend):
+                flush_wgrad_reduces(dev)
+        return out
     ws = workspace(nbytes, x.device, stream)
     if out is None:
         out = torch.empty(wshape, device=x.device, dtype=torch.float32)
@@ -1002,12 +1129,12 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
         stream_wait(hside, _stream())               # dconv / x (and the zero_grad memset) are ready
         # launched ON the side stream by handle: torch's current stream stays the main one
         conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                     dy_amax=dy_amax, stream=hside)
+                     dy_amax=dy_amax, stream=hside, defer=WGRAD_DEFER[0])
         x.record_stream(side)                       # keep the caching allocator from recycling them early
         dconv.record_stream(side)
     else:
         conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                     dy_amax=dy_amax)
+                     dy_amax=dy_amax, defer=WGRAD_DEFER[0])
     sink.grad_ready(param)
 
 

@@ -24,7 +24,11 @@ from . import ops
 
 _ALIGN = 64   # floats; keeps every parameter 256-byte aligned inside the flat buffer
 import os as _os
-RANGE_GUARD = [_os.environ.get("WSDL_RANGE_GUARD", "warn")]   # what FlatAdam does when the sentinel fires: "warn" | "auto" (switch the guards on) | "off"
+# what FlatAdam does when the sentinel fires: "auto" (the default since round 6: switch the range guards on for the steps that
+# follow - the reference's fp32 has no range floor, so the default must not keep computing below it) | "warn" (say so, change
+# nothing) | "off"
+RANGE_GUARD_DEFAULT = "auto"
+RANGE_GUARD = [_os.environ.get("WSDL_RANGE_GUARD", RANGE_GUARD_DEFAULT)]
 RANGE_GUARD_ACTIVE = [False]                                  # "auto" has switched the guards on in this process
 RANGE_SENTINEL = [_os.environ.get("WSDL_RANGE_SENTINEL", "1") != "0"]      # FlatAdam.step() checks the step's tensors for regions below the fp16x2 arithmetic's safe range
 
@@ -151,6 +155,7 @@ class FlatAdam:
         (a collective's work handle)."""
         dev = self.flat_param.device
         lo, hi = self.segments[k]
+        ops.flush_wgrad_reduces(dev)            # the segment's weight gradients may still be un-reduced slabs
         side = ops.side_stream(dev)
         ops.stream_wait(side, ops.raw_stream(dev))
         if not self.capture_mode and self._prep_done[k] is not None:
@@ -217,6 +222,8 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none=False):
         self.sync_hyper()               # (segments may be stepped from backward hooks, before step() is reached)
+        if self.flat_grad.is_cuda:
+            ops.flush_wgrad_reduces(self.flat_grad.device)   # reductions still pending would land in the zeroed buffer
         if self.flat_grad.is_cuda and getattr(self, "_dirty", True):
             ops.join_side_stream(self.flat_grad.device)      # a backward without a step may still be writing
         if self.flat_grad.is_cuda:
@@ -278,8 +285,20 @@ class FlatAdam:
             warnings.warn(what + "select the range guards: ops.set_option('conv_arith', 2) (forward / input gradient) and "
                           "ops.set_option('wgrad_chan_scale', 1) (weight gradient), or WSDL_RANGE_GUARD=auto")
 
+    def _sentinel(self):
+        """Range sentinel of the fp16x2 arithmetic (every exit of a step, the segmented / data-parallel one too): what the
+        PREVIOUS step's tensors spanned, then this step's check - behind the join with the side stream, whose pools it reads."""
+        if self.flat_param.is_cuda and RANGE_SENTINEL[0] and ops.CONV_ARITH[0] == 1 and not self.capture_mode_on():
+            self.range_poll()
+            ops.range_check(self.flat_param.device)
+
+    def capture_mode_on(self):
+        return bool(getattr(self, "capture_mode", False))
+
     def _step(self):
         self.sync_hyper()
+        if self.flat_param.is_cuda:
+            ops.flush_wgrad_reduces(self.flat_param.device)     # (normally done: the end of the backward pass flushed them)
         if self.pre_step_hook is not None:
             # (the data-parallel reducer's wait(): collectives' work handles, control-plane exchange - host work that a launch
             # plan repeats live at this place)
@@ -289,6 +308,7 @@ class FlatAdam:
                 self._finish_segments()         # (the segment hook has re-laid-out the weights)
                 ops.bump_param_epoch()
                 self._dirty = False             # the main stream waits for the Adam launches, which follow every gradient
+                self._sentinel()
                 return
             self._fired = set()                 # one launch over the whole buffer, below
         if self.flat_param.is_cuda:
@@ -304,9 +324,6 @@ class FlatAdam:
         else:
             raise ops.WsdlError("FlatAdam.step: parameters are not on the device; there is no CPU fallback")
         self._dirty = False                     # (joined above)
-        if self.flat_param.is_cuda and RANGE_SENTINEL[0] and ops.CONV_ARITH[0] == 1:
-            # range sentinel of the fp16x2 arithmetic: what the PREVIOUS step's tensors spanned, then this step's check
-            self.range_poll()
-            ops.range_check(self.flat_param.device)
+        self._sentinel()
         if self.post_step_hook is not None:
             self.post_step_hook()

@@ -94,7 +94,12 @@ def record(fn, *args, **kwargs):
     check(lib().wsdl_plan_begin())
     ops.PLAN_REC[0] = rec
     try:
-        out = fn(*args, **kwargs)
+        # The recording belongs to THIS host thread (csrc/plan.hip: thread_local).  The autograd engine runs the backward nodes
+        # of a device on a worker thread of its own - their launches would not be recorded (and, were the recording process-wide,
+        # a second thread's backward would be recorded into this plan).  With the engine's multithreading off for the recorded
+        # call the whole backward pass runs on the calling thread: same nodes, same order.
+        with torch.autograd.set_multithreading_enabled(False):
+            out = fn(*args, **kwargs)
     except BaseException:
         ops.PLAN_REC[0] = None
         lib().wsdl_plan_abort()
@@ -418,9 +423,9 @@ def loss_tag(obj):
     code = getattr(obj, "__code__", None)
     if code is None:
         return id(obj)
-    cells = tuple(c.cell_contents if isinstance(c.cell_contents, _SCALARS) else id(c.cell_contents) for c in (obj.__closure__ or ()))
-    return (code, id(getattr(obj, "__self__", None)), tuple(type(x).__name__ for x in cells),
-            tuple(x for x in cells if not isinstance(x, (int, float)) or isinstance(x, bool)))
+    # scalars in cells belong to the KEY (host_scalars), not to the tag; objects count by identity
+    cells = tuple("scalar" if isinstance(c.cell_contents, _SCALARS) else id(c.cell_contents) for c in (obj.__closure__ or ()))
+    return (code, id(getattr(obj, "__self__", None)), cells)
 
 
 def planned_step_for(model, optimizer, eager, tag):
