@@ -294,6 +294,22 @@ int wsdl_conv2d_wgrad_deferred(const float* x, const float* dy, float* dw, int B
                                int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                                long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
                                size_t ws_bytes, wsdl_wgrad_reduce_desc* desc, wsdl_stream_t stream);
+/* The weight gradient with PER-CHANNEL operands (round 6; both optional, NULL = as wsdl_conv2d_wgrad):
+ *   x_chan_amax[Cin] / dy_chan_amax[Cout]: one maximum per channel of x / dY, as the channel-resident BatchNorm kernels publish
+ *     them (wsdl_bn_train_fwd / _bwd chan_amax).  The fp16x2 kernels then scale each channel by its OWN power of two - exact (a
+ *     channel is a row / column of this GEMM's output) and the range guard of the weight gradient for nothing: a channel 2^30
+ *     below the tensor's maximum keeps its 22 bits.  "wgrad_chan_scale" = 1 takes missing maxima with a pre-pass instead.
+ *   dy_presplit: dY already as the kernel's fp16 (high, low) rows [ceil(P / 32)][Cout][128 B], written by the BatchNorm backward that
+ *     produced dY (wsdl_bn_train_bwd dy_presplit) with the scales of dy_chan_amax: dy_split16_kernel (one more read and write of
+ *     dY per layer, 24 launches per training step) does not run.  wsdl_conv2d_wgrad_presplit_bytes: the buffer's size for a
+ *     geometry, 0 where the weight gradient would not use it.
+ *   desc_or_null: non-NULL = the deferred form (wsdl_conv2d_wgrad_deferred). */
+size_t wsdl_conv2d_wgrad_presplit_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil);
+int wsdl_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                         int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                         long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax,
+                         const float* x_chan_amax, const float* dy_chan_amax, const void* dy_presplit, void* ws,
+                         size_t ws_bytes, wsdl_wgrad_reduce_desc* desc_or_null, wsdl_stream_t stream);
 /* desc: DEVICE array of n entries; total_blocks = the sum of their nblocks */
 int wsdl_wgrad_reduce_multi(const wsdl_wgrad_reduce_desc* desc, int n, int total_blocks, wsdl_stream_t stream);
 
@@ -325,7 +341,13 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
                                    them, layers of few channels (option bn_coop: 0* = off, 64) run several workgroups per channel, which
                                    hand their partial sums over through the workspace (64 channels at B=16, 64x64: 17.2 -> 13.8 us;
                                    profiles/r05_notes.md); the kernel leaves the counters zeroed.  NULL: one workgroup per channel */,
+                      float* chan_amax /* optional [C]: max|y| per CHANNEL (a plain store by the channel's workgroup; wants y_amax and
+                                          wsdl_bn_channel_resident(B, C, HW, 0)) - the per-channel scales of the weight gradient that
+                                          reads y as its x operand (wsdl_conv2d_wgrad_ex) */,
                       wsdl_stream_t stream);
+/* 1 when (B, C, HW) runs the channel-resident kernel (one workgroup holds a whole channel in registers: what chan_amax /
+ * dy_presplit need), forward (backward = 0) or backward (1), under the current options. */
+int wsdl_bn_channel_resident(int B, int C, int HW, int backward);
 /* Backward of the above.  relu = 1: the ReLU mask is read from the forward output y (needed when a residual was
  * added); relu = 2: the mask is recomputed from x - y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
  * expression - so y is neither read nor needs keeping (y may be NULL, beta is required); relu = 3: the mask is read from
@@ -339,7 +361,13 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       long long dy_bs, long long y_bs,
                       float* dx_amax /* optional: atomicMax of max|dx| into a ZEROED device scalar */,
                       const uint8_t* relu_mask /* relu = 3 */,
-                      void* ws, size_t ws_bytes, int* coop /* as for the forward */, wsdl_stream_t stream);
+                      void* ws, size_t ws_bytes, int* coop /* as for the forward */,
+                      float* chan_amax /* optional [C]: max|dx| per channel (as for the forward; wsdl_bn_channel_resident(.., 1)) */,
+                      void* dy_presplit /* optional: dx ALSO as the fp16 (high, low) rows the producing convolution's weight gradient
+                                           reads ([B*HW / 32][C][128 B], each channel scaled by the power of two of its chan_amax;
+                                           size: wsdl_conv2d_wgrad_presplit_bytes) - the channel's workgroup holds it in registers
+                                           anyway.  Wants chan_amax and B*HW % 32 == 0 (dx itself is always dense) */,
+                      wsdl_stream_t stream);
 /* eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale (fed to wsdl_conv2d_fwd). */
 int wsdl_bn_fold(const float* gamma, const float* beta, const float* running_mean,
                  const float* running_var, float eps, float* scale, float* shift, int C,

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--scale", type=int, default=1, help="2 = 512x512 inputs")
     ap.add_argument("--shapes", default="", help="comma-separated substrings of shape names to run")
     ap.add_argument("--opt", default="", help="name=value[,name=value] library options, e.g. conv_split=0")
+    ap.add_argument("--camax", default="", help="weight gradient with per-channel maxima of: x, dy, or x,dy (as the BatchNorm kernels publish them)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.opt:
@@ -91,9 +92,11 @@ def main():
         OH, OW = ops.conv_out_hw(H, H, k, s, pad, d)
         dy = torch.randn(B, Cout, OH, OW, device=dev)
         flops = 2.0 * B * OH * OW * Cout * Cin * k * k
+        xc = x.abs().amax(dim=(0, 2, 3)).contiguous() if "x" in args.camax.split(",") else None
+        dc = dy.abs().amax(dim=(0, 2, 3)).contiguous() if "dy" in args.camax.split(",") else None
         passes = {"fwd": lambda: ops.conv2d_fwd(x, wf, w.shape, s, pad, d),
                   "dgrad": lambda: ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d),
-                  "wgrad": lambda: ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)}
+                  "wgrad": lambda: ops.conv2d_wgrad(x, dy, w.shape, s, pad, d, x_camax=xc, dy_camax=dc)}
         for pname, fn in passes.items():
             if args.only and pname not in args.only.split(","):
                 continue

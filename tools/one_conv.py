@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--opt", default="")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands (power / clock experiment)")
+    ap.add_argument("--plain", action="store_true", help="weight gradient as a stand-alone call (per-tensor scales, dy_split16, its own reduce launch)")
     a = ap.parse_args()
     for kv in [x for x in a.opt.split(",") if x]:
         k, v = kv.split("=")
@@ -60,13 +61,31 @@ def main():
     if a.zeros:
         x.zero_(); w.zero_(); dy.zero_()
         wf, wd = ops.prep_weights(w)
+    # the weight gradient AS THE TRAINING STEP RUNS IT (round 6): its dY operand comes from a BatchNorm backward, which publishes the
+    # per-channel maxima and - where the launch reads them - the pre-split rows (no dy_split16 pass); the slab reduction is deferred
+    # (in the step: one launch for all layers; here one launch for this layer - an upper bound of its share)
+    cam = pre = None
+    if a.which == "wgrad" and not a.plain:
+        gamma, beta = torch.rand(Cout, device=dev) + 0.5, torch.zeros(Cout, device=dev)
+        conv_out = torch.randn(B, Cout, OH, OW, device=dev)
+        _y, mean, invstd = ops.bn_train_fwd(conv_out, gamma, beta, torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), 0.1, 1e-5, relu=True)
+        psb = ops.wgrad_presplit_bytes(tuple(x.shape), tuple(w.shape), s, pad, d)
+        if a.zeros:
+            dy.zero_()
+        dyb, _, _, _ = ops.bn_train_bwd(conv_out, dy, None, gamma, mean, invstd, True, False, beta=beta, presplit_bytes=psb)
+        dy = dyb
+        cam, pre = getattr(dy, "_wsdl_camax", None), getattr(dy, "_wsdl_presplit", None)
+    dw = torch.zeros_like(w)
     for _ in range(a.reps):
         if a.which == "fwd":
             ops.conv2d_fwd(x, wf, w.shape, s, pad, d)
         elif a.which == "dgrad":
             ops.conv2d_dgrad(dy, wd, w.shape, x.shape, s, pad, d)
-        else:
+        elif a.plain:
             ops.conv2d_wgrad(x, dy, w.shape, s, pad, d)
+        else:
+            ops.conv2d_wgrad(x, dy, w.shape, s, pad, d, out=dw, defer=True, dy_camax=cam, dy_presplit=pre)
+            ops.flush_wgrad_reduces(dev)
     torch.cuda.synchronize()
 
 

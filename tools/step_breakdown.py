@@ -5,7 +5,7 @@ import sys
 
 
 def category(n):
-    if "wgrad_reduce" in n or "dy_split" in n or "transpose_add" in n:
+    if "wgrad_reduce" in n or "dy_split" in n or "transpose_add" in n or "channel_amax" in n:
         return "weight-gradient satellites (dY pre-split, slab reduces)"
     if "wgrad" in n:
         return "weight gradients"

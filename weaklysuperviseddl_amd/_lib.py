@@ -47,12 +47,15 @@ SIGNATURES = {
     "wsdl_conv2d_wgrad": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp]),
     "wsdl_conv2d_wgrad_deferred": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
     "wsdl_wgrad_reduce_multi": (_i, [_vp, _i, _i, _vp]),
+    "wsdl_conv2d_wgrad_presplit_bytes": (_sz, [_i] * 10),
+    "wsdl_conv2d_wgrad_ex": (_i, [_vp, _vp, _vp] + [_i] * 10 + [_i, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "wsdl_amax": (_i, [_vp, _i, _ll, _ll, _vp, _i, _vp]),
     "wsdl_multi_amax": (_i, [_vp, _vp, _i, _vp, _vp]),
     "wsdl_bias_grad": (_i, [_vp, _vp, _i, _i, _i, _ll, _i, _vp]),
     "wsdl_bn_workspace": (_sz, [_i]),
-    "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
-    "wsdl_bn_train_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "wsdl_bn_train_fwd": (_i, [_vp] * 8 + [_f, _f, _i, _i, _i, _vp, _i, _ll, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "wsdl_bn_train_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "wsdl_bn_channel_resident": (_i, [_i, _i, _i, _i]),
     "wsdl_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "wsdl_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wsdl_affine_act_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _i, _vp, _vp]),

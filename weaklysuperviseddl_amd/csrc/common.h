@@ -189,7 +189,10 @@ __device__ __forceinline__ void publish_amax(float m, float* __restrict__ amax) 
 // (max, min piece maximum) of a step into "spread exceeded 2^25 somewhere" without a host synchronisation.  The minimum is
 // kept as the bitwise complement of its float bits, so that the zero a slot starts from means "none yet" and atomicMax
 // orders it.  Every thread of the workgroup must call it.
-__device__ __forceinline__ void publish_amax_min(float m, float* __restrict__ amax, float* __restrict__ cmin) {
+// `chan` (optional): this workgroup's own maximum as a plain store - the per-CHANNEL maximum of the channel-resident BatchNorm
+// kernels, which the weight-gradient kernels use as per-channel scales (exact: a channel is a row / column of that GEMM's output).
+__device__ __forceinline__ void publish_amax_min(float m, float* __restrict__ amax, float* __restrict__ cmin,
+                                                 float* __restrict__ chan = nullptr) {
     __shared__ float s_amax2[16];
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_amax2[threadIdx.x >> 6] = m;
@@ -197,6 +200,7 @@ __device__ __forceinline__ void publish_amax_min(float m, float* __restrict__ am
     if (threadIdx.x == 0) {
         const int nw = (blockDim.x * blockDim.y + 63) >> 6;
         for (int i = 1; i < nw; ++i) m = fmaxf(m, s_amax2[i]);
+        if (chan) *chan = m;
         if (m > 0.f) {
             unsigned* a = reinterpret_cast<unsigned*>(amax);
             const unsigned bits = __builtin_bit_cast(unsigned, m);
@@ -215,6 +219,47 @@ __device__ __forceinline__ void publish_amax_min(float m, float* __restrict__ am
             }
         }
     }
+}
+// ---- the fp16x2 split, shared by the convolution kernels (conv_split.h) and by the producers that write pre-split operands
+// (bn_bwd_resident_kernel: the weight gradient's dY rows)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// (x0, x1), already scaled -> packed fp16 pairs of the two pieces (round to nearest even; x - h is exact in fp32)
+__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
+    f32x2 v = {x0, x1};
+    const half2v hv = __builtin_convertvector(v, half2v);
+    h = __builtin_bit_cast(unsigned, hv);
+    f32x2 r = {x0 - (float)hv[0], x1 - (float)hv[1]};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
+}
+
+// power-of-two scale that puts amax in [2^14, 2^15); 1 for amax = 0 / inf / NaN.  `e` returns its exponent.
+__device__ __forceinline__ float pow2_scale(float amax, int& e) {
+    const unsigned bits = __builtin_bit_cast(unsigned, amax) & 0x7fffffffu;
+    const int be = (int)(bits >> 23);                   // biased exponent
+    e = (bits == 0u || be == 255) ? 0 : 14 - (be - 127);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+}
+__device__ __forceinline__ float pow2(int e) {          // |e| <= 200: two exact factors
+    const int e1 = e / 2, e2 = e - e1;
+    return __builtin_bit_cast(float, (unsigned)(e1 + 127) << 23) * __builtin_bit_cast(float, (unsigned)(e2 + 127) << 23);
+}
+
+// max over the workgroup, returned to EVERY thread (blockDim.x <= 1024, a multiple of 64)
+__device__ __forceinline__ float block_max_all(float m, float* smem /* >= 17 floats */) {
+    m = wave_max(m);
+    __syncthreads();                                   // (smem may still be read from a previous use)
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, smem[i]);
+        smem[16] = m;
+    }
+    __syncthreads();
+    return smem[16];
 }
 __device__ __forceinline__ float amax4(float m, const float4& v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));

@@ -645,6 +645,7 @@ struct WgradP {
     int nb, splits;               // column bands inside one launch: blockIdx.z = band * splits + split
     int b_ow0[4], b_own[4], b_cps[4];   // per band: window and 32-pixel chunks per split
     const float* x_amax;                // split kernel, fp16x2 arithmetic: device scalar >= max|x|
+    int xa_stride, da_stride;           // CS kernels: x_amax / dy_amax are read at [channel * stride] (0: one scale for the tensor, 1: per channel)
 };
 
 #include "conv_split.h"
@@ -1633,6 +1634,7 @@ constexpr int kStemIW = 2 * kStemHalf;              // row stride in LDS
 constexpr int kStemPlane = kStemIH * kStemIW;
 constexpr int kStemK = 148;                         // 147 + one zero row: K steps of 2
 wsdl::Opt g_stem_kernel{1};
+wsdl::Opt g_stem_wgrad{1};       // the stem's weight gradient on its own kernel (stem_wgrad7x7s2_kernel)
 
 __global__ __launch_bounds__(256, 2) void stem_conv7x7s2_kernel(ConvP p, int tiles_w, int tiles_h) {
     __shared__ float w_s[kStemK * 64];              // [k][cout]
@@ -1926,6 +1928,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "col_bands")) { g_col_bands = value; return WSDL_OK; }
     if (!strcmp(name, "conv_split")) { g_conv_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "stem_kernel")) { g_stem_kernel = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "stem_wgrad")) { g_stem_wgrad = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_direct")) { g_wgrad_direct = value; return WSDL_OK; }
     if (!strcmp(name, "wgrad_imbalance_split")) { g_wgrad_imbalance_split = value != 0; return WSDL_OK; }
     if (!strcmp(name, "wgrad_chan_scale")) { g_wgrad_chan_scale = value != 0; return WSDL_OK; }
@@ -2327,6 +2330,106 @@ __global__ void channel_amax_kernel(const float* __restrict__ t, int B, int C, i
     publish_amax(m, out + c);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The stem's WEIGHT GRADIENT (round 6): dW[64][3][7][7] = sum over pixels of dY[co][pixel] x patch[(ky, kx, ci)][pixel].  K = 147
+// is no multiple of 16 and Cin = 3, so it ran on the generic fp32 kernel with per-element bounds checks: 164 us at B = 16,
+// 256 x 256 - the LAST kernel of the backward pass, on the main stream, with nothing left to overlap it (the fp32-MFMA bound of
+// its 5 GFLOP is 34 us).  Same idea as the forward stem kernel: a workgroup takes 4 x 32 output pixels, stages the
+// 13 x 69 x 3 input patch (de-interleaved by column parity) and the 64 x 128 tile of dY in LDS once, and runs the GEMM
+// D[co][k] over the tile's 128 pixels on v_mfma_f32_32x32x2_f32 - exact fp32 products as before.  The 2 x 5 output tiles
+// (64 channels x 147 -> 160 k) are dealt to the four waves 3 / 3 / 2 / 2; a workgroup walks several pixel tiles with its
+// accumulators in registers (grid = at most 768 workgroups = 768 slabs of 37 KB, summed in fixed order by the slab reduction).
+constexpr int kSwTH = 4;                              // output rows of a tile
+constexpr int kSwIH = 2 * kSwTH + 5;                  // 13 input rows
+constexpr int kSwPlane = kSwIH * kStemIW;
+constexpr int kSwLD = kSwTH * kStemTW + 1;            // dY rows of 128 pixels + 1: lanes of different channels on different banks
+constexpr int kSwMaxGrid = 768;
+
+__global__ __launch_bounds__(256, 3) void stem_wgrad7x7s2_kernel(WgradP p, int tiles_w, int tiles_h, int total_tiles) {
+    __shared__ float dy_s[64 * kSwLD];
+    __shared__ float x_s[3 * kSwPlane + 1];           // + one zero word: what the 13 padding columns of the k dimension read
+    __shared__ int koff[160];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (tid < 160) {
+        int off = 3 * kSwPlane;                       // k >= 147: the zero word (and no pixel offset: see the loop)
+        if (tid < 147) {
+            const int tap = tid / 3, ci = tid - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+            off = ci * kSwPlane + ky * kStemIW + (kx & 1) * kStemHalf + (kx >> 1);
+        }
+        koff[tid] = off;
+    }
+    if (tid == 0) x_s[3 * kSwPlane] = 0.f;
+    // this wave's output tiles: (channel tile 0, k tile nt0), (channel tile 1, k tile nt0) and, for waves 0 / 1, (channel
+    // tile wid, k tile 4)
+    const int nt0 = wid;
+    const bool third = wid < 2;
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = 0.f;
+    const int HW = p.H * p.W, OHOW = p.OH * p.OW;
+    __syncthreads();
+    const int kb0 = koff[nt0 * 32 + l31], kb4 = koff[128 + l31];
+    const bool pad0 = nt0 * 32 + l31 >= 147, pad4 = 128 + l31 >= 147;
+    for (int t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, b = t / (tiles_w * tiles_h);
+        const int oy0 = th * kSwTH, ox0 = tw * kStemTW;
+        // the input patch
+        const float* xb = p.x + (long long)b * p.x_bs;
+        const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+        for (int i = tid; i < 3 * kSwIH * 69; i += 256) {
+            const int ci = i / (kSwIH * 69), r = i - ci * (kSwIH * 69);
+            const int row = r / 69, col = r - row * 69;
+            const int iy = iy0 + row, ix = ix0 + col;
+            float v = 0.f;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xb[(long long)ci * HW + iy * p.W + ix];
+            x_s[ci * kSwPlane + row * kStemIW + (col & 1) * kStemHalf + (col >> 1)] = v;
+        }
+        // the tile of dY: 64 channels x 4 rows x 32 columns (zeros beyond the map)
+        const float* dyb = p.dy + (long long)b * p.dy_bs;
+        for (int i = tid; i < 64 * kSwTH * 32; i += 256) {
+            const int co = i >> 7, r = i & 127, row = r >> 5, col = r & 31;
+            const int oy = oy0 + row, ox = ox0 + col;
+            dy_s[co * kSwLD + r] = (oy < p.OH && ox < p.OW) ? dyb[(long long)co * OHOW + oy * p.OW + ox] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int st = 0; st < kSwTH * kStemTW / 2; ++st) {
+            const int px = 2 * st + lh;                                      // pixel of the tile: row px / 32, column px % 32
+            const int po = (px >> 5) * 2 * kStemIW + (px & 31);              // its offset inside a patch plane
+            const float a0 = dy_s[l31 * kSwLD + px], a1 = dy_s[(32 + l31) * kSwLD + px];
+            const float b0 = x_s[pad0 ? kb0 : kb0 + po];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc1, 0, 0, 0);
+            if (third) {
+                const float b4 = x_s[pad4 ? kb4 : kb4 + po];
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wid == 0 ? a0 : a1, b4, acc2, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (the channel inside its tile), column = lane & 31 (k inside its tile)
+    float* slab = p.slab + (long long)blockIdx.x * 64 * 147;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int n = nt0 * 32 + l31;
+        if (n < 147) {
+            slab[(long long)row * 147 + n] = acc0[r];
+            slab[(long long)(32 + row) * 147 + n] = acc1[r];
+        }
+        if (third && 128 + l31 < 147) slab[(long long)(wid * 32 + row) * 147 + 128 + l31] = acc2[r];
+    }
+}
+
+static bool stem_wgrad_eligible(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil) {
+    return g_stem_wgrad && Cin == 3 && Cout == 64 && kh == 7 && kw == 7 && stride == 2 && pad == 3 && dil == 1 && H >= 7 && W >= 7;
+}
+static int stem_wgrad_grid(int B, int OH, int OW) {
+    const long long tiles = (long long)B * wsdl::cdiv(OH, kSwTH) * wsdl::cdiv(OW, kStemTW);
+    return (int)std::min<long long>(tiles, kSwMaxGrid);
+}
+
 static size_t wgrad_dys_bytes(int Cout, int Cin, int N, int P) {
     if (!wgrad_chunk32(Cout, Cin, N)) return 0;
     const size_t n = (size_t)wsdl::cdiv(P, 32) * Cout * w2row_bytes(g_conv_arith);
@@ -2344,6 +2447,26 @@ static int wgrad_bands(int Cout, int Cin, int OW, int W, int kw, int stride, int
     return column_bands(OW, W, 1, dil, -pad, 1, kw, bands);
 }
 
+// Bytes of the pre-split dY rows ([ceil(P / 32)][Cout][128 B]) this geometry's weight gradient reads when its producer writes
+// them (wsdl_bn_train_bwd dy_presplit) - 0 when the launch would not run dy_split16_kernel anyway: shapes off the fp16x2
+// split kernels, the role-swapped 1x1 form, the direct-fragment kernel reading dY as fp32 (few N tiles).
+size_t wsdl_conv2d_wgrad_presplit_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride, int pad, int dil) {
+    int OH, OW;
+    if (check_geom(B, Cin, H, W, Cout, kh, kw, stride, pad, dil, &OH, &OW)) return 0;
+    if (g_conv_arith != 1 && g_conv_arith != 2) return 0;
+    if (wgrad_role_swap(Cin, Cout, kh, kw, stride, pad)) return 0;
+    const int N = kh * kw * Cin, P = B * OH * OW;
+    const size_t bytes = wgrad_dys_bytes(Cout, Cin, N, P);
+    if (!bytes || P % 32 != 0) return 0;
+    const long long xb = (long long)B * Cin * H * W * 4, dyb = (long long)B * Cout * OH * OW * 4;
+    if (xb >= (1ll << 31) || dyb >= (1ll << 31)) return 0;          // processed in batch slices
+    bool taps_aligned = true;
+    for (int kx = 0; kx < kw; ++kx) taps_aligned = taps_aligned && (((kx * dil - pad) & 3) == 0);
+    const bool direct = g_wgrad_direct && taps_aligned && stride == 1 && OW % 32 == 0 && W % 4 == 0 && (H * W) % 4 == 0;
+    const bool dyraw = direct && g_wgrad_dyraw && (N / 128 <= 10 || g_wgrad_dyraw == 2) && (OH * OW) % 4 == 0;
+    return dyraw ? 0 : bytes;
+}
+
 size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int kh, int kw, int stride,
                                    int pad, int dil) {
     int OH, OW;
@@ -2355,18 +2478,27 @@ size_t wsdl_conv2d_wgrad_workspace(int B, int Cin, int H, int W, int Cout, int k
     Band bands[8];
     const int nb = wgrad_bands(Cout, Cin, OW, W, kw, stride, pad, dil, bands);
     const int n_live = __builtin_popcountll(live_taps(H, W, OH, OW, kh, kw, stride, pad, dil)) * Cin;
-    const size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live, wgrad_tap_balance(H, OH, kh, stride, pad, dil)) *
-                         Cout * N * sizeof(float);
+    size_t slabs = (size_t)nb * wgrad_splits(Cout, Cin, N, B * OH * OW, n_live, wgrad_tap_balance(H, OH, kh, stride, pad, dil)) *
+                   Cout * N * sizeof(float);
+    if (stem_wgrad_eligible(B, Cin, H, W, Cout, kh, kw, stride, pad, dil))
+        slabs = std::max(slabs, (size_t)stem_wgrad_grid(B, OH, OW) * Cout * N * sizeof(float));
     return wsdl::align_up(slabs, 256) + wsdl::align_up(wgrad_dys_bytes(Cout, Cin, N, B * OH * OW), 256) +
            (g_wgrad_chan_scale ? wsdl::align_up((size_t)(Cin + Cout) * sizeof(float), 256) : 0);
 }
 
 // `defer` (wsdl_conv2d_wgrad_deferred): the slabs are left un-reduced and *defer describes the reduction (kind < 0: nothing is
 // pending - the call reduced by itself, e.g. a batch processed in slices).
+// per-channel operands (optional; wsdl_conv2d_wgrad_ex): x_chan / dy_chan = one maximum per channel of x / dY as published by the
+// channel-resident BatchNorm kernels; dy_presplit = dY already as the kernel's fp16 rows, scaled per channel by dy_chan
+struct WgradExtra {
+    const float* x_chan;
+    const float* dy_chan;
+    const void* dy_presplit;
+};
 static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
                       int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
                       long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax, void* ws,
-                      size_t ws_bytes, wsdl_stream_t stream, wsdl_wgrad_reduce_desc* defer) {
+                      size_t ws_bytes, wsdl_stream_t stream, wsdl_wgrad_reduce_desc* defer, WgradExtra ex = WgradExtra{}) {
     WSDL_REQUIRE(x && dy && dw && ws, "conv2d_wgrad: null pointer");
     if (defer) defer->kind = -1;
     int OH, OW;
@@ -2380,7 +2512,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
             wsdl_wgrad_reduce_desc inner{};
             if (int rc = wgrad_impl(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
                                     dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
-                                    dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, &inner))
+                                    dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, &inner,
+                                    WgradExtra{ex.dy_chan, ex.x_chan, nullptr}))
                 return rc;
             if (inner.kind == WSDL_WGRAD_REDUCE_VEC4) {
                 *defer = inner;                      // slab, S as recorded: slab[z][ci][co]
@@ -2401,7 +2534,8 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
             }
         } else if (int rc = wgrad_impl(dy, x, dwt, B, Cout, OH, OW, Cin, 1, 1, 1, 0, 1, 0,
                                        dy_bs ? dy_bs : (long long)Cout * OH * OW, x_bs ? x_bs : (long long)Cin * H * W,
-                                       dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, nullptr))
+                                       dy_amax, x_amax, static_cast<char*>(ws) + t_bytes, ws_bytes - t_bytes, stream, nullptr,
+                                       WgradExtra{ex.dy_chan, ex.x_chan, nullptr}))
             return rc;
         WSDL_TRACE("role-swapped (dW^T) + transpose");
         hipLaunchKernelGGL(transpose_add_kernel, dim3(wsdl::cdiv(Cout, 32), wsdl::cdiv(Cin, 32)), dim3(32, 8), 0,
@@ -2417,6 +2551,42 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
     p.x_bs = x_bs ? x_bs : (long long)Cin * H * W;
     p.dy_bs = dy_bs ? dy_bs : (long long)Cout * OH * OW;
     p.x_amax = x_amax;
+    if (stem_wgrad_eligible(B, Cin, H, W, Cout, kh, kw, stride, pad, dil) &&
+        (long long)B * wsdl::cdiv(OH, kSwTH) * wsdl::cdiv(OW, kStemTW) < (1ll << 31)) {
+        const int G = stem_wgrad_grid(B, OH, OW);
+        const size_t need = (size_t)G * Cout * p.N * sizeof(float);
+        if (ws_bytes < need) {
+            wsdl::set_error("conv2d_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+            return WSDL_EWORKSPACE;
+        }
+        hipStream_t s = wsdl::as_stream(stream);
+        const int tiles_w = wsdl::cdiv(OW, kStemTW), tiles_h = wsdl::cdiv(OH, kSwTH);
+        {
+            const double flops = 2.0 * p.P * (double)Cout * p.N;
+            wsdl::ProfScope prof(WSDL_PROF_WGRAD_64x128, s, flops, flops, 4.0 * ((double)B * Cin * H * W + (double)p.P * Cout + (double)G * Cout * p.N));
+            WSDL_TRACE("stem_wgrad7x7s2 fp32 workgroups=%d slabs=%d", G, G);
+            hipLaunchKernelGGL(stem_wgrad7x7s2_kernel, dim3(G), dim3(256), 0, s, p, tiles_w, tiles_h, B * tiles_w * tiles_h);
+            WSDL_LAUNCH_CHECK();
+        }
+        wsdl_wgrad_reduce_desc rd{};
+        rd.slab = p.slab; rd.dw = dw; rd.S = G; rd.Cout = Cout; rd.Cin = Cin; rd.T = kh * kw; rd.accumulate = accumulate;
+        rd.live = ~0ull;
+        const long long total = (long long)Cout * p.N;
+        if (G >= 16) {
+            rd.kind = WSDL_WGRAD_REDUCE_MANY;
+            rd.nblocks = (int)((total + 63) / 64);
+        } else {
+            rd.kind = WSDL_WGRAD_REDUCE_PLAIN;
+            rd.nblocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        }
+        if (defer) {
+            *defer = rd;
+            WSDL_TRACE("wgrad_reduce slabs=%d deferred", G);
+            return WSDL_OK;
+        }
+        WSDL_TRACE("wgrad_reduce slabs=%d", G);
+        return wgrad_reduce_one(rd, s);
+    }
     const unsigned long long live_all = live_taps(H, W, OH, OW, kh, kw, stride, pad, dil);
     const int S = wgrad_splits(Cout, Cin, p.N, p.P, __builtin_popcountll(live_all) * Cin, wgrad_tap_balance(H, OH, kh, stride, pad, dil));
     Band bands[8];
@@ -2448,7 +2618,7 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
             const int nb_img = (int)std::min<long long>(per, B - b0);
             if (int rc = wgrad_impl(x + (long long)b0 * p.x_bs, dy + (long long)b0 * p.dy_bs, dw, nb_img, Cin, H, W,
                                     Cout, kh, kw, stride, pad, dil, (accumulate || b0 > 0) ? 1 : 0, p.x_bs, p.dy_bs,
-                                    x_amax, dy_amax, ws, ws_bytes, stream, nullptr))
+                                    x_amax, dy_amax, ws, ws_bytes, stream, nullptr, WgradExtra{ex.x_chan, ex.dy_chan, nullptr}))
                 return rc;
         }
         return WSDL_OK;
@@ -2506,24 +2676,44 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
                 dim3 grid(p.N / 128, Cout / 128, S);
                 p.xcd_order = ((long long)grid.x * grid.y * grid.z) % 8 == 0 ? g_wgrad_xcd : 0;
                 const dim3 sgrid((int)std::min<long long>((total + 255) / 256, 16384));
-                // the range guard of the weight gradient: a scale per channel (maxima taken here, one read of x and of dY)
+                // Per-channel scales (the range guard of the weight gradient; exact: a channel is a row / column of this GEMM's
+                // output).  Where the caller has the channels' maxima - the channel-resident BatchNorm kernels publish them
+                // for nothing - they are used as they are; "wgrad_chan_scale" takes the missing ones with a pre-pass (one more
+                // read of that operand); an operand without either keeps its one scale per tensor (stride 0).
                 const size_t cm_off = wsdl::align_up(dys_off + dys_bytes, 256);
-                const bool cs = g_wgrad_chan_scale && g_conv_arith &&
-                                ws_bytes >= cm_off + (size_t)(Cin + Cout) * sizeof(float);
+                const bool cm_fits = ws_bytes >= cm_off + (size_t)(Cin + Cout) * sizeof(float);
+                p.xa_stride = 0;
                 int dy_stride = 0;
-                if (cs) {
+                if (g_conv_arith) {
                     float* cm = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + cm_off);
-                    WSDL_HIP_CHECK(hipMemsetAsync(cm, 0, (size_t)(Cin + Cout) * sizeof(float), s));
-                    hipLaunchKernelGGL(channel_amax_kernel, dim3(Cin, std::min(B, std::max(1, 1024 / Cin))), dim3(256), 0, s, x, B, Cin,
-                                       H * W, p.x_bs, cm);
-                    WSDL_LAUNCH_CHECK();
-                    hipLaunchKernelGGL(channel_amax_kernel, dim3(Cout, std::min(B, std::max(1, 1024 / Cout))), dim3(256), 0, s, dy, B,
-                                       Cout, OH * OW, p.dy_bs, cm + Cin);
-                    WSDL_LAUNCH_CHECK();
-                    p.x_amax = x_amax = cm;
-                    dy_amax = cm + Cin;
-                    dy_stride = 1;
+                    if (ex.x_chan) {
+                        p.x_amax = x_amax = ex.x_chan;
+                        p.xa_stride = 1;
+                    } else if (g_wgrad_chan_scale && cm_fits) {
+                        WSDL_HIP_CHECK(hipMemsetAsync(cm, 0, (size_t)Cin * sizeof(float), s));
+                        hipLaunchKernelGGL(channel_amax_kernel, dim3(Cin, std::min(B, std::max(1, 1024 / Cin))), dim3(256), 0, s, x, B, Cin,
+                                           H * W, p.x_bs, cm);
+                        WSDL_LAUNCH_CHECK();
+                        p.x_amax = x_amax = cm;
+                        p.xa_stride = 1;
+                    }
+                    if (ex.dy_chan) {
+                        dy_amax = ex.dy_chan;
+                        dy_stride = 1;
+                    } else if (g_wgrad_chan_scale && cm_fits) {
+                        WSDL_HIP_CHECK(hipMemsetAsync(cm + Cin, 0, (size_t)Cout * sizeof(float), s));
+                        hipLaunchKernelGGL(channel_amax_kernel, dim3(Cout, std::min(B, std::max(1, 1024 / Cout))), dim3(256), 0, s, dy, B,
+                                           Cout, OH * OW, p.dy_bs, cm + Cin);
+                        WSDL_LAUNCH_CHECK();
+                        dy_amax = cm + Cin;
+                        dy_stride = 1;
+                    }
                 }
+                p.da_stride = dy_stride;
+                const bool cs = p.xa_stride || dy_stride;
+                // dY already in the kernel's row format (written by the BatchNorm backward that produced it, scaled per channel)
+                const bool presplit = ex.dy_presplit && ex.dy_chan && g_conv_arith;
+                if (presplit) dys = static_cast<unsigned char*>(const_cast<void*>(ex.dy_presplit));
                 if (g_conv_arith) {
                     WSDL_REQUIRE(x_amax && dy_amax, "conv2d_wgrad: the fp16x2 split kernel needs x_amax and dy_amax");
                     // the direct-fragment kernel where every tap's column shift is a multiple of 4 elements (its two
@@ -2537,11 +2727,11 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
                         // dY straight from the fp32 tensor (no pre-split pass) where its rows are 16-byte aligned too
                         // - where few N tiles share a row tile of dY (1x1 convolutions up to 1280 input channels: every N tile's
                         // workgroup splits its slice again; 7-11 % faster there, 7-21 % slower on the 3x3 shapes with 36-72 N tiles)
-                        const bool dyraw = taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
+                        const bool dyraw = !presplit && taps_aligned && g_wgrad_dyraw && (p.N / 128 <= 10 || g_wgrad_dyraw == 2) &&
                                            (OH * OW) % 4 == 0 && p.dy_bs % 4 == 0 &&
                                            reinterpret_cast<uintptr_t>(dy) % 16 == 0 && p.dy_bytes != 0;
-                        WSDL_TRACE(dyraw ? "dyraw" : "dy_split16");
-                        if (!dyraw) {
+                        WSDL_TRACE(dyraw ? "dyraw" : presplit ? "dY pre-split by its producer" : "dy_split16");
+                        if (!dyraw && !presplit) {
                             hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
                                                dy_stride);
                             WSDL_LAUNCH_CHECK();
@@ -2559,10 +2749,12 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
                             hipLaunchKernelGGL(conv_wgrad_split16d_kernel<0>, grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
                     } else {
-                        WSDL_TRACE("dy_split16");
-                        hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
-                                           dy_stride);
-                        WSDL_LAUNCH_CHECK();
+                        WSDL_TRACE(presplit ? "dY pre-split by its producer" : "dy_split16");
+                        if (!presplit) {
+                            hipLaunchKernelGGL(dy_split16_kernel, sgrid, dim3(256), 0, s, dy, dys, B, Cout, OH * OW, p.dy_bs, p.P, dy_amax,
+                                               dy_stride);
+                            WSDL_LAUNCH_CHECK();
+                        }
                         if (cs)
                             hipLaunchKernelGGL((conv_wgrad_split16_kernel<128, 128, true>), grid, dim3(kThreads), 0, s, p, dys,
                                                (unsigned)dys_bytes, dy_amax);
@@ -2653,6 +2845,18 @@ int wsdl_conv2d_wgrad_deferred(const float* x, const float* dy, float* dw, int B
     WSDL_REQUIRE(desc != nullptr, "conv2d_wgrad_deferred: null descriptor");
     return wgrad_impl(x, dy, dw, B, Cin, H, W, Cout, kh, kw, stride, pad, dil, accumulate, x_bs, dy_bs, x_amax, dy_amax, ws,
                       ws_bytes, stream, desc);
+}
+
+int wsdl_conv2d_wgrad_ex(const float* x, const float* dy, float* dw, int B, int Cin, int H, int W,
+                         int Cout, int kh, int kw, int stride, int pad, int dil, int accumulate,
+                         long long x_bs, long long dy_bs, const float* x_amax, const float* dy_amax,
+                         const float* x_chan_amax, const float* dy_chan_amax, const void* dy_presplit, void* ws,
+                         size_t ws_bytes, wsdl_wgrad_reduce_desc* desc_or_null, wsdl_stream_t stream) {
+    WSDL_REQUIRE(!dy_presplit || dy_chan_amax, "conv2d_wgrad_ex: dy_presplit comes with dy_chan_amax (the scales it was written with)");
+    WSDL_REQUIRE(!dy_presplit || wsdl_conv2d_wgrad_presplit_bytes(B, Cin, H, W, Cout, kh, kw, stride, pad, dil) != 0,
+                 "conv2d_wgrad_ex: this geometry's weight gradient does not read pre-split dY (wsdl_conv2d_wgrad_presplit_bytes)");
+    return wgrad_impl(x, dy, dw, B, Cin, H, W, Cout, kh, kw, stride, pad, dil, accumulate, x_bs, dy_bs, x_amax, dy_amax, ws,
+                      ws_bytes, stream, desc_or_null, WgradExtra{x_chan_amax, dy_chan_amax, dy_presplit});
 }
 
 int wsdl_wgrad_reduce_multi(const wsdl_wgrad_reduce_desc* desc, int n, int total_blocks, wsdl_stream_t stream) {

@@ -48,10 +48,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 // (x0, x1) -> packed bf16 pairs of the three pieces
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
@@ -61,15 +58,6 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& h, unsigned
     m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
     f32x2 s = {r[0] - __builtin_bit_cast(float, m << 16), r[1] - __builtin_bit_cast(float, m & 0xffff0000u)};
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2));
-}
-
-// (x0, x1), already scaled -> packed fp16 pairs of the two pieces (round to nearest even; x - h is exact in fp32)
-__device__ __forceinline__ void split2h(float x0, float x1, unsigned& h, unsigned& l) {
-    f32x2 v = {x0, x1};
-    const half2v hv = __builtin_convertvector(v, half2v);
-    h = __builtin_bit_cast(unsigned, hv);
-    f32x2 r = {x0 - (float)hv[0], x1 - (float)hv[1]};
-    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
 }
 
 // fp16x2 with the LOW piece carried at 2^11 times its value ("AR = 2"): l' = fp16((x - h) * 2^11).  |x - h| <= 2^-11 |h|, so l'
@@ -83,19 +71,6 @@ __device__ __forceinline__ void split2hs(float x0, float x1, unsigned& h, unsign
     h = __builtin_bit_cast(unsigned, hv);
     f32x2 r = {(x0 - (float)hv[0]) * 2048.f, (x1 - (float)hv[1]) * 2048.f};
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, half2v));
-}
-
-// power-of-two scale that puts amax in [2^14, 2^15); 1 for amax = 0 / inf / NaN.  `e` returns its exponent.
-__device__ __forceinline__ float pow2_scale(float amax, int& e) {
-    const unsigned bits = __builtin_bit_cast(unsigned, amax) & 0x7fffffffu;
-    const int be = (int)(bits >> 23);                   // biased exponent
-    e = (bits == 0u || be == 255) ? 0 : 14 - (be - 127);
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-    return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
-}
-__device__ __forceinline__ float pow2(int e) {          // |e| <= 200: two exact factors
-    const int e1 = e / 2, e2 = e - e1;
-    return __builtin_bit_cast(float, (unsigned)(e1 + 127) << 23) * __builtin_bit_cast(float, (unsigned)(e2 + 127) << 23);
 }
 
 template <int AR> struct SplitArith;
@@ -260,7 +235,7 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     // 16-byte slot each - 8 distinct slots of the 128-byte store bank row.  With one k run per wave (64 consecutive pixels, the
     // round 1-5 mapping) lanes i and i + 8 hit the same 8 bytes (8 rows of 80 bytes = 5 bank rows): a 2-way conflict on every
     // store, part of the 30 % of LDS-active cycles the counters showed (profiles/r05_pmc_dominant_kernels.txt).
-#ifndef WSDL_EXP_OLD_LDS_MAP
+#if !defined(WSDL_EXP_OLD_LDS_MAP) && !defined(WSDL_EXP_NO_PAIRB)
     constexpr bool kPairB = !MF && B_PER == 4 && B_STEP == 4;
 #else
     constexpr bool kPairB = false;
@@ -381,7 +356,7 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     // In unit order (a lane group = two rows x four parts) the group's first and last lane are 128 bytes apart: a 2-way
     // conflict on every weight store (conv_split.h said "conflict-free" until round 6; the counters did not).  The global side
     // is unchanged: a wave still loads one contiguous 1 KB run, its lanes permuted inside it.
-#ifndef WSDL_EXP_OLD_LDS_MAP
+#if !defined(WSDL_EXP_OLD_LDS_MAP) && !defined(WSDL_EXP_NO_ROWA)
     constexpr bool kRowMajorA = UPR == 4 && (A_UPS % 64) == 0;
 #else
     constexpr bool kRowMajorA = false;
@@ -1213,8 +1188,9 @@ __global__ void dy_split16_kernel(const float* __restrict__ dy, unsigned char* _
     }
 }
 
-// CS ("wgrad_chan_scale", the range guard of the weight gradient): p.x_amax / dy_amax are ARRAYS, one maximum per input / per
-// output channel.  A channel is a row or a column of this GEMM's OUTPUT (K = pixels), so a scale of its own per channel is
+// CS (per-channel scales, the range guard of the weight gradient): p.x_amax / dy_amax are read at [channel * p.xa_stride] /
+// [channel * p.da_stride] - stride 1: ARRAYS with one maximum per input / per output channel (published by the channel-resident
+// BatchNorm kernels that wrote the tensors, or taken by a pre-pass under "wgrad_chan_scale"), stride 0: one maximum for the tensor.  A channel is a row or a column of this GEMM's OUTPUT (K = pixels), so a scale of its own per channel is
 // a power of two on the operand's rows and the inverse on the result's rows / columns: exact, and no second accumulator set.
 template <int BM, int BN, bool CS = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP p, const unsigned char* __restrict__ dys,
@@ -1269,7 +1245,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     if constexpr (CS) {
         if (tid < BN) {
             int e_;
-            xst[tid] = pow2_scale(p.x_amax[ci0 + tid], e_);
+            xst[tid] = pow2_scale(p.x_amax[(ci0 + tid) * p.xa_stride], e_);
         }
         __syncthreads();
     }
@@ -1429,14 +1405,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     if constexpr (CS) {
         int en[TNI];
 #pragma unroll
-        for (int j = 0; j < TNI; ++j) (void)pow2_scale(p.x_amax[ci0 + wn * (BN / 2) + j * 16 + l15], en[j]);
+        for (int j = 0; j < TNI; ++j) (void)pow2_scale(p.x_amax[(ci0 + wn * (BN / 2) + j * 16 + l15) * p.xa_stride], en[j]);
 #pragma unroll
         for (int i = 0; i < TMI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
                 int edr;
-                (void)pow2_scale(dy_amax[co], edr);
+                (void)pow2_scale(dy_amax[co * p.da_stride], edr);
 #pragma unroll
                 for (int j = 0; j < TNI; ++j)
                     slab[(long long)co * p.N + n0 + wn * (BN / 2) + j * 16 + l15] = acc[i][j][r] * pow2(-(en[j] + edr));
@@ -1525,12 +1501,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
     int exr[CS ? TNI : 1];
     if constexpr (CS) {
 #pragma unroll
-        for (int j = 0; j < TNI; ++j) xsr[j] = pow2_scale(p.x_amax[ci0 + wid * 32 + j * 16 + l15], exr[j]);
+        for (int j = 0; j < TNI; ++j) xsr[j] = pow2_scale(p.x_amax[(ci0 + wid * 32 + j * 16 + l15) * p.xa_stride], exr[j]);
         if constexpr (DYRAW) {
 #pragma unroll
             for (int e = 0; e < A_U; ++e) {
                 int e_;
-                dsr[e] = pow2_scale(dy_amax[m0 + dr_row + 32 * e], e_);
+                dsr[e] = pow2_scale(dy_amax[(m0 + dr_row + 32 * e) * p.da_stride], e_);
             }
         }
     }
@@ -1724,7 +1700,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
             for (int r = 0; r < 4; ++r) {
                 const int co = m0 + i * 16 + lg * 4 + r;
                 int edr;
-                (void)pow2_scale(dy_amax[co], edr);
+                (void)pow2_scale(dy_amax[co * p.da_stride], edr);
 #pragma unroll
                 for (int j = 0; j < TNI; ++j)
                     slab[(long long)co * p.N + n0 + wid * 32 + j * 16 + l15] = acc[i][j][r] * pow2(-(exr[j] + edr));

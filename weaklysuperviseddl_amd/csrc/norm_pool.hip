@@ -338,7 +338,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ rmean, float* __restrict__ rvar,
     float momentum, float eps, const float* __restrict__ res, float* __restrict__ y, int B, int C, int HW,
     long long y_bs, int relu, float* __restrict__ amax, uint8_t* __restrict__ rmask, float* __restrict__ cmin,
-    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt) {
+    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt, float* __restrict__ chan_amax) {
     // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
     // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
     // S > 1: workgroup blockIdx.x = c * S + s holds slice s of channel c (coop_exchange above); S = 1: the whole channel
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             if (rmask) store_mask_pair(rmask, ((long long)b * C + c) * HW + r, o);
         }
     }
-    if (amax) publish_amax_min(vmax, amax, cmin);
+    if (amax) publish_amax_min(vmax, amax, cmin, (chan_amax && S == 1) ? chan_amax + c : nullptr);
 }
 
 template <int NT, int V = 16>
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ dx,
     float* __restrict__ dres, int B, int C, int HW, long long dy_bs, long long y_bs, int relu,
     float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask, float* __restrict__ cmin,
-    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt) {
+    int S, unsigned long long* __restrict__ part, int* __restrict__ cnt, float* __restrict__ chan_amax,
+    unsigned char* __restrict__ presplit) {
     __shared__ double sm[16];
     __shared__ float bc[2];
     const int c = S > 1 ? blockIdx.x / S : blockIdx.x, sl = S > 1 ? blockIdx.x - c * S : 0, tid = threadIdx.x;
@@ -482,9 +483,37 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             *reinterpret_cast<float4*>(dx + o) = d;
             vmax = amax4(vmax, d);
             if (dres) *reinterpret_cast<float4*>(dres + o) = g[k];
+            if (presplit) g[k] = d;                      // kept for the pre-split rows below (g is dead otherwise)
         }
     }
-    if (amax) publish_amax_min(vmax, amax, cmin);
+    if (presplit) {
+        // dx is the dY operand of the producing convolution's WEIGHT GRADIENT (conv_wgrad_split16*_kernel), which wants it as
+        // fp16 (high, low) pieces in 128-byte rows [pixel / 32][channel] - a pass of its own until round 5 (dy_split16_kernel:
+        // one more read and write of dY per layer, 24 launches per training step).  This workgroup holds the whole channel in
+        // registers: it takes the channel's maximum (one more workgroup-wide reduction), derives the channel's power-of-two scale
+        // - per CHANNEL, which a separate pass could only afford per tensor without reading dY twice - and writes the rows.
+        // A thread's float4 is half of a 16-byte unit (8 pixels): lane pairs fill units, a wave 8 whole rows.
+        __shared__ float smx[17];
+        const float cm = block_max_all(vmax, smx);
+        int e_;
+        const float sc = pow2_scale(cm, e_);
+        const unsigned sw = (unsigned)((c >> 1) & 7);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int i4 = tid + k * NT;
+            if (i4 < n4) {
+                const int pix = (lo4 + i4) << 2;             // linear pixel (b, h, w) of the float4's first element
+                const unsigned kg = (unsigned)((pix & 31) >> 3), half = (unsigned)((pix >> 2) & 1);
+                unsigned h0, l0, h1, l1;
+                split2h(g[k].x * sc, g[k].y * sc, h0, l0);
+                split2h(g[k].z * sc, g[k].w * sc, h1, l1);
+                unsigned char* row = presplit + ((long long)(pix >> 5) * C + c) * 128 + half * 8;
+                *reinterpret_cast<u32x2*>(row + ((kg ^ sw) << 4)) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(row + (((4u + kg) ^ sw) << 4)) = u32x2{l0, l1};
+            }
+        }
+    }
+    if (amax) publish_amax_min(vmax, amax, cmin, (chan_amax && S == 1) ? chan_amax + c : nullptr);
 }
 
 // threads of the channel-resident form for (C, n = B*HW values per channel), 0 = use the two-kernel form
@@ -777,6 +806,11 @@ inline int flat_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256,
 
 extern "C" {
 
+int wsdl_bn_channel_resident(int B, int C, int HW, int backward) {
+    if (B <= 0 || C <= 0 || HW <= 0) return 0;
+    return resident_threads(C, (long long)B * HW, HW, backward != 0) != 0 && coop_slices(C, B, HW) == 1;
+}
+
 size_t wsdl_bn_workspace(int C) {
     return C > 0 ? (size_t)C * kStatSplit * 2 * sizeof(double) + (size_t)C * 2 * sizeof(float) : 0;
 }
@@ -784,7 +818,8 @@ size_t wsdl_bn_workspace(int C) {
 int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                       float* save_invstd, float* running_mean, float* running_var, float momentum,
                       float eps, int B, int C, int HW, const float* residual, int relu, long long y_bs,
-                      float* y_amax, uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, wsdl_stream_t stream) {
+                      float* y_amax, uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, float* chan_amax,
+                      wsdl_stream_t stream) {
     WSDL_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     WSDL_REQUIRE(!relu_mask || (relu && (HW & 7) == 0), "bn_train_fwd: the bit mask needs relu and HW %% 8 == 0");
     WSDL_REQUIRE(B > 0 && C > 0 && C <= 65535 && HW > 0 && (long long)B * HW < (1ll << 31), "bn_train_fwd: bad shape");
@@ -797,11 +832,16 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
     WSDL_REQUIRE(!relu_mask || (y_bs & 3) == 0, "bn_train_fwd: the bit mask needs a 16-byte aligned batch stride");
     hipStream_t s = wsdl::as_stream(stream);
     float* cmin = (wsdl::g_range_sentinel && y_amax) ? y_amax + 1 : nullptr;      // "range_sentinel": y_amax is a (max, ~min) pair
+    WSDL_REQUIRE(!chan_amax || (y_amax && wsdl_bn_channel_resident(B, C, HW, 0) && (y_bs & 3) == 0 && (!coop || coop_slices(C, B, HW) == 1)),
+                 "bn_train_fwd: chan_amax needs the channel-resident kernel (wsdl_bn_channel_resident) and y_amax");
     if (const int S = (coop && (y_bs & 3) == 0) ? coop_slices(C, B, HW) : 1; S > 1) {
         // several workgroups per channel (coop_exchange): partial sums in the workspace, the channel's counters in `coop`
+        // (re-armed here as well as by the last workgroup out: a launch whose wait ran into its bound - two processes sharing the
+        // GPU - must not leave counters behind that poison every later launch on the stream)
+        WSDL_HIP_CHECK(hipMemsetAsync(coop, 0, (size_t)2 * C * sizeof(int), s));
         hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C * S), dim3(1024), 0, s, x, gamma, beta, save_mean,
                            save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                           y_amax, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop);
+                           y_amax, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop, (float*)nullptr);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -809,19 +849,19 @@ int wsdl_bn_train_fwd(const float* x, const float* gamma, const float* beta, flo
         if (nt == 1025)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 16>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax);
         else if (nt == 1024)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax);
         else if (nt == 256)
             hipLaunchKernelGGL((bn_fwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax);
         else
             hipLaunchKernelGGL((bn_fwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, gamma, beta, save_mean,
                                save_invstd, running_mean, running_var, momentum, eps, residual, y, B, C, HW, y_bs, relu,
-                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               y_amax, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -840,7 +880,8 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
                       const float* save_mean, const float* save_invstd, float* dx, float* dgamma,
                       float* dbeta, float* dres, int B, int C, int HW, int relu,
                       int accumulate_param_grads, long long dy_bs, long long y_bs, float* dx_amax,
-                      const uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, wsdl_stream_t stream) {
+                      const uint8_t* relu_mask, void* ws, size_t ws_bytes, int* coop, float* chan_amax, void* dy_presplit,
+                      wsdl_stream_t stream) {
     WSDL_REQUIRE(x && dy && gamma && save_mean && save_invstd && dx && ws, "bn_train_bwd: null pointer");
     WSDL_REQUIRE(relu != 1 || y, "bn_train_bwd: relu = 1 takes the mask from the forward output y");
     WSDL_REQUIRE(relu != 2 || beta, "bn_train_bwd: relu = 2 recomputes the mask from x and needs beta");
@@ -856,10 +897,16 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     if (!y_bs) y_bs = (long long)C * HW;
     hipStream_t s = wsdl::as_stream(stream);
     float* cmin = (wsdl::g_range_sentinel && dx_amax) ? dx_amax + 1 : nullptr;
+    WSDL_REQUIRE(!(chan_amax || dy_presplit) || (dx_amax && wsdl_bn_channel_resident(B, C, HW, 1) && ((dy_bs | y_bs) & 3) == 0 &&
+                                                 (!coop || coop_slices(C, B, HW) == 1)),
+                 "bn_train_bwd: chan_amax / dy_presplit need the channel-resident kernel (wsdl_bn_channel_resident) and dx_amax");
+    WSDL_REQUIRE(!dy_presplit || (chan_amax && ((long long)B * HW) % 32 == 0),
+                 "bn_train_bwd: dy_presplit needs chan_amax (its scales) and B * HW a multiple of 32");
     if (const int S = (coop && ((dy_bs | y_bs) & 3) == 0) ? coop_slices(C, B, HW) : 1; S > 1) {
+        WSDL_HIP_CHECK(hipMemsetAsync(coop, 0, (size_t)2 * C * sizeof(int), s));      // (see the forward)
         hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C * S), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                            save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                           dx_amax, beta, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop);
+                           dx_amax, beta, relu_mask, cmin, S, static_cast<unsigned long long*>(ws), coop, (float*)nullptr, (unsigned char*)nullptr);
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }
@@ -867,15 +914,15 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
         if (nt == 1024)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
         else if (nt == 256)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<256>), dim3(C), dim3(256), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
         else
             hipLaunchKernelGGL((bn_bwd_resident_kernel<512>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr);
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
         WSDL_LAUNCH_CHECK();
         return WSDL_OK;
     }

@@ -403,6 +403,8 @@ def set_option(name, value):
     check(lib().wsdl_set_option(name.encode(), int(value)))
     if name == "conv_arith":
         CONV_ARITH[0] = int(value != 0)
+    if name == "bn_coop":
+        BN_COOP_ON[0] = int(value) > 0
     _both_split_cache.clear()          # what the library answered under the old option set
     _size_cache.clear()
     LAYOUT_EPOCH[0] += 1
@@ -849,6 +851,11 @@ class _ReduceDesc(C.Structure):       # wsdl_wgrad_reduce_desc (include/wsdl_hip
 # gradient bucket's all-reduce, before the optimiser step.  ~60 launches of 9-10 us per training step become one (or one per
 # bucket).  Bit-identical to the per-layer reductions.  WSDL_WGRAD_DEFER=0: the per-layer form (A/B).
 WGRAD_DEFER = [os.environ.get("WSDL_WGRAD_DEFER", "1") != "0"]
+# ... in groups: pending reductions are flushed once their slabs exceed this many bytes, so that most of the summing happens
+# DURING the backward pass (on the side stream, between weight-gradient kernels) and only the last group's behind it.
+# Everything in ONE launch at the end of backward measured 1 % SLOWER than the per-layer launches (844-847 against 851-856
+# img/s, same box): ~0.5 GB of slabs read in the one place of the step where nothing overlaps them.
+WGRAD_DEFER_BYTES = [int(float(os.environ.get("WSDL_WGRAD_DEFER_MB", "48")) * (1 << 20))]
 _wgrad_pending = {}       # device -> {"descs": [_ReduceDesc], "dws": set of dw pointers, "keep": [tensors], "side": bool, "cb": bool}
 _wgrad_ws = {}            # (device, geometry, dw pointer) -> that layer's own workspace (its slabs outlive the launch)
 _reduce_tables = {}       # descriptor bytes -> (device table, n, total blocks)
@@ -857,7 +864,7 @@ _reduce_tables = {}       # descriptor bytes -> (device table, n, total blocks)
 def _pending_of(device):
     pend = _wgrad_pending.get(device)
     if pend is None:
-        pend = _wgrad_pending[device] = {"descs": [], "dws": set(), "keep": [], "side": False, "cb": False}
+        pend = _wgrad_pending[device] = {"descs": [], "dws": set(), "keep": [], "side": False, "cb": False, "bytes": 0}
     return pend
 
 
@@ -893,7 +900,7 @@ def flush_wgrad_reduces(device=None):
         if rec is not None:
             rec.keep.extend(pend["keep"])        # the slabs' workspaces: their addresses are inside the table, not arguments
         check(lib().wsdl_wgrad_reduce_multi(_p(ent[0]), ent[1], ent[2], hs))
-        pend["descs"], pend["keep"], pend["side"], pend["cb"] = [], [], False, False
+        pend["descs"], pend["keep"], pend["side"], pend["cb"], pend["bytes"] = [], [], False, False, 0
         pend["dws"].clear()
 
 
@@ -910,11 +917,27 @@ def _queue_flush(pend):
     return True
 
 
-def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None, stream=None, defer=False):
+def wgrad_presplit_bytes(xshape, wshape, stride, pad, dil):
+    """Bytes of the pre-split dY rows the weight gradient of this convolution reads when its producer writes them
+    (``bn_train_bwd(presplit_bytes=)``); 0 where it would not use them."""
+    B, Cin, H, W = xshape
+    Cout, _, kh, kw = wshape
+    return _ws_bytes("wsdl_conv2d_wgrad_presplit_bytes", B, Cin, H, W, Cout, kh, kw, stride, pad, dil)
+
+
+def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_amax=None, dy_amax=None, stream=None, defer=False,
+                 x_camax=None, dy_camax=None, dy_presplit=None):
     """``stream``: raw handle of the stream to launch on (default: the current stream) - the side-stream launches of the
     training step pass it instead of switching torch's current stream (a ``with torch.cuda.stream()`` costs the host ~20 us,
     61 times per step).  ``defer``: leave the slab reduction to ``flush_wgrad_reduces`` (``out`` given; the caller has made
-    sure a flush follows - ``_wgrad_into``)."""
+    sure a flush follows - ``_wgrad_into``).  ``x_camax`` / ``dy_camax``: per-channel maxima of the operands (``_wsdl_camax`` of a
+    BatchNorm output / input gradient), ``dy_presplit``: dY as the kernel's fp16 rows (``_wsdl_presplit``) - wsdl_conv2d_wgrad_ex."""
+    if dy_camax is None:
+        dy_presplit = None
+    elif dy_presplit is None:
+        dy_camax_p = getattr(dy, "_wsdl_camax", None)
+        if dy_camax_p is dy_camax:
+            dy_presplit = getattr(dy, "_wsdl_presplit", None)
     if stream is not None and stream != _stream():
         # everything this function would otherwise enqueue on the CURRENT stream (amax passes, densifying copies) must have
         # been resolved by the caller, in front of the wait that orders ``stream`` behind the current one (_wgrad_into)
@@ -948,22 +971,24 @@ def conv2d_wgrad(x, dy, wshape, stride, pad, dil, out=None, accumulate=False, x_
             ws = _wgrad_ws[wkey] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
         desc = _ReduceDesc()
         hs = _stream() if stream is None else stream
-        check(lib().wsdl_conv2d_wgrad_deferred(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
-                                               _p(ws), ws.numel(), C.byref(desc), hs))
+        check(lib().wsdl_conv2d_wgrad_ex(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
+                                         _p(x_camax), _p(dy_camax), _p(dy_presplit), _p(ws), ws.numel(), C.addressof(desc), hs))
         if desc.kind >= 0:
             pend["descs"].append(desc)
             pend["dws"].add(out.data_ptr())
             pend["keep"].append(ws)
             pend["side"] = pend["side"] or hs != raw_stream(dev)
-            if not _queue_flush(pend):
+            pend["bytes"] += 4 * desc.S * desc.Cout * desc.Cin * desc.T
+            if pend["bytes"] >= WGRAD_DEFER_BYTES[0] or not _queue_flush(pend):
                 flush_wgrad_reduces(dev)
         return out
     ws = workspace(nbytes, x.device, stream)
     if out is None:
         out = torch.empty(wshape, device=x.device, dtype=torch.float32)
         accumulate = False
-    check(lib().wsdl_conv2d_wgrad(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
-                                  _p(ws), ws.numel(), _stream() if stream is None else stream))
+    check(lib().wsdl_conv2d_wgrad_ex(_p(x), _p(dy), _p(out), *geom, int(accumulate), x_bs, dy_bs, _p(x_amax), _p(dy_amax),
+                                     _p(x_camax), _p(dy_camax), _p(dy_presplit), _p(ws), ws.numel(), None,
+                                     _stream() if stream is None else stream))
     return out
 
 
@@ -984,6 +1009,28 @@ def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps):
     check(lib().wsdl_bn_fold(_p(_dense(bn_weight)), _p(_dense(bn_bias)), _p(_dense(running_mean)),
                              _p(_dense(running_var)), float(eps), _p(scale), _p(shift), Cc, _stream()))
     return scale, shift
+
+
+# Per-channel maxima from the channel-resident BatchNorm kernels -> per-channel scales of the weight gradients (exact; the range
+# guard of the weight gradient for nothing), and the weight gradient's dY operand written pre-split by the BatchNorm backward that
+# produces it (no dy_split16 pass).  WSDL_CHAN_AMAX=0 / WSDL_DY_PRESPLIT=0: the round-5 forms (A/B).
+CHAN_AMAX = [os.environ.get("WSDL_CHAN_AMAX", "1") != "0"]
+DY_PRESPLIT = [os.environ.get("WSDL_DY_PRESPLIT", "1") != "0"]
+
+
+def _bn_resident(B, Cc, HW, backward):
+    key = ("wsdl_bn_channel_resident", (B, Cc, HW, backward))
+    r = _size_cache.get(key)
+    if r is None:
+        r = _size_cache[key] = bool(lib().wsdl_bn_channel_resident(B, Cc, HW, backward)) and coop_off()
+    return r
+
+
+def coop_off():
+    return not BN_COOP_ON[0]
+
+
+BN_COOP_ON = [False]       # set by set_option("bn_coop", n > 0): several workgroups per channel publish no per-channel maximum
 
 
 # The ReLU mask of a residual layer as bits written by the forward kernel (1/32 of the bytes of y, which the backward would
@@ -1012,16 +1059,24 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, resid
     mask = None
     if want_mask and mask_if and relu and BN_RELU_BITS[0] and (H * W) % 8 == 0 and y_bs % 4 == 0:
         mask = torch.empty(x.numel() // 8, device=x.device, dtype=torch.uint8)
+    # per-channel maxima of the output: the scales of the weight gradient that reads it as its x operand (free in the
+    # channel-resident kernel: the channel's workgroup has the maximum anyway)
+    camax = None
+    if y_amax is not None and CHAN_AMAX[0] and y_bs % 4 == 0 and _bn_resident(B, Cc, H * W, 0):
+        camax = torch.empty(Cc, device=x.device, dtype=torch.float32)
     check(lib().wsdl_bn_train_fwd(_p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(invstd), _p(running_mean),
                                   _p(running_var), float(momentum), float(eps), B, Cc, H * W, _p(residual),
-                                  int(relu), y_bs, _p(y_amax), _p(mask), _p(ws), ws.numel(), _p(coop_counters(x.device)), _stream()))
+                                  int(relu), y_bs, _p(y_amax), _p(mask), _p(ws), ws.numel(), _p(coop_counters(x.device)),
+                                  _p(camax), _stream()))
     if y_amax is not None:
         _publish_amax(out, y_amax)
+    if camax is not None:
+        out._wsdl_camax = camax
     return (out, mean, invstd, mask) if want_mask else (out, mean, invstd)
 
 
 def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None, dbeta_out=None, accumulate=False,
-                 beta=None, relu_mask=None):
+                 beta=None, relu_mask=None, presplit_bytes=0):
     """``relu``: True with ``y`` = the forward output (mask read from it), or True with ``relu_mask`` = the bits the
     forward wrote (``bn_train_fwd(want_mask=True)``), or True with ``y=None`` and ``beta`` given: the mask is recomputed
     from x (no residual was added in the forward) and y is never touched."""
@@ -1049,13 +1104,24 @@ def bn_train_bwd(x, dy, y, gamma, mean, invstd, relu, want_dres, dgamma_out=None
     dres = torch.empty_like(x) if want_dres else None
     ws = workspace(_ws_bytes("wsdl_bn_workspace", Cc), x.device)
     dx_amax = amax_slot(x.device) if CONV_ARITH[0] == 1 else None
+    # ``presplit_bytes`` (wsdl_conv2d_wgrad_presplit_bytes of the convolution whose output gradient this is): dx is also written
+    # as the fp16 rows that convolution's weight gradient reads, scaled per channel - dy_split16_kernel does not run for it
+    camax = presplit = None
+    if dx_amax is not None and CHAN_AMAX[0] and dy_bs % 4 == 0 and y_bs % 4 == 0 and _bn_resident(B, Cc, H * W, 1):
+        camax = torch.empty(Cc, device=x.device, dtype=torch.float32)
+        if presplit_bytes and DY_PRESPLIT[0] and (B * H * W) % 32 == 0:
+            presplit = torch.empty(int(presplit_bytes), device=x.device, dtype=torch.uint8)
     check(lib().wsdl_bn_train_bwd(_p(x), _p(dy), _p(y if mode == 1 else None), _p(gamma),
                                   _p(_dense(beta) if mode == 2 else None), _p(mean), _p(invstd), _p(dx),
                                   _p(dgamma), _p(dbeta), _p(dres), B, Cc, H * W, mode, int(acc), dy_bs, y_bs,
                                   _p(dx_amax), _p(relu_mask if mode == 3 else None), _p(ws), ws.numel(),
-                                  _p(coop_counters(x.device)), _stream()))
+                                  _p(coop_counters(x.device)), _p(camax), _p(presplit), _stream()))
     if dx_amax is not None:
         _publish_amax(dx, dx_amax)
+    if camax is not None:
+        dx._wsdl_camax = camax
+        if presplit is not None:
+            dx._wsdl_presplit = presplit
     dx._wsdl_fresh = True
     if dres is not None:
         dres._wsdl_fresh = True
@@ -1112,7 +1178,7 @@ def join_side_stream(device):
         stream_wait(raw_stream(device), st)
 
 
-def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, last=False):
+def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, last=False, x_camax=None):
     """d(param) = wgrad(x, dconv) written straight into param.grad (a slice of the flat gradient buffer).
     ``last``: no input gradient follows (the network's first layer): nothing else is left for the main stream, so the
     kernel runs there, beside whatever the side stream still has queued, instead of behind it."""
@@ -1120,6 +1186,15 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
     split = _wgrad_split(wshape)
     x_amax = x_amax if x_amax is not None else amax_of(x, split)       # resolved on the MAIN stream (may launch a pass)
     dy_amax = amax_of(dconv, split)
+    # per-channel maxima / pre-split rows travel as attributes of the tensors their producers returned
+    dy_camax = getattr(dconv, "_wsdl_camax", None) if split else None
+    dy_presplit = getattr(dconv, "_wsdl_presplit", None) if dy_camax is not None else None
+    if not split:
+        x_camax = None
+    elif x_camax is None:
+        x_camax = getattr(x, "_wsdl_camax", None)
+    if x_camax is not None and x_camax.numel() != wshape[1]:
+        x_camax = None                  # (a channel slice / concatenation of the tensor that carried it)
     if OVERLAP_WGRAD[0] and not (last and LAST_WGRAD_ON_MAIN[0]):
         # a densifying copy (never needed by the training step's own tensors) would be enqueued on the CURRENT stream: make it
         # happen before the side stream's wait, not inside conv2d_wgrad behind it
@@ -1129,12 +1204,16 @@ def _wgrad_into(param, x, dconv, wshape, stride, pad, dil, sink, x_amax=None, la
         stream_wait(hside, _stream())               # dconv / x (and the zero_grad memset) are ready
         # launched ON the side stream by handle: torch's current stream stays the main one
         conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                     dy_amax=dy_amax, stream=hside, defer=WGRAD_DEFER[0])
+                     dy_amax=dy_amax, stream=hside, defer=WGRAD_DEFER[0], x_camax=x_camax, dy_camax=dy_camax,
+                     dy_presplit=dy_presplit)
+        for t in (x_camax, dy_camax, dy_presplit):
+            if t is not None:
+                t.record_stream(side)
         x.record_stream(side)                       # keep the caching allocator from recycling them early
         dconv.record_stream(side)
     else:
         conv2d_wgrad(x, dconv, wshape, stride, pad, dil, out=param.grad, accumulate=accumulate, x_amax=x_amax,
-                     dy_amax=dy_amax, defer=WGRAD_DEFER[0])
+                     dy_amax=dy_amax, defer=WGRAD_DEFER[0], x_camax=x_camax, dy_camax=dy_camax, dy_presplit=dy_presplit)
     sink.grad_ready(param)
 
 
@@ -1201,6 +1280,7 @@ class _ConvBNAct(torch.autograd.Function):
         ctx.cfg = (stride, pad, dil, relu, tuple(weight.shape), tuple(x.shape), residual is not None)
         ctx.params = (weight, gamma, beta)
         ctx.x_amax = x_amax              # saved tensors come back as new Python objects: keep the scalar explicitly
+        ctx.x_camax = getattr(x, "_wsdl_camax", None)     # ... and the per-channel maxima its producer published
         # the ReLU mask is recomputed from the conv output in the backward unless a residual was added: then the forward
         # kernel wrote it as bits (or, where it cannot - H*W not a multiple of 8 - y is kept and read)
         ctx.save_for_backward(x, conv, y if (relu and residual is not None and rbits is None) else None, gamma, mean, invstd,
@@ -1209,6 +1289,8 @@ class _ConvBNAct(torch.autograd.Function):
             xv = x.view_as(x)
             if x_amax is not None:
                 _publish_amax(xv, x_amax)
+            if ctx.x_camax is not None:
+                xv._wsdl_camax = ctx.x_camax
             return y, xv
         return y
 
@@ -1244,10 +1326,13 @@ class _ConvBNAct(torch.autograd.Function):
         else:
             relu_b, y_b, beta_b, bits_b = relu, y, beta_s, rbits
         sg = _sink_of(pg) if (ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and _sink_of(pg) is _sink_of(pb)) else None
+        # the weight gradient's dY operand, written pre-split by the BatchNorm backward where that launch reads it so
+        psb = wgrad_presplit_bytes(xshape, wshape, stride, pad, dil) if (ctx.needs_input_grad[1] and _sink_of(pw) is not None) else 0
         if sg is not None:
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
             dconv, _, _, dres = bn_train_bwd(conv, dy, y_b, _dense(gamma), mean, invstd, relu_b, need_res,
-                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_b, relu_mask=bits_b)
+                                             pg.grad, pb.grad, accumulate=not fresh, beta=beta_b, relu_mask=bits_b,
+                                             presplit_bytes=psb)
             dgamma = dbeta = None
             sg.grad_ready(pg)
             sg.grad_ready(pb)
@@ -1288,7 +1373,8 @@ class _ConvBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sw = _sink_of(pw)
             if sw is not None:
-                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax, last=not ctx.needs_input_grad[0])
+                _wgrad_into(pw, x, dconv, wshape, stride, pad, dil, sw, ctx.x_amax, last=not ctx.needs_input_grad[0],
+                            x_camax=ctx.x_camax)
             else:
                 dw = conv2d_wgrad(x, dconv, wshape, stride, pad, dil, x_amax=ctx.x_amax)
         if not WGRAD_AFTER_DGRAD[0]:
@@ -1333,10 +1419,13 @@ class _ConvBNBranches(torch.autograd.Function):
         ctx.cfg = ([(b[0], b[1]) for b in branches], wshapes, tuple(x.shape))
         ctx.params = [(w, g, b) for (w, g, b, _rm, _rv) in params]
         ctx.x_amax = x_amax
+        ctx.x_camax = getattr(x, "_wsdl_camax", None)
         ctx.save_for_backward(*saved)
         xv = x.view_as(x)
         if x_amax is not None:
             _publish_amax(xv, x_amax)
+        if ctx.x_camax is not None:
+            xv._wsdl_camax = ctx.x_camax
         return (*outs, xv)
 
     @staticmethod
@@ -1356,12 +1445,13 @@ class _ConvBNBranches(torch.autograd.Function):
             if sg is None or sg is not _sink_of(pb) or _sink_of(pw) is None:
                 raise WsdlError("conv -> BatchNorm branches: the parameters must be owned by a FlatAdam (gradient sinks)")
             fresh = sg.take_fresh(pg) & sg.take_fresh(pb)
+            pad, dil = geo[i]
             dconv, _, _, _ = bn_train_bwd(conv, dys[i], None, _dense(gamma), mean, invstd, True, False, pg.grad, pb.grad,
-                                          accumulate=not fresh, beta=beta)
+                                          accumulate=not fresh, beta=beta,
+                                          presplit_bytes=wgrad_presplit_bytes(xshape, wshapes[i], 1, pad, dil))
             sg.grad_ready(pg)
             sg.grad_ready(pb)
-            pad, dil = geo[i]
-            _wgrad_into(pw, x, dconv, wshapes[i], 1, pad, dil, _sink_of(pw), ctx.x_amax)
+            _wgrad_into(pw, x, dconv, wshapes[i], 1, pad, dil, _sink_of(pw), ctx.x_amax, x_camax=ctx.x_camax)
             dconvs.append(dconv)
             wds.append(wd)
         dx = None
