@@ -66,11 +66,16 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used
  *   col_bands      1*  dilated convolutions: one pixel-tile range per output-column band (exact padding-tap skipping)
  *   xcd_map        1*  XCD-aware tile order of the split kernels (0 off, 1 auto, 10 + py forces py row groups)
- *   wgrad_min_tiles 6*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles on (1: the layer2 1x1
- *                      kernels 20-30 % faster, the step 1 % slower - the pre-split, reduce and amax launches)
+ *   wgrad_min_tiles 1*  which shapes the fp16x2 weight-gradient kernel takes: from this many 128-wide N tiles on (rounds 2-5: 6 - from
+ *                      one tile on the layer2 1x1 kernels were 20-30 % faster and the step 1 % slower: pre-split, reduce and amax
+ *                      launches; round 6, with the pre-split and the maxima coming from the producers: +0.5-0.9 % on the step)
  *   wgrad_xcd      1*  split weight-gradient kernel: XCD-aware tile order (1 contiguous eighths, 2 in 2x2 blocks); bit-identical,
  *                      -1.4 % on the kernel sweep, +0.4 % on the step (half the traffic past L2 for the kernels beside it)
- *   group_tps10   20*  wsdl_conv2d_fwd_group: taps per K slice in tenths (20: a 9-tap problem in 4 slices, a 4-tap one in 2)
+ *   group_tps10   45*  wsdl_conv2d_fwd_group: taps per K slice in tenths (45: a 9-tap problem in 2 slices, the others whole; 20 -
+ *                      round 5's default: 4 and 2 slices, eight streams; same box 575.7 us at 45 against 638.6 at 20)
+ *   tile_img_major 1*  pixel tiles taken image-fastest inside a column band: 1 = in the grouped forward launch only, 2 = in every
+ *                      split launch with taps, 0 = off.  Tiles at the same place of different images run the same tap list;
+ *                      bit-identical; grouped forward 601.0 -> 575.7 us, multi-source input gradient 693 -> 709 (hence 1, not 2)
  *   group_interleave 1* ... with the workgroups of its (problem, slice) streams interleaved, one stream per XCD when there are 8
  *   ms_rowfast     1*  wsdl_conv2d_dgrad_multi: XCD-aware tile order taken row tile fastest;  ms_py 0* = 4 row groups (1 / 2 / 4 / 8)
  *   bn_coop        0*  (64 = on for the 64-channel layers) channel-resident BatchNorm kernels with 4 / 2 workgroups per channel for layers of up to this many channels
@@ -280,7 +285,7 @@ int wsdl_conv2d_wgrad(const float* x, const float* dy, float* dw,
  *   - desc->kind < 0: nothing is pending (the call reduced by itself: a batch processed in slices);
  *   - two deferred gradients into the same dw must not share a multi launch (flush in between). */
 enum { WSDL_WGRAD_REDUCE_PLAIN = 0, WSDL_WGRAD_REDUCE_TILED = 1, WSDL_WGRAD_REDUCE_VEC4 = 2, WSDL_WGRAD_REDUCE_MANY = 3,
-       WSDL_WGRAD_REDUCE_TRANSPOSED = 4 };
+       WSDL_WGRAD_REDUCE_TRANSPOSED = 4, WSDL_WGRAD_REDUCE_MANY16 = 5 };
 typedef struct wsdl_wgrad_reduce_desc {
     const float* slab;       /* [S][Cout][taps*Cin]   (TRANSPOSED: [S][Cin][Cout]) */
     float* dw;               /* [Cout][Cin][taps] */

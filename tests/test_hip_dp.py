@@ -450,3 +450,26 @@ def test_ranks_that_disagree_on_replaying_stay_in_step(dev, tmp_path):
     for pa, pb in zip(a["params"], b["params"]):
         assert torch.equal(pa, pb)
     assert torch.equal(b["params"][0], b["params"][1])
+
+
+def test_deferred_slab_reductions_under_the_bucket_reducer(dev, tmp_path):
+    """WSDL_WGRAD_DEFER=1 under data parallelism (one rank over RCCL): a bucket's pending slab reductions are flushed - one launch -
+    right before its all-reduce is enqueued (dp.GradBucketReducer._launch), eagerly and as part of a replayed plan.  Ten
+    steps equal the default's (per-layer reductions) bit for bit."""
+    res = {}
+    old = os.environ.get("WSDL_WGRAD_DEFER")
+    try:
+        for name, env in (("default", "0"), ("deferred", "1")):
+            os.environ["WSDL_WGRAD_DEFER"] = env
+            out = str(tmp_path / f"defer_dp_{name}.pt")
+            mp.spawn(_worker_plan_dp, args=(1, _free_port(), out, "nccl", True), nprocs=1, join=True)
+            res[name] = torch.load(out)
+    finally:
+        if old is None:
+            os.environ.pop("WSDL_WGRAD_DEFER", None)
+        else:
+            os.environ["WSDL_WGRAD_DEFER"] = old
+    a, b = res["default"], res["deferred"]
+    assert b["disabled"] is None and b["replays"] >= 3, (b["disabled"], b["replays"])
+    assert a["losses"] == b["losses"]
+    assert torch.equal(a["params"][0], b["params"][0])

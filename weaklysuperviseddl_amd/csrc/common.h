@@ -277,6 +277,27 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 16 floats 
         for (int i = 0; i < nw; ++i) r += smem[i];
     return r;
 }
+// two block-wide sums behind ONE pair of barriers (the channel-resident BatchNorm kernels reduce two statistics per launch);
+// each sum in block_sum_d's order: same bits
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double* smem /* >= 32 doubles */) {
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        smem[wid] = a;
+        smem[16 + wid] = b;
+    }
+    __syncthreads();
+    double ra = 0.0, rb = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) {
+            ra += smem[i];
+            rb += smem[16 + i];
+        }
+    a = ra;
+    b = rb;
+}
 __device__ __forceinline__ double block_sum_d(double v, double* smem /* >= 16 doubles */) {
     v = wave_sum_d(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

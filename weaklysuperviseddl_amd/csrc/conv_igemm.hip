@@ -1041,6 +1041,50 @@ __global__ void wgrad_reduce_many_kernel(const float* __restrict__ slab, float* 
     wgrad_reduce_many_body(slab, dw, S, Cout, Cin, T, accumulate, live, blockIdx.x, part);
 }
 
+// MANY slabs of a SMALL matrix (round 6: the stem's 64 x 147 values in 768 slabs; 64 outputs per block would be 147 blocks whose
+// waves each walk 192 slabs one dependent-looking load after the other - that reduction, not the matrix kernel, was most of the
+// stem weight gradient's 155 us).  16 outputs per block and 16 slab lanes: thread (o, zl) adds slabs zl, zl + 16, ... in four
+// independent chains, the 16 lane sums are combined in lane order - a fixed order again.
+__device__ __forceinline__ void wgrad_reduce_many16_body(const float* __restrict__ slab, float* __restrict__ dw, int S, int Cout, int Cin,
+                                                         int T, int accumulate, unsigned long long live, long long lb, float* sm /* [16 * 17] */) {
+    const long long total = (long long)Cout * Cin * T;
+    const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const long long idx = lb * 16 + o;
+    const int N = Cin * T;
+    int co = 0, tap = 0, ci = 0;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < total) {
+        co = (int)(idx / N);
+        const int n = (int)(idx - (long long)co * N);
+        tap = n / Cin;
+        ci = n - tap * Cin;
+        if (tap >= 64 || ((live >> tap) & 1ull)) {
+            int z = zl;
+            for (; z + 48 < S; z += 64) {
+                s0 += slab[(long long)z * total + idx];
+                s1 += slab[(long long)(z + 16) * total + idx];
+                s2 += slab[(long long)(z + 32) * total + idx];
+                s3 += slab[(long long)(z + 48) * total + idx];
+            }
+            for (; z < S; z += 16) s0 += slab[(long long)z * total + idx];
+        }
+    }
+    sm[zl * 17 + o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zl == 0 && idx < total) {
+        float r = sm[o];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) r += sm[j * 17 + o];
+        const long long out = ((long long)co * Cin + ci) * T + tap;
+        dw[out] = accumulate ? dw[out] + r : r;
+    }
+}
+__global__ void wgrad_reduce_many16_kernel(const float* __restrict__ slab, float* __restrict__ dw, int S,
+                                           int Cout, int Cin, int T, int accumulate, unsigned long long live) {
+    __shared__ float sm[16 * 17];
+    wgrad_reduce_many16_body(slab, dw, S, Cout, Cin, T, accumulate, live, blockIdx.x, sm);
+}
+
 // T == 1 (1x1 kernels: slab layout == dw layout): 16 bytes per thread, four slabs in flight per step.  The sum
 // order is fixed (pairs of pairs), so the result stays bitwise reproducible.
 __device__ __forceinline__ float4 wgrad_sum_slabs4(const float4* __restrict__ slab, int S, long long total4, long long idx) {
@@ -1168,6 +1212,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const wsdl_wgra
             break;
         case WSDL_WGRAD_REDUCE_TRANSPOSED:
             wgrad_reduce_transposed_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.accumulate, lb % q.grid_x, lb / q.grid_x, sm);
+            break;
+        case WSDL_WGRAD_REDUCE_MANY16:
+            wgrad_reduce_many16_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.T, q.accumulate, q.live, lb, sm);
             break;
         default:
             wgrad_reduce_plain_body(q.slab, q.dw, q.S, q.Cout, q.Cin, q.T, q.accumulate, q.live, lb, q.nblocks);
@@ -1333,8 +1380,10 @@ wsdl::Opt g_tile_threshold{400};   // blocks below which the half-size pixel til
 wsdl::Opt g_xcd_rowfast{0};               // experiment: row-tile-fastest XCD order for every XCD-mapped launch of the split kernels
 wsdl::Opt g_ms_rowfast{1}, g_ms_py{0};   // multi-source launches: row-tile-fastest XCD order; forced number of row groups (0 = auto)
 wsdl::Opt g_group_interleave{1};          // grouped forward: stream-interleaved workgroup order when the streams fill the XCDs evenly
-wsdl::Opt g_group_tps10{20};       // "group_tps10": taps per K slice of a grouped forward launch, in tenths (20: d12 in 4 slices, d24 in 2 = eight
-                              // streams, one per XCD.  648 / 623 / 636 us at 20 / 30 / 45 on one box, 662 / 713 at 20 / 30 on another)
+wsdl::Opt g_group_tps10{45};       // "group_tps10": taps per K slice of a grouped forward launch, in tenths.  20 (round 5's default): d12 in 4 slices,
+                              // d24 in 2 = eight streams, one per XCD; 45 (round 6): d12 in 2 slices, the others whole - 67 MB of slabs less, problem-major
+                              // order.  Round 5: 648 / 623 / 636 us at 20 / 30 / 45 on one box, 662 / 713 at 20 / 30 on another; round 6 (image-major
+                              // tile order on / off): 638.6 / 634.2 at 20, 575.7 / 601.0 at 45, 1058 at 60 (d12 whole: workgroups of 9 taps)
 constexpr int kNumCU = 256, kLdsPerCU = 160 * 1024;
 
 wsdl::Opt g_wgrad_bk{16};   // pixel chunk of the fast weight-gradient kernel: 16 or 32
@@ -1365,7 +1414,10 @@ bool split_eligible(int rows, int kc, int T) {
     return g_conv_split && kc % 16 == 0 && T <= 9 && split_layout_bytes(g_conv_arith, (long long)T * kc, rows) < (1ll << 31);
 }
 
-wsdl::Opt g_tile_img_major{1};   // pixel tiles image-fastest inside a column band for convolutions with taps (conv_split.h, "image-major tile order")
+wsdl::Opt g_tile_img_major{1};   // pixel tiles image-fastest inside a column band (conv_split.h, "image-major tile order"): 0 off, 1 = in the grouped
+                                 // forward launch (ASPP) only - the default, 2 = in every split launch with taps.  Measured (profiles/r06_notes.md):
+                                 // grouped forward 575.7 us with / 601.0 without at group_tps10 = 45; multi-source input gradient 709 with / 693
+                                 // without (and 2.15 / 1.85 GB past L2): there it stays off; plain dilated launches: no difference
 wsdl::Opt g_xcd_map{1};        // XCD-aware tile order of the split kernels: 0 off, 1 auto (by operand bytes), 10 + py forced
 // row groups of the XCD-aware tile order: minimise (weight bytes x pixel groups + activation bytes x row groups); only
 // worth a re-labelling when that beats the launch order (every XCD streams all weights, 1/8 of the pixels) by > 10 %
@@ -1392,7 +1444,7 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
     ConvP p = p_in;
     grid.z = p.ksplit > 1 ? p.ksplit : 1;
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
-    p.tile_img_major = g_tile_img_major && p.KH * p.KW > 1;
+    p.tile_img_major = g_tile_img_major == 2 && p.KH * p.KW > 1;
     constexpr bool MF = BK == 32;
     WSDL_TRACE("split<%d,%d,%d> ar=%d %s ks=%d xcd_py=%d nb=%d grid=%ux%ux%u", BM, BN, BK, (int)g_conv_arith,
                (MF && g_conv_arith) ? "mfma16x16x32" : "mfma32x32x16", p.ksplit, p.xcd_py, p.nb, grid.x, grid.y, grid.z);
@@ -1420,7 +1472,7 @@ int launch_split_256x128(const ConvP& p_in, hipStream_t s) {
     dim3 grid(p.grid_x > 0 ? p.grid_x : wsdl::cdiv(p.P, 128), wsdl::cdiv(p.Cout, 256), p.ksplit > 1 ? p.ksplit : 1);
     p.xcd_py = choose_xcd_py(p, grid.x, grid.y);
     p.xcd_rowfast = g_xcd_rowfast;
-    p.tile_img_major = g_tile_img_major && (p.KH * p.KW > 1 || p.nsrc > 0);
+    p.tile_img_major = g_tile_img_major == 2 && (p.KH * p.KW > 1 || p.nsrc > 0);
     if (p.nsrc > 0 && g_ms_rowfast && grid.y % 2 == 0 && ((long long)grid.x * grid.y) % 8 == 0) {
         // the sources' weights together are the larger operand and every workgroup streams all of them: let the workgroups
         // an XCD runs at once span row tiles as well as pixel tiles
@@ -1775,7 +1827,10 @@ wsdl::Opt g_wgrad_xcd{1};         // XCD-aware tile order of the split weight-gr
 // (that was the bf16x3 kernel; the fp16x2 kernel on 16x16x32 MFMAs wins from ONE N tile on: 1x1 convs of layer2 / layer3.0
 // 76 -> 61, 41 -> 31, 63 -> 43 us.  64-row / 64-column tiles for the 64-channel layers of layer1 lost to the fp32 kernels there -
 // 87 -> 121 us on the 64 -> 64 3x3: few tiles, hundreds of slabs - and were removed in round 3.)
-wsdl::Opt g_wgrad_min_tiles{6};     // (1 is faster per kernel and slower per step: dY pre-split, slab reduce and amax passes join the chain)
+wsdl::Opt g_wgrad_min_tiles{1};     // (rounds 2-5: 6 - from one tile on was faster per kernel and 1 % slower per step, the dY pre-split, slab reduce and
+                                    // amax passes joining the chain.  Round 6: the pre-split comes from the BatchNorm backward or is not needed (dY read
+                                    // as fp32), the maxima are published by the producers: same box 882.5 / 890.0 / 886.8 img/s with 1 against 882.5 /
+                                    // 882.8 / 878.7 with 6, and 857.9 / 857.2 against 847.9 / 851.5 on another box)
 bool wgrad_chunk32(int Cout, int Cin, int N) {
     if (!g_wgrad_split || Cout % 128 != 0 || Cin % 128 != 0) return false;
     return N / 128 >= (g_conv_arith ? g_wgrad_min_tiles : std::max((int)g_wgrad_min_tiles, 6));
@@ -1896,6 +1951,10 @@ int wgrad_reduce_one(const wsdl_wgrad_reduce_desc& d, hipStream_t s) {
             hipLaunchKernelGGL(wgrad_reduce_many_kernel, dim3(d.nblocks), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T,
                                d.accumulate, d.live);
             break;
+        case WSDL_WGRAD_REDUCE_MANY16:
+            hipLaunchKernelGGL(wgrad_reduce_many16_kernel, dim3(d.nblocks), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T,
+                               d.accumulate, d.live);
+            break;
         default:
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d.nblocks), dim3(256), 0, s, d.slab, d.dw, d.S, d.Cout, d.Cin, d.T, d.accumulate,
                                d.live);
@@ -1937,7 +1996,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
     if (!strcmp(name, "conv_il")) { g_conv_il = value != 0; return WSDL_OK; }
-    if (!strcmp(name, "tile_img_major")) { g_tile_img_major = value != 0; return WSDL_OK; }
+    if (!strcmp(name, "tile_img_major")) { g_tile_img_major = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_target")) { g_ksplit_target = value; return WSDL_OK; }
     if (!strcmp(name, "ksplit_max")) { g_ksplit_max = value; return WSDL_OK; }
@@ -1948,7 +2007,7 @@ int wsdl_set_option(const char* name, int value) {
         return WSDL_OK;
     }
     if (!strcmp(name, "range_sentinel")) { wsdl::g_range_sentinel = value != 0; return WSDL_OK; }
-    if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 20; return WSDL_OK; }
+    if (!strcmp(name, "group_tps10")) { g_group_tps10 = value > 0 ? value : 45; return WSDL_OK; }
     if (!strcmp(name, "group_interleave")) { g_group_interleave = value; return WSDL_OK; }
     if (!strcmp(name, "ms_rowfast")) { g_ms_rowfast = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_rowfast")) { g_xcd_rowfast = value; return WSDL_OK; }
@@ -2176,7 +2235,7 @@ int wsdl_conv2d_fwd_group(int n, const float* x, const void* const* wt_fwd, floa
             wsp += wsdl::align_up((size_t)ks * Cout * p.P * sizeof(float), 256);
         }
         p.xcd_py = (start % 8 == 0) ? choose_xcd_py(p, gx, gy) : 0;
-        p.tile_img_major = g_tile_img_major && k[i] > 1;
+        p.tile_img_major = g_tile_img_major >= 1 && k[i] > 1;
         grp.start[j] = start;
         grp.gx[j] = gx;
         grp.gy[j] = gy;
@@ -2338,14 +2397,14 @@ __global__ void channel_amax_kernel(const float* __restrict__ t, int B, int C, i
 // 13 x 69 x 3 input patch (de-interleaved by column parity) and the 64 x 128 tile of dY in LDS once, and runs the GEMM
 // D[co][k] over the tile's 128 pixels on v_mfma_f32_32x32x2_f32 - exact fp32 products as before.  The 2 x 5 output tiles
 // (64 channels x 147 -> 160 k) are dealt to the four waves 3 / 3 / 2 / 2; a workgroup walks several pixel tiles with its
-// accumulators in registers (grid = at most 768 workgroups = 768 slabs of 37 KB, summed in fixed order by the slab reduction).
+// accumulators in registers (grid = at most 512 workgroups = 512 slabs of 37 KB, summed in fixed order by the slab reduction).
 constexpr int kSwTH = 4;                              // output rows of a tile
 constexpr int kSwIH = 2 * kSwTH + 5;                  // 13 input rows
 constexpr int kSwPlane = kSwIH * kStemIW;
 constexpr int kSwLD = kSwTH * kStemTW + 1;            // dY rows of 128 pixels + 1: lanes of different channels on different banks
-constexpr int kSwMaxGrid = 768;
+constexpr int kSwMaxGrid = 512;                     // two workgroups per CU (178 registers): one round, four tiles each at B = 16, 256 x 256
 
-__global__ __launch_bounds__(256, 3) void stem_wgrad7x7s2_kernel(WgradP p, int tiles_w, int tiles_h, int total_tiles) {
+__global__ __launch_bounds__(256, 2) void stem_wgrad7x7s2_kernel(WgradP p, int tiles_w, int tiles_h, int total_tiles) {
     __shared__ float dy_s[64 * kSwLD];
     __shared__ float x_s[3 * kSwPlane + 1];           // + one zero word: what the 13 padding columns of the k dimension read
     __shared__ int koff[160];
@@ -2377,20 +2436,56 @@ __global__ __launch_bounds__(256, 3) void stem_wgrad7x7s2_kernel(WgradP p, int t
         // the input patch
         const float* xb = p.x + (long long)b * p.x_bs;
         const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
-        for (int i = tid; i < 3 * kSwIH * 69; i += 256) {
+        // (all of a thread's loads are issued before its first LDS store: a load-store-load-store loop waits out the memory
+        // latency once per element - 43 times per tile)
+        constexpr int kXN = (3 * kSwIH * 69 + 255) / 256;          // 11 patch elements per thread
+        float xv[kXN];
+#pragma unroll
+        for (int e = 0; e < kXN; ++e) {
+            const int i = tid + e * 256;
             const int ci = i / (kSwIH * 69), r = i - ci * (kSwIH * 69);
             const int row = r / 69, col = r - row * 69;
             const int iy = iy0 + row, ix = ix0 + col;
-            float v = 0.f;
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = xb[(long long)ci * HW + iy * p.W + ix];
-            x_s[ci * kSwPlane + row * kStemIW + (col & 1) * kStemHalf + (col >> 1)] = v;
+            xv[e] = (i < 3 * kSwIH * 69 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? xb[(long long)ci * HW + iy * p.W + ix] : 0.f;
         }
-        // the tile of dY: 64 channels x 4 rows x 32 columns (zeros beyond the map)
+        // the tile of dY: 64 channels x 4 rows x 32 columns (zeros beyond the map): eight 16-byte loads per thread where the rows
+        // allow them (OW a multiple of 4: whole 4-column groups are inside or outside the map)
         const float* dyb = p.dy + (long long)b * p.dy_bs;
-        for (int i = tid; i < 64 * kSwTH * 32; i += 256) {
-            const int co = i >> 7, r = i & 127, row = r >> 5, col = r & 31;
+        float4 dv[8];
+        const bool vec = (p.OW & 3) == 0 && (p.dy_bs & 3) == 0 && (OHOW & 3) == 0 && (reinterpret_cast<unsigned long long>(p.dy) & 15) == 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = tid + e * 256;                       // (channel, row, 4-column group): 64 x 4 x 8
+            const int co = i >> 5, row = (i >> 3) & 3, col = (i & 7) * 4;
             const int oy = oy0 + row, ox = ox0 + col;
-            dy_s[co * kSwLD + r] = (oy < p.OH && ox < p.OW) ? dyb[(long long)co * OHOW + oy * p.OW + ox] : 0.f;
+            dv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.OH) {
+                const float* src = dyb + (long long)co * OHOW + oy * p.OW + ox;
+                if (vec) {
+                    if (ox < p.OW) dv[e] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (ox < p.OW) dv[e].x = src[0];
+                    if (ox + 1 < p.OW) dv[e].y = src[1];
+                    if (ox + 2 < p.OW) dv[e].z = src[2];
+                    if (ox + 3 < p.OW) dv[e].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < kXN; ++e) {
+            const int i = tid + e * 256;
+            if (i < 3 * kSwIH * 69) {
+                const int ci = i / (kSwIH * 69), r = i - ci * (kSwIH * 69);
+                const int row = r / 69, col = r - row * 69;
+                x_s[ci * kSwPlane + row * kStemIW + (col & 1) * kStemHalf + (col >> 1)] = xv[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = tid + e * 256;
+            const int co = i >> 5, r = ((i >> 3) & 3) * 32 + (i & 7) * 4;
+            float* d = dy_s + co * kSwLD + r;
+            d[0] = dv[e].x; d[1] = dv[e].y; d[2] = dv[e].z; d[3] = dv[e].w;
         }
         __syncthreads();
 #pragma unroll 4
@@ -2572,7 +2667,10 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
         rd.slab = p.slab; rd.dw = dw; rd.S = G; rd.Cout = Cout; rd.Cin = Cin; rd.T = kh * kw; rd.accumulate = accumulate;
         rd.live = ~0ull;
         const long long total = (long long)Cout * p.N;
-        if (G >= 16) {
+        if (G >= 64) {
+            rd.kind = WSDL_WGRAD_REDUCE_MANY16;
+            rd.nblocks = (int)((total + 15) / 16);
+        } else if (G >= 16) {
             rd.kind = WSDL_WGRAD_REDUCE_MANY;
             rd.nblocks = (int)((total + 63) / 64);
         } else {
@@ -2814,6 +2912,9 @@ static int wgrad_impl(const float* x, const float* dy, float* dw, int B, int Cin
     } else if (T == 1 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0) {
         rd.kind = WSDL_WGRAD_REDUCE_VEC4;
         rd.nblocks = (int)std::min<long long>((total / 4 + 255) / 256, 8192);
+    } else if (S_total >= 64 && total < 64 * 512) {
+        rd.kind = WSDL_WGRAD_REDUCE_MANY16;        // few outputs, very many slabs: more blocks, 16 slab lanes each
+        rd.nblocks = (int)((total + 15) / 16);
     } else if (S_total >= 16 && total <= (1ll << 24)) {
         rd.kind = WSDL_WGRAD_REDUCE_MANY;
         rd.nblocks = (int)((total + 63) / 64);

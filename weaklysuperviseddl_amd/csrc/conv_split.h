@@ -39,10 +39,10 @@
 // between the global load and the LDS store.  LDS rows are (BK/16) x NP x 32 bytes + 16 bytes of padding: a row stride
 // that is an odd multiple of 16 bytes makes every ds_read_b128 lane group (16 lanes: 16 different rows) hit 16 distinct
 // 16-byte slots of the 256-byte read bank row.  The STORES bank over 128 bytes and go by groups of 8 (b128) / 16 (b64)
-// consecutive lanes: they are conflict-free only because of which unit each lane carries - 8 consecutive rows per b128
-// group (weights), 8 pixels x one whole slot per b64 group (activations of the 256 x 128 form); see the two mappings in
-// conv_igemm_split_body (round 6; rounds 1-5 stored in unit order and paid a 2-way conflict per store: 30 % of the LDS-active
-// cycles of the dominant kernel).
+// consecutive lanes: the weight stores are conflict-free because of which unit each lane carries - 8 consecutive rows per
+// b128 group (round 6; rounds 1-5 stored in unit order: a 2-way conflict per store).  The 8-byte activation stores of the
+// 256 x 128 form keep their 2-way conflict (lanes i and i + 8 of a group): the mapping that removes it was built and measured
+// slower - see kPairB in conv_igemm_split_body.
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -235,7 +235,11 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     // 16-byte slot each - 8 distinct slots of the 128-byte store bank row.  With one k run per wave (64 consecutive pixels, the
     // round 1-5 mapping) lanes i and i + 8 hit the same 8 bytes (8 rows of 80 bytes = 5 bank rows): a 2-way conflict on every
     // store, part of the 30 % of LDS-active cycles the counters showed (profiles/r05_pmc_dominant_kernels.txt).
-#if !defined(WSDL_EXP_OLD_LDS_MAP) && !defined(WSDL_EXP_NO_PAIRB)
+    // MEASURED, NOT ADOPTED (round 6, same box, three builds): the pairing removes the store conflict and costs the global side
+    // more than that - a lane quad then reads 2 pixels x 2 channels instead of 16 contiguous bytes.  Training step 847.8 / 852.1
+    // img/s with it alone against 853.1 / 853.4 without; the 256 x 128 launches 1.5-2.5 % slower with both mappings
+    // (l4.conv2 d4 221.5 against 217.8 us).  Kept as a build option (-DWSDL_EXP_PAIRB, tools/build_variant.sh).
+#if defined(WSDL_EXP_PAIRB) && !defined(WSDL_EXP_OLD_LDS_MAP)
     constexpr bool kPairB = !MF && B_PER == 4 && B_STEP == 4;
 #else
     constexpr bool kPairB = false;
@@ -355,7 +359,9 @@ __device__ __forceinline__ void conv_igemm_split_body(const ConvP& p, const int 
     // for the padded rows (80 bytes: slot 5 row + part) and for the swizzled 128-byte rows of the MF form (unit ^ (row & 7)) alike.
     // In unit order (a lane group = two rows x four parts) the group's first and last lane are 128 bytes apart: a 2-way
     // conflict on every weight store (conv_split.h said "conflict-free" until round 6; the counters did not).  The global side
-    // is unchanged: a wave still loads one contiguous 1 KB run, its lanes permuted inside it.
+    // is unchanged: a wave still loads one contiguous 1 KB run, its lanes permuted inside it.  Same box, three builds: the
+    // 16 x 16 x 32 forms 2-3 % faster per launch (l2.conv2 41.3 -> 40.1 us), the training step 853.5 / 855.1 img/s against
+    // 853.1 / 853.4 in unit order: kept.
 #if !defined(WSDL_EXP_OLD_LDS_MAP) && !defined(WSDL_EXP_NO_ROWA)
     constexpr bool kRowMajorA = UPR == 4 && (A_UPS % 64) == 0;
 #else
@@ -1242,10 +1248,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
     const unsigned b_row = (unsigned)((ci0 + 2 * hw) * HW);
     // CS: the scales of the tile's 128 rows of x in LDS (eight registers per thread for them spilled)
     __shared__ float xst[CS ? BN : 1];
+    __shared__ int edy_s[CS ? BM : 1];                 // CS: exponent of the scale of each of the tile's rows of dY (the epilogue's)
     if constexpr (CS) {
         if (tid < BN) {
             int e_;
             xst[tid] = pow2_scale(p.x_amax[(ci0 + tid) * p.xa_stride], e_);
+            (void)pow2_scale(dy_amax[(m0 + tid) * p.da_stride], e_);        // (BM == BN)
+            edy_s[tid] = e_;
         }
         __syncthreads();
     }
@@ -1410,12 +1419,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16_kernel(WgradP 
         for (int i = 0; i < TMI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m0 + wm * (BM / 2) + i * 16 + lg * 4 + r;
-                int edr;
-                (void)pow2_scale(dy_amax[co * p.da_stride], edr);
+                const int row = wm * (BM / 2) + i * 16 + lg * 4 + r, co = m0 + row;
+                const int edr = edy_s[row];
+                // (one add and one v_ldexp_f32 per element: exact, and in range whatever the two exponents are; the per-element
+                // pow2() products of round 5 were ~1000 instructions of this epilogue - 2-6 % of the kernel)
 #pragma unroll
                 for (int j = 0; j < TNI; ++j)
-                    slab[(long long)co * p.N + n0 + wn * (BN / 2) + j * 16 + l15] = acc[i][j][r] * pow2(-(en[j] + edr));
+                    slab[(long long)co * p.N + n0 + wn * (BN / 2) + j * 16 + l15] = ldexpf(acc[i][j][r], -(en[j] + edr));
             }
         return;
     }
@@ -1499,7 +1509,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
     for (int j = 0; j < TNI; ++j) vrow[j] = (unsigned)((ci0 + wid * 32 + j * 16 + l15) * HW + lg * 8);
     float xsr[CS ? TNI : 1], dsr[CS && DYRAW ? A_U : 1];       // CS: the scales of this lane's rows of x / of the rows of dY it stages
     int exr[CS ? TNI : 1];
+    __shared__ int edy_s[CS ? BM : 1];                          // CS: exponent of the scale of each of the tile's rows of dY (the epilogue's)
     if constexpr (CS) {
+        if (tid < BM) {
+            int e_;
+            (void)pow2_scale(dy_amax[(m0 + tid) * p.da_stride], e_);
+            edy_s[tid] = e_;
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < TNI; ++j) xsr[j] = pow2_scale(p.x_amax[(ci0 + wid * 32 + j * 16 + l15) * p.xa_stride], exr[j]);
         if constexpr (DYRAW) {
@@ -1698,12 +1715,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_split16d_kernel(WgradP
         for (int i = 0; i < TMI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = m0 + i * 16 + lg * 4 + r;
-                int edr;
-                (void)pow2_scale(dy_amax[co * p.da_stride], edr);
+                const int row = i * 16 + lg * 4 + r, co = m0 + row;
+                const int edr = edy_s[row];
 #pragma unroll
                 for (int j = 0; j < TNI; ++j)
-                    slab[(long long)co * p.N + n0 + wid * 32 + j * 16 + l15] = acc[i][j][r] * pow2(-(exr[j] + edr));
+                    slab[(long long)co * p.N + n0 + wid * 32 + j * 16 + l15] = ldexpf(acc[i][j][r], -(exr[j] + edr));
             }
         return;
     }

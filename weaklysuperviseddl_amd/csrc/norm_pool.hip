@@ -61,7 +61,7 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
     // forward : part = (sum x, sum x^2) ; backward: part = (sum dy', sum dy'*xhat), dy' = dy*[y>0]
     // relu == 2: the mask [y > 0] is recomputed from x (y = fma(x - mean, invstd*gamma, beta), the forward's own pinned
     // expression - no residual was added): y is not read
-    __shared__ double sm[16];
+    __shared__ double sm[32];
     const int c = blockIdx.x, s = blockIdx.y;
     const int slice = (HW + nsplit - 1) / nsplit;
     const int r0 = s * slice;
@@ -127,8 +127,7 @@ __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __rest
             a1 += (double)g * ((xv - mu) * is);
         }
     }
-    a0 = block_sum_d(a0, sm);
-    a1 = block_sum_d(a1, sm);
+    block_sum2_d(a0, a1, sm);
     if (threadIdx.x == 0) {
         part[((long long)c * kStatSplit + s) * 2 + 0] = a0;
         part[((long long)c * kStatSplit + s) * 2 + 1] = a1;
@@ -342,7 +341,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
     // V float4 per thread: 16 with 256 / 512 threads; 4 with 1024 threads for the 256- and 512-channel layers (one
     // workgroup per CU at most: sixteen waves keep four times the requests of four waves moving - see resident_threads)
     // S > 1: workgroup blockIdx.x = c * S + s holds slice s of channel c (coop_exchange above); S = 1: the whole channel
-    __shared__ double sm[16];
+    __shared__ double sm[32];
     __shared__ float bc[2];
     const int c = S > 1 ? blockIdx.x / S : blockIdx.x, sl = S > 1 ? blockIdx.x - c * S : 0, tid = threadIdx.x;
     const int HW4 = HW >> 2, hw_sh = pow2_shift(HW4);
@@ -360,8 +359,7 @@ __global__ __launch_bounds__(NT) void bn_fwd_resident_kernel(
             a1 += (double)v[k].x * v[k].x + (double)v[k].y * v[k].y + (double)v[k].z * v[k].z + (double)v[k].w * v[k].w;
         }
     }
-    a0 = block_sum_d(a0, sm);
-    a1 = block_sum_d(a1, sm);
+    block_sum2_d(a0, a1, sm);
     if (tid == 0) {
         if (S > 1) coop_exchange(a0, a1, part, cnt, c, sl, S);
         const long long n = (long long)B * HW;
@@ -415,7 +413,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
     float* __restrict__ amax, const float* __restrict__ beta, const uint8_t* __restrict__ rmask, float* __restrict__ cmin,
     int S, unsigned long long* __restrict__ part, int* __restrict__ cnt, float* __restrict__ chan_amax,
     unsigned char* __restrict__ presplit) {
-    __shared__ double sm[16];
+    __shared__ double sm[32];
     __shared__ float bc[2];
     const int c = S > 1 ? blockIdx.x / S : blockIdx.x, sl = S > 1 ? blockIdx.x - c * S : 0, tid = threadIdx.x;
     const int HW4 = HW >> 2, hw_sh = pow2_shift(HW4);
@@ -453,8 +451,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_resident_kernel(
             a1 += (double)gv.x * xh[k].x + (double)gv.y * xh[k].y + (double)gv.z * xh[k].z + (double)gv.w * xh[k].w;
         }
     }
-    a0 = block_sum_d(a0, sm);
-    a1 = block_sum_d(a1, sm);
+    block_sum2_d(a0, a1, sm);
     if (tid == 0) {
         if (S > 1) coop_exchange(a0, a1, part, cnt, c, sl, S);
         const long long n = (long long)B * HW;

@@ -846,16 +846,18 @@ class _ReduceDesc(C.Structure):       # wsdl_wgrad_reduce_desc (include/wsdl_hip
 
 
 # Deferred slab reductions of the weight gradients (wsdl_conv2d_wgrad_deferred / wsdl_wgrad_reduce_multi): a weight gradient
-# written into a parameter's slice of the flat gradient buffer leaves its pixel slabs un-reduced; ALL pending reductions run
+# written into a parameter's slice of the flat gradient buffer leaves its pixel slabs un-reduced; the pending reductions run
 # as one launch when the gradients are needed - at the end of the backward pass (an autograd engine callback), before a
-# gradient bucket's all-reduce, before the optimiser step.  ~60 launches of 9-10 us per training step become one (or one per
-# bucket).  Bit-identical to the per-layer reductions.  WSDL_WGRAD_DEFER=0: the per-layer form (A/B).
-WGRAD_DEFER = [os.environ.get("WSDL_WGRAD_DEFER", "1") != "0"]
-# ... in groups: pending reductions are flushed once their slabs exceed this many bytes, so that most of the summing happens
-# DURING the backward pass (on the side stream, between weight-gradient kernels) and only the last group's behind it.
-# Everything in ONE launch at the end of backward measured 1 % SLOWER than the per-layer launches (844-847 against 851-856
-# img/s, same box): ~0.5 GB of slabs read in the one place of the step where nothing overlaps them.
-WGRAD_DEFER_BYTES = [int(float(os.environ.get("WSDL_WGRAD_DEFER_MB", "48")) * (1 << 20))]
+# gradient bucket's all-reduce, before the optimiser step - or in groups (WSDL_WGRAD_DEFER_MB: flushed once the pending slabs
+# exceed that many MB).  Bit-identical to the per-layer reductions.
+# BUILT, MEASURED, OFF BY DEFAULT (round 6; WSDL_WGRAD_DEFER=1 switches it on).  ~60 launches of 9-10 us per training step do
+# become 1-10, but the step is SLOWER: 853.8 / 852.5 img/s in 48 MB groups, 846 in 16 MB groups, 854.6 / 856.4 all at the end,
+# against 864.0 / 864.7 with the per-layer launches (same box, profiles/r06_notes.md).  A layer's slabs are reduced by the
+# launch right behind the kernel that wrote them - out of the L2s and the Infinity Cache, from ONE workspace the next layer
+# reuses; deferred, every layer needs slabs of its own (0.5 GB per step) that go out to HBM and come back.  The launches
+# saved were latency on the side stream, which is not what bounds the step.
+WGRAD_DEFER = [os.environ.get("WSDL_WGRAD_DEFER", "0") != "0"]
+WGRAD_DEFER_BYTES = [int(float(os.environ.get("WSDL_WGRAD_DEFER_MB", "100000")) * (1 << 20))]
 _wgrad_pending = {}       # device -> {"descs": [_ReduceDesc], "dws": set of dw pointers, "keep": [tensors], "side": bool, "cb": bool}
 _wgrad_ws = {}            # (device, geometry, dw pointer) -> that layer's own workspace (its slabs outlive the launch)
 _reduce_tables = {}       # descriptor bytes -> (device table, n, total blocks)
