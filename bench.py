@@ -209,10 +209,13 @@ def pmc_traffic(kernel, with_source=False):
 
 
 def mfma_busy_3x3():
-    """Cycle-weighted MFMA-busy fraction of the 3x3 convolutions (north_star: ">= 40 % MFMA util on the 3x3 convs") from
-    the committed per-shape counter runs, profiles/r*_mfma_busy_3x3.txt (tools/mfma_busy_3x3.sh: one rocprofv3 --pmc
-    SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE run per SURVEY 8a shape and pass) - a lookup, like `traffic`."""
+    """MFMA-busy fraction of the 3x3 convolutions (north_star: ">= 40 % MFMA util on the 3x3 convs") from the committed
+    per-shape counter runs, profiles/r*_mfma_busy_3x3.txt (tools/mfma_busy_3x3.sh: one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+    GRBM_GUI_ACTIVE run per SURVEY 8a shape and pass) - a lookup, like `traffic`.  Since round 6 every (shape, pass) is weighted
+    by its LAUNCHES PER STEP and a pass's denominator holds its satellite launches (slab / split-K reduces, dY pre-split): the
+    pass keys are that figure, `<pass>_matrix_kernels_alone` the matrix kernels' own."""
     import glob
+    import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy_3x3.txt")))
     if not files:
         return None
@@ -221,6 +224,10 @@ def mfma_busy_3x3():
         if line.startswith("3x3 convolutions"):
             parts = line.split()
             out[parts[2]] = float(parts[-1])
+            m = re.search(r"matrix kernels alone\s+([0-9.]+)", line)
+            if m:
+                out[parts[2] + "_matrix_kernels_alone"] = float(m.group(1))
+                out["weighting"] = "launches per step; satellite launches in the denominator"
     return out if len(out) > 1 else None
 
 
@@ -1043,7 +1050,7 @@ def main():
                                   "mfma_products_per_fp32_product": (nprod if split else 1),
                                   "traffic": pmc_traffic(traffic_kernel),
                                   "traffic_source": pmc_traffic(traffic_kernel, with_source=True)[1],
-                                  "traffic_is": "HBM bytes per launch of the plain entry point (the other two: profiles/r05_notes.md)" if entries else "HBM bytes per launch",
+                                  "traffic_is": "HBM bytes per launch of the plain entry point (the other two: profiles/r05_notes.md, r06_notes.md)" if entries else "HBM bytes per launch",
                                   "mfma_busy_3x3": mfma_busy_3x3(),
                                   "algorithmic_bytes_per_launch": top["alg_bytes"] / top["launches"],
                                   "launches": top["launches"], "avg_launch_us": top["avg_us"],

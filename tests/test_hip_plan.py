@@ -378,16 +378,14 @@ def test_deferred_slab_reductions_equal_the_per_layer_ones(dev, group_mb):
     m0, o0, l0, _ = _run(dev, False, 4, batches)
     old = ops.WGRAD_DEFER[0], ops.WGRAD_DEFER_BYTES[0]
     ops.WGRAD_DEFER[0], ops.WGRAD_DEFER_BYTES[0] = True, group_mb << 20
+    ops._reduce_tables.clear()
     try:
-        ops.launch_trace(True)
-        ops.last_launches()
         m1, o1, l1, _ = _run(dev, False, 4, batches)
-        trace = ops.last_launches()
+        tables = len(ops._reduce_tables)
         m2, o2, l2, st = _run(dev, True, 6, batches)
     finally:
-        ops.launch_trace(False)
         ops.WGRAD_DEFER[0], ops.WGRAD_DEFER_BYTES[0] = old
-    assert "deferred" in trace, trace[:400]
+    assert tables >= (1 if group_mb > 1000 else 2), tables       # descriptor tables were built: the deferred path really ran
     assert l0 == l1
     for a, b in zip(_state(m0, o0), _state(m1, o1)):
         assert torch.equal(a, b)
