@@ -7,6 +7,7 @@
 #include <cstdint>
 
 wsdl::Opt wsdl::g_bn_resident{1};
+wsdl::Opt wsdl::g_bn_bwd_form{0};     // "bn_bwd_form" (experiment): the channel-resident backward of the > 256-channel layers as 512 x 8 (1) / 1024 x 4 (2) float4 instead of 256 x 16
 wsdl::Opt wsdl::g_bn_wide_c{512};      // channel counts up to which the resident kernels run 1024 threads x 4 float4 ("bn_wide_c" option, 0 = never)
 
 namespace {
@@ -909,6 +910,14 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     }
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW, true) : 0) {
         if (nt == 1024)
+            hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
+        else if (nt == 256 && wsdl::g_bn_bwd_form == 1 && (long long)B * HW <= 512 * 32)
+            hipLaunchKernelGGL((bn_bwd_resident_kernel<512, 8>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
+                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
+                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
+        else if (nt == 256 && wsdl::g_bn_bwd_form == 2 && (long long)B * HW <= 1024 * 16)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
                                dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
