@@ -83,7 +83,6 @@ extern std::atomic<int> g_plans_recording;     // host threads between wsdl_plan
 
 // A/B switch (wsdl_set_option "bn_resident"): channel-resident fused BatchNorm kernels (norm_pool.hip)
 extern Opt g_bn_resident;
-extern Opt g_bn_bwd_form;
 extern Opt g_bn_wide_c;     // "bn_wide_c": resident BatchNorm kernels with 1024 threads up to this channel count
 extern Opt g_layercam_tail_mod;   // "layercam_tail_mod": see layercam_optim.hip
 extern Opt g_bn_coop;             // "bn_coop": several workgroups per channel in the resident BatchNorm kernels up to this channel count (0 off)

@@ -2016,7 +2016,6 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "bn_coop_wide")) { wsdl::g_bn_coop_wide = value; return WSDL_OK; }
     if (!strcmp(name, "bn_resident")) { wsdl::g_bn_resident = value; return WSDL_OK; }
     if (!strcmp(name, "bn_wide_c")) { wsdl::g_bn_wide_c = value; return WSDL_OK; }
-    if (!strcmp(name, "bn_bwd_form")) { wsdl::g_bn_bwd_form = value; return WSDL_OK; }
     if (!strcmp(name, "layercam_tail_mod")) {
         WSDL_REQUIRE(value >= 0 && value <= 32, "layercam_tail_mod: 0..32");
         wsdl::g_layercam_tail_mod = value;

@@ -7,7 +7,6 @@
 #include <cstdint>
 
 wsdl::Opt wsdl::g_bn_resident{1};
-wsdl::Opt wsdl::g_bn_bwd_form{0};     // "bn_bwd_form" (experiment): the channel-resident backward of the > 256-channel layers as 512 x 8 (1) / 1024 x 4 (2) float4 instead of 256 x 16
 wsdl::Opt wsdl::g_bn_wide_c{512};      // channel counts up to which the resident kernels run 1024 threads x 4 float4 ("bn_wide_c" option, 0 = never)
 
 namespace {
@@ -524,7 +523,8 @@ static int resident_threads(int C, long long n, int HW, bool backward = false) {
     // 256 / 512 channels = one or two workgroups per CU.  Sixteen waves of a quarter of the work each instead of four:
     // forward 14.5 -> 11.6 us (256 channels) and 21.5 -> 16.6 us (512) on the 16 x 32 x 32 maps; backward 16.2 -> 15.0 us at 256
     // channels but 22.0 -> 23.3 us at 512 (three tensors in flight per thread already): wide up to 512 / 256 channels
-    // (tools/bn_bench.py, profiles/r03_notes.md)
+    // (tools/bn_bench.py, profiles/r03_notes.md).  Round 6 tried the backward of the > 256-channel layers as 512 x 8 and 1024 x 4
+    // float4 once more: 2048 x 1024 114.6 -> 126.9 / 121.2 us, the step 864.1 / 865.6 -> 856.7 / 856.6 and 861.6 / 860.2 img/s - removed again.
     if (n <= 1024 * 16 && C <= (backward ? wsdl::g_bn_wide_c / 2 : wsdl::g_bn_wide_c)) return 1024;
     if (n <= 256 * 64) return 256;
     if (n <= 512 * 64) return 512;
@@ -910,14 +910,6 @@ int wsdl_bn_train_bwd(const float* x, const float* dy, const float* y, const flo
     }
     if (const int nt = (((dy_bs | y_bs) & 3) == 0) ? resident_threads(C, (long long)B * HW, HW, true) : 0) {
         if (nt == 1024)
-            hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
-                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
-        else if (nt == 256 && wsdl::g_bn_bwd_form == 1 && (long long)B * HW <= 512 * 32)
-            hipLaunchKernelGGL((bn_bwd_resident_kernel<512, 8>), dim3(C), dim3(512), 0, s, x, dy, y, gamma, save_mean,
-                               save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
-                               dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
-        else if (nt == 256 && wsdl::g_bn_bwd_form == 2 && (long long)B * HW <= 1024 * 16)
             hipLaunchKernelGGL((bn_bwd_resident_kernel<1024, 4>), dim3(C), dim3(1024), 0, s, x, dy, y, gamma, save_mean,
                                save_invstd, dgamma, dbeta, accumulate_param_grads, dx, dres, B, C, HW, dy_bs, y_bs, relu,
                                dx_amax, beta, relu_mask, cmin, 1, (unsigned long long*)nullptr, (int*)nullptr, chan_amax, static_cast<unsigned char*>(dy_presplit));
