@@ -866,7 +866,7 @@ def main():
         "config": {"workload": f"{cfg}: DeepLabV3-ResNet50 (SegmentationModel, aux head computed) {CONFIGS[cfg]['what']}, "
                                f"B={B}/GPU {S}x{S}x3, random-init weights, live dropout",
                    "arithmetic": ("fp32 tensors; conv products as 3 fp16 MFMAs on exact 2-way fp16 splits of both operands (22 "
-                                  "significant bits, per-tensor power-of-two scales), fp32 accumulate"
+                                  "significant bits; power-of-two scales per tensor in the forward / input gradient, per CHANNEL in the weight gradients), fp32 accumulate"
                                   if ops.CONV_ARITH[0] == 1 else
                                   "fp32 tensors; conv products as 6 bf16 MFMAs on exact 3-way bf16 splits of both operands, "
                                   "fp32 accumulate") + " - rms error vs fp64 at the level of the exact-fp32 MFMA chain "
@@ -925,7 +925,11 @@ def main():
                            note="range sentinel of the fp16x2 arithmetic (one power-of-two scale per tensor): the BatchNorm kernels publish "
                                 "max|tensor| and the smallest non-zero channel maximum; worst_log2 = the largest log2 of "
                                 "their ratio over the last step's tensors, exceeded = some tensor beyond 2^25 (there conv_arith = 2, the "
-                                "range guard, is the arithmetic to use; FlatAdam.step() warns once)")
+                                "range guard of the forward / input gradient, is the arithmetic to use: WSDL_RANGE_GUARD=auto, the default, "
+                                "switches it on for the steps that follow; the weight gradients scale every channel by its own power of two "
+                                "from step 0 - the maxima come from the BatchNorm kernels)",
+                           guard=__import__("weaklysuperviseddl_amd.optim", fromlist=["x"]).RANGE_GUARD[0],
+                           guard_active=bool(__import__("weaklysuperviseddl_amd.optim", fromlist=["x"]).RANGE_GUARD_ACTIVE[0]))
     result["streams"] = ops.stream_census(device)
     if dp_on and dist.get_backend() != "nccl":
         result["config"]["rehearsal"] = ("ranks share the GPU(s) and the gradients travel over gloo through host memory: a rehearsal "

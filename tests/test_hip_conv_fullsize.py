@@ -14,7 +14,8 @@ weight gradient at
 
 in every arithmetic of the library (fp16x2 with the interleaved loop on and off, fp16x2 with the range guard, bf16x3,
 exact-fp32 MFMA) and is compared with ``F.conv2d`` / ``torch.nn.grad.conv2d_input`` / ``conv2d_weight`` evaluated in FLOAT64 ON THE
-HOST: max-norm error of every output channel relative to that channel's own maximum (rows AND columns of dW for the weight
+HOST (1x1 convolutions as the three float64 matrix products they are - the host BLAS is several times faster than ATen's float64
+convolution paths): max-norm error of every output channel relative to that channel's own maximum (rows AND columns of dW for the weight
 gradient) - an error confined to one tile cannot hide in a tensor norm.  Bar: north_star's 1e-3; asserted 1e-4; measured ~1e-6.
 Which configuration each comparison went through comes from the library itself (``wsdl_launch_trace``) and is printed with the
 worst error per (configuration, pass, arithmetic) in the test summary ("parity counts").
@@ -153,13 +154,30 @@ def _run_shape(ops, dev, table, B, scale, shape, g, timing):
     _VERIFIED.update(keys)
     t_ref = time.time()
     x64, w64 = x.double(), w.double()
-    y64 = F.conv2d(x64, w64, None, s, pad, d)
-    dy = torch.randn(y64.shape, generator=g)
-    dy64 = dy.double()
-    ref = {"f": y64.to(dev)}
-    if "d" in passes:
-        ref["d"] = torch.nn.grad.conv2d_input(x.shape, w64, dy64, s, pad, d).to(dev)
-    ref["w"] = torch.nn.grad.conv2d_weight(x64, w.shape, dy64, s, pad, d).to(dev)
+    if k == 1:
+        # a 1x1 convolution is three matrix products (the float64 GEMM of the host's BLAS is several times faster than ATen's
+        # float64 convolution paths, which this test's time goes into): y[b] = W x[b], dx[b] = W^T dy[b], dW = sum_b dy[b] x[b]^T
+        xs_ = x64[:, :, ::s, ::s].contiguous()
+        OH, OW = xs_.shape[2], xs_.shape[3]
+        w2 = w64.view(Cout, Cin)
+        y64 = torch.matmul(w2, xs_.view(B, Cin, OH * OW)).view(B, Cout, OH, OW)
+        dy = torch.randn(y64.shape, generator=g)
+        dy64 = dy.double()
+        ref = {"f": y64.to(dev)}
+        if "d" in passes:
+            dxs = torch.matmul(w2.t(), dy64.view(B, Cout, OH * OW)).view(B, Cin, OH, OW)
+            dx64 = torch.zeros(x.shape, dtype=torch.float64)
+            dx64[:, :, ::s, ::s] = dxs
+            ref["d"] = dx64.to(dev)
+        ref["w"] = torch.einsum("bop,bip->oi", dy64.view(B, Cout, OH * OW), xs_.view(B, Cin, OH * OW)).view(Cout, Cin, 1, 1).to(dev)
+    else:
+        y64 = F.conv2d(x64, w64, None, s, pad, d)
+        dy = torch.randn(y64.shape, generator=g)
+        dy64 = dy.double()
+        ref = {"f": y64.to(dev)}
+        if "d" in passes:
+            ref["d"] = torch.nn.grad.conv2d_input(x.shape, w64, dy64, s, pad, d).to(dev)
+        ref["w"] = torch.nn.grad.conv2d_weight(x64, w.shape, dy64, s, pad, d).to(dev)
     del x64, w64, y64, dy64
     timing["host_oracle_s"] += time.time() - t_ref
     xd, wd_, dyd = x.to(dev), w.to(dev), dy.to(dev)
@@ -236,9 +254,18 @@ def test_aspp_grouped_forward_and_multi_source_dgrad_vs_float64_at_full_size(dev
     dys = [torch.randn(B, Co, H, H, generator=g) * sc for sc in (1.0, 0.25, 4.0, 0.5)]
     x64 = x.double()
     t0 = time.time()
-    y64 = [F.conv2d(x64, w.double(), None, 1, d * (k - 1) // 2, d).to(dev) for w, k, d in zip(ws, ks, dils)]
-    dx64 = sum(torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d * (k - 1) // 2, d)
-               for w, dy, k, d in zip(ws, dys, ks, dils)).to(dev)
+    def fwd64(w, k, d):
+        if k == 1:
+            return torch.matmul(w.double().view(Co, C), x64.view(B, C, H * H)).view(B, Co, H, H)
+        return F.conv2d(x64, w.double(), None, 1, d * (k - 1) // 2, d)
+
+    def dgrad64(w, dy, k, d):
+        if k == 1:
+            return torch.matmul(w.double().view(Co, C).t(), dy.double().view(B, Co, H * H)).view(B, C, H, H)
+        return torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, d * (k - 1) // 2, d)
+
+    y64 = [fwd64(w, k, d).to(dev) for w, k, d in zip(ws, ks, dils)]
+    dx64 = sum(dgrad64(w, dy, k, d) for w, dy, k, d in zip(ws, dys, ks, dils)).to(dev)
     del x64
     xd, wsd, dysd = x.to(dev), [w.to(dev) for w in ws], [dy.to(dev) for dy in dys]
     if not (ops.fwd_group_ok(4, tuple(x.shape), Co) and ops.dgrad_multi_ok(4, tuple(x.shape), Co)):
