@@ -528,6 +528,19 @@ def test_global_avgpool_and_linear(dev):
     assert_close(bd.grad, br.grad, what="db")
 
 
+def test_global_avgpool_one_wave_per_plane(dev):
+    """ASPP's pooling branch (2048 planes of 32 x 32 per image): gap_fwd_wave_kernel - one wave per plane, 16-byte loads - against
+    torch's float64 mean, and bitwise reproducible."""
+    from weaklysuperviseddl_amd import ops
+    x = torch.randn(2, 2048, 32, 32, generator=torch.Generator().manual_seed(3)) + 0.25
+    xd = x.to(dev)
+    y = ops.global_avg_pool(xd)
+    ref = x.double().mean(dim=(2, 3), keepdim=True)
+    assert tuple(y.shape) == (2, 2048, 1, 1)
+    assert ((y.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-6
+    assert torch.equal(y, ops.global_avg_pool(xd))
+
+
 @pytest.mark.parametrize("shape,size", [((2, 3, 4, 4), (32, 32)), ((1, 2, 14, 14), (224, 224)),
                                         ((2, 5, 1, 1), (8, 8)), ((1, 2, 7, 9), (20, 31)), ((2, 2, 8, 8), (8, 8)),
                                         ((3, 4, 1, 1), (32, 32))])

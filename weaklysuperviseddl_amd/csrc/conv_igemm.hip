@@ -1459,6 +1459,7 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
 }
 
 wsdl::Opt g_conv_il{1};        // 256x128 form: MFMAs and staging instructions interleaved in every wave's stream (conv_split.h, IL)
+wsdl::Opt g_tile64{0};         // 64 x 64 tiles for 128-row layers that give < 400 tiles of 128 x 64 (experiment)
 wsdl::Opt g_tile256{1};        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
 // (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
@@ -1607,7 +1608,13 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     // 256-row tiles only where the rows fill them (>= 90 %: not for 128-channel outputs)
     const bool t256 = cfg == 0 && split && g_tile256 && p.Cout * 10 >= wsdl::cdiv(p.Cout, 256) * 256 * 9 &&
                       (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 256) * p.ksplit >= 256;
-    const int bn_tile = cfg == 0 ? 128 : cfg == 1 ? 64 : cfg == 2 ? 256 : 128;
+    // 64 x 64 tiles (experiment, "tile64"): a 128-row layer at 32 x 32 x 16 is 256 tiles of 128 x 64 - ONE four-wave workgroup per CU,
+    // whose chunks run staging, barrier, fragment reads and MFMAs one after the other (profiles/r05_notes.md); 512 tiles of 64 x 64 put
+    // two workgroups on a CU, out of phase
+    if (cfg == 1 && g_tile64 && split && g_conv_arith >= 1 && g_split_bk32 && p.Cin % 32 == 0 && p.Cout % 64 == 0 && p.ksplit == 1 &&
+        p.nsrc == 0 && (long long)wsdl::cdiv(p.P, 64) * wsdl::cdiv(p.Cout, 128) < kWant)
+        cfg = 4;
+    const int bn_tile = cfg == 0 ? 128 : (cfg == 1 || cfg == 4) ? 64 : cfg == 2 ? 256 : 128;
     double executed = flops;
     if (aligned && wsdl::prof_enabled()) {
         executed = 0.0;
@@ -1619,7 +1626,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     }
     const double bytes = 4.0 * ((double)p.B * p.Cin * p.H * p.W + (double)p.K * p.Cout + (double)p.P * p.Cout * (p.res ? 2 : 1));
     wsdl::ProfScope prof(t256 ? (p.nsrc > 0 ? WSDL_PROF_SPLIT_MULTI : WSDL_PROF_SPLIT_256x128)
-                              : split ? WSDL_PROF_SPLIT_128x128 + cfg : WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1),
+                              : split ? WSDL_PROF_SPLIT_128x128 + (cfg == 4 ? 1 : cfg) : WSDL_PROF_IGEMM_128x128_A + cfg * 2 + (aligned ? 0 : 1),
                          s, flops, executed, bytes);
     {
         ConvP q = p;
@@ -1645,6 +1652,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
             case 0: rc = launch_cfg<128, 128, 2>(q, s, aligned, split); break;
             case 1: rc = launch_cfg<128, 64, 2>(q, s, aligned, split); break;
             case 2: rc = launch_cfg<64, 256, 1>(q, s, aligned, split); break;
+            case 4: rc = launch_split<64, 64, 2, 32>(q, s, dim3(q.grid_x > 0 ? q.grid_x : wsdl::cdiv(q.P, 64), wsdl::cdiv(q.Cout, 64))); break;
             default: rc = launch_cfg<64, 128, 1>(q, s, aligned, split); break;
         }
         if (rc) return rc;
@@ -1995,6 +2003,7 @@ int wsdl_set_option(const char* name, int value) {
     if (!strcmp(name, "split_bk32")) { g_split_bk32 = value != 0; return WSDL_OK; }
     if (!strcmp(name, "ksplit_big")) { g_ksplit_big = value; return WSDL_OK; }
     if (!strcmp(name, "tile256")) { g_tile256 = value; return WSDL_OK; }
+    if (!strcmp(name, "tile64")) { g_tile64 = value; return WSDL_OK; }
     if (!strcmp(name, "conv_il")) { g_conv_il = value != 0; return WSDL_OK; }
     if (!strcmp(name, "tile_img_major")) { g_tile_img_major = value; return WSDL_OK; }
     if (!strcmp(name, "xcd_map")) { g_xcd_map = value; return WSDL_OK; }
