@@ -61,6 +61,8 @@ const char* wsdl_target_arch(void);   /* "gfx950" */
  *   conv_split     1*  0 = forward / input-gradient convolutions on the exact-fp32 MFMA kernels everywhere
  *   wgrad_split    1*  0 = weight gradients on the exact-fp32 MFMA kernels everywhere
  *   tile256        1*  256x128 workgroup tiles (512 threads) where they still give >= 256 workgroups
+ *   tile64         1*  64x64 tiles for layers that give fewer than `tile_threshold` tiles of 128x64 (128 output rows at 32 x 32 x 16):
+ *                      two four-wave workgroups per CU instead of one (round 6: 3-9 % per launch on layer2's convolutions)
  *   split_bk32     1*  K chunks of 32 in the small-tile split forms;   bk32  1*  same for the fp32 kernels
  *   ksplit_big     1*  128x128 tiles + 2 K slices for grids of 200..399 tiles with K >= 2048
  *   tile_threshold 400* workgroups below which the half-size pixel tile is used

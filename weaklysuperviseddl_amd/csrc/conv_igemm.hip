@@ -1459,7 +1459,8 @@ int launch_split(const ConvP& p_in, hipStream_t s, dim3 grid) {
 }
 
 wsdl::Opt g_conv_il{1};        // 256x128 form: MFMAs and staging instructions interleaved in every wave's stream (conv_split.h, IL)
-wsdl::Opt g_tile64{0};         // 64 x 64 tiles for 128-row layers that give < 400 tiles of 128 x 64 (experiment)
+wsdl::Opt g_tile64{1};         // 64 x 64 tiles for 128-row layers that give < 400 tiles of 128 x 64 (round 6): two four-wave workgroups per CU instead of
+                               // one - l2.conv1 forward / l2.conv3 input gradient 20.2 -> 18.3 us, l2.conv2 38.8 -> 37.7 / 38.1 -> 36.6; ~20 us of the step
 wsdl::Opt g_tile256{1};        // 256x128 tiles, 512 threads, one workgroup per CU where that still gives >= 256 workgroups: 4-5 % faster on layer4
                           // (128x256 measured 1 % behind it)
 // (The 256x128 form with K chunks of 32 - "t256_bk32", 169-228 registers and 99-111 KB of LDS - was an option until round 4: faster
@@ -1608,7 +1609,7 @@ int launch_igemm(const ConvP& p_in, hipStream_t s, double flops, void* ws, size_
     // 256-row tiles only where the rows fill them (>= 90 %: not for 128-channel outputs)
     const bool t256 = cfg == 0 && split && g_tile256 && p.Cout * 10 >= wsdl::cdiv(p.Cout, 256) * 256 * 9 &&
                       (long long)wsdl::cdiv(p.P, 128) * wsdl::cdiv(p.Cout, 256) * p.ksplit >= 256;
-    // 64 x 64 tiles (experiment, "tile64"): a 128-row layer at 32 x 32 x 16 is 256 tiles of 128 x 64 - ONE four-wave workgroup per CU,
+    // 64 x 64 tiles ("tile64"): a 128-row layer at 32 x 32 x 16 is 256 tiles of 128 x 64 - ONE four-wave workgroup per CU,
     // whose chunks run staging, barrier, fragment reads and MFMAs one after the other (profiles/r05_notes.md); 512 tiles of 64 x 64 put
     // two workgroups on a CU, out of phase
     if (cfg == 1 && g_tile64 && split && g_conv_arith >= 1 && g_split_bk32 && p.Cin % 32 == 0 && p.Cout % 64 == 0 && p.ksplit == 1 &&
