@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round 5's tree (git archive d6e83c1 -> _r5tree/, built in place) against this tree on ONE box: the training step (cfg2) four times
+# Round 5's tree against this tree on ONE box.  Prepare it first (here, before gpurun snapshots the repository; _r5tree/ is git-ignored):
+#     mkdir _r5tree && git archive d6e83c1 | tar -x -C _r5tree && (cd _r5tree && python -m weaklysuperviseddl_amd._build)
+# then: the training step (cfg2) four times
 # each, interleaved, then cfg3 / cfg5 / CAM once each.   usage: tools/ab_r5_r6.sh  (on the GPU box, from the repository root)
 mkdir -p gpurun_out/r6
 run() {  # label, dir, bench args
